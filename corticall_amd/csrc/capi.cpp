@@ -1,0 +1,287 @@
+// extern "C" surface of libldbg.so (include/ldbg.h).  Every entry point converts C++ exceptions
+// into status codes + a thread-local message; there is no CPU fallback behind any of them.
+#include <string.h>
+
+#include <memory>
+
+#include "cursor.h"
+#include "engine_host.h"
+
+using namespace ldbg;
+
+namespace ldbg {
+void profile_reset_all();
+bool profile_get(const char* family, double* ms, int64_t* n);
+}  // namespace ldbg
+
+struct ldbg_graph { Graph g; ldbg_graph(const std::string& p, const void* img, int64_t n, int dev) : g(p, img, n, dev) {} };
+struct ldbg_links { Links l; ldbg_links(const std::string& p, const Graph& g) : l(p, g) {} };
+struct ldbg_engine {
+    Engine e;
+    std::unique_ptr<CursorHost> cursor;
+    explicit ldbg_engine(const ldbg_engine_config& c) : e(c) {}
+};
+struct ldbg_dfs_result { int unused; };
+
+namespace {
+thread_local std::string g_err;
+template <class F>
+ldbg_status guard(F f) {
+    try { f(); return LDBG_OK; }
+    catch (const StatusError& e) { g_err = e.what(); return (ldbg_status)e.status; }
+    catch (const std::bad_alloc&) { g_err = "out of host memory"; return LDBG_ERR_HIP; }
+    catch (const std::exception& e) { g_err = e.what(); return LDBG_ERR_ARG; }
+}
+// the engine config refers to graphs/links through opaque handles; unwrap them for Engine
+ldbg_engine_config unwrap(const ldbg_engine_config& c, std::vector<const ldbg_links*>& keep) {
+    ldbg_engine_config u = c;
+    u.graph = c.graph ? (const ldbg_graph*)&c.graph->g : nullptr;
+    u.rois = c.rois ? (const ldbg_graph*)&c.rois->g : nullptr;
+    keep.clear();
+    for (int i = 0; i < c.nlinks; i++) keep.push_back(c.links[i] ? (const ldbg_links*)&c.links[i]->l : nullptr);
+    u.links = keep.data();
+    return u;
+}
+}  // namespace
+
+extern "C" {
+
+const char* ldbg_last_error(void) { return g_err.c_str(); }
+const char* ldbg_version(void) { return "ldbg 0.1 (gfx950)"; }
+ldbg_status ldbg_device_count(int* count) { *count = rt::device_count(); return LDBG_OK; }
+
+ldbg_status ldbg_kmer_encode(const char* ascii, int k, uint64_t* words_out) {
+    return guard([&] {
+        if (k <= 0 || k > 128) throw StatusError(LDBG_ERR_ARG, "bad k");
+        if (!ascii_to_words(ascii, k, words_out, (k + 31) / 32))
+            throw StatusError(LDBG_ERR_ARG, "Nucleotide is not a valid character nucleotide");
+    });
+}
+ldbg_status ldbg_kmer_decode(const uint64_t* words, int k, char* ascii_out) {
+    return guard([&] {
+        if (k <= 0 || k > 128) throw StatusError(LDBG_ERR_ARG, "bad k");
+        words_to_ascii(words, k, (k + 31) / 32, ascii_out);
+        ascii_out[k] = 0;
+    });
+}
+
+// ---- graph
+ldbg_status ldbg_graph_open(const char* path, int device, ldbg_graph** out) {
+    return guard([&] { *out = nullptr; *out = new ldbg_graph(path, nullptr, 0, device); });
+}
+ldbg_status ldbg_graph_open_memory(const void* image, int64_t nbytes, int device, ldbg_graph** out) {
+    return guard([&] { *out = nullptr; *out = new ldbg_graph("<memory>", image, nbytes, device); });
+}
+ldbg_status ldbg_graph_close(ldbg_graph* g) { return guard([&] { delete g; }); }
+ldbg_status ldbg_graph_info(const ldbg_graph* g, int* k, int* W, int* C, int64_t* N, int* version) {
+    return guard([&] {
+        if (k) *k = g->g.hdr.k;
+        if (W) *W = g->g.hdr.W;
+        if (C) *C = g->g.hdr.C;
+        if (N) *N = g->g.hdr.num_records;
+        if (version) *version = g->g.hdr.version;
+    });
+}
+ldbg_status ldbg_graph_device(const ldbg_graph* g, int* device) { *device = g->g.device; return LDBG_OK; }
+ldbg_status ldbg_graph_sample_name(const ldbg_graph* g, int color, char* buf, int buflen) {
+    return guard([&] {
+        if (color < 0 || color >= g->g.hdr.C) throw StatusError(LDBG_ERR_ARG, "colour out of range");
+        snprintf(buf, buflen, "%s", g->g.hdr.colors[color].sample_name.c_str());
+    });
+}
+ldbg_status ldbg_graph_color_info(const ldbg_graph* g, int color, ldbg_color_info* out, char* name, int buflen) {
+    return guard([&] {
+        if (color < 0 || color >= g->g.hdr.C) throw StatusError(LDBG_ERR_ARG, "colour out of range");
+        const CtxColor& c = g->g.hdr.colors[color];
+        out->mean_read_length = c.mean_read_length;
+        out->total_sequence = c.total_sequence;
+        out->tip_clipping = c.tip_clipping;
+        out->low_covg_supernodes_removed = c.low_covg_supernodes_removed;
+        out->low_covg_kmers_removed = c.low_covg_kmers_removed;
+        out->cleaned_against_graph = c.cleaned_against_graph;
+        out->low_cov_supernodes_threshold = c.low_cov_supernodes_threshold;
+        out->low_cov_kmer_threshold = c.low_cov_kmer_threshold;
+        if (name) snprintf(name, buflen, "%s", c.cleaned_against_graph_name.c_str());
+    });
+}
+ldbg_status ldbg_graph_color_for_sample_name(const ldbg_graph* g, const char* name, int* color) {
+    return guard([&] { *color = g->g.color_for_sample_name(name); });
+}
+
+ldbg_status ldbg_graph_records_dev(const ldbg_graph* g, int64_t first, int64_t n, uint64_t* d_words, uint32_t* d_cov, uint8_t* d_edges, void* stream) {
+    return guard([&] {
+        if (first < 0 || n < 0 || first + n > g->g.hdr.num_records) throw StatusError(LDBG_ERR_ARG, "record range outside 0.." + std::to_string(g->g.hdr.num_records));
+        rt::set_device(g->g.device);
+        g->g.records_dev(first, n, d_words, d_cov, d_edges, stream ? (rt::stream_t)stream : g->g.stream);
+    });
+}
+ldbg_status ldbg_graph_records(const ldbg_graph* g, int64_t first, int64_t n, uint64_t* words, uint32_t* cov, uint8_t* edges) {
+    return guard([&] {
+        if (first < 0 || n < 0 || first + n > g->g.hdr.num_records) throw StatusError(LDBG_ERR_ARG, "record range outside 0.." + std::to_string(g->g.hdr.num_records));
+        if (n == 0) return;
+        rt::set_device(g->g.device);
+        const int W = g->g.hdr.W, C = g->g.hdr.C;
+        rt::stream_t s = g->g.stream;
+        uint64_t* dw = (uint64_t*)rt::dmalloc((size_t)n * W * 8);
+        uint32_t* dc = cov ? (uint32_t*)rt::dmalloc((size_t)n * C * 4) : nullptr;
+        uint8_t* de = edges ? (uint8_t*)rt::dmalloc((size_t)n * C) : nullptr;
+        g->g.records_dev(first, n, dw, dc, de, s);
+        if (words) rt::d2h(words, dw, (size_t)n * W * 8, s);
+        if (cov) rt::d2h(cov, dc, (size_t)n * C * 4, s);
+        if (edges) rt::d2h(edges, de, (size_t)n * C, s);
+        rt::stream_sync(s);
+        rt::dfree(dw); rt::dfree(dc); rt::dfree(de);
+    });
+}
+
+ldbg_status ldbg_graph_find_dev(const ldbg_graph* g, const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, void* stream) {
+    return guard([&] {
+        rt::set_device(g->g.device);
+        g->g.find_dev(d_packed, n, d_idx, d_cov, d_edges, stream ? (rt::stream_t)stream : g->g.stream);
+    });
+}
+ldbg_status ldbg_graph_find(const ldbg_graph* g, const uint64_t* packed, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {
+    return guard([&] {
+        if (n <= 0) return;
+        rt::set_device(g->g.device);
+        const int W = g->g.hdr.W, C = g->g.hdr.C;
+        rt::stream_t s = g->g.stream;
+        uint64_t* dq = (uint64_t*)rt::dmalloc((size_t)n * W * 8);
+        int64_t* di = (int64_t*)rt::dmalloc((size_t)n * 8);
+        uint32_t* dc = cov_out ? (uint32_t*)rt::dmalloc((size_t)n * C * 4) : nullptr;
+        uint8_t* de = edges_out ? (uint8_t*)rt::dmalloc((size_t)n * C) : nullptr;
+        rt::h2d(dq, packed, (size_t)n * W * 8, s);
+        g->g.find_dev(dq, n, di, dc, de, s);
+        rt::d2h(idx_out, di, (size_t)n * 8, s);
+        if (cov_out) rt::d2h(cov_out, dc, (size_t)n * C * 4, s);
+        if (edges_out) rt::d2h(edges_out, de, (size_t)n * C, s);
+        rt::stream_sync(s);
+        rt::dfree(dq); rt::dfree(di); rt::dfree(dc); rt::dfree(de);
+    });
+}
+ldbg_status ldbg_graph_find_ascii(const ldbg_graph* g, const char* kmers, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {
+    return guard([&] {
+        const int W = g->g.hdr.W, k = g->g.hdr.k;
+        std::vector<uint64_t> packed((size_t)n * W);
+        for (int64_t i = 0; i < n; i++)
+            if (!ascii_to_words(kmers + i * k, k, &packed[i * W], W)) packed[i * W] = ~0ull;   // Q4: non-ACGT never matches
+        ldbg_status st = ldbg_graph_find(g, packed.data(), n, idx_out, cov_out, edges_out);
+        if (st != LDBG_OK) throw StatusError(st, g_err);
+    });
+}
+
+// ---- links
+ldbg_status ldbg_links_open(const char* path, const ldbg_graph* g, ldbg_links** out) {
+    return guard([&] { *out = nullptr; *out = new ldbg_links(path, g->g); });
+}
+ldbg_status ldbg_links_close(ldbg_links* l) { return guard([&] { delete l; }); }
+ldbg_status ldbg_links_info(const ldbg_links* l, int* version, int* num_colors, int* k, int64_t* nkg, int64_t* nkl, int64_t* nl) {
+    return guard([&] {
+        if (version) *version = l->l.version;
+        if (num_colors) *num_colors = l->l.num_colors;
+        if (k) *k = l->l.k;
+        if (nkg) *nkg = l->l.num_kmers_in_graph;
+        if (nkl) *nkl = l->l.num_kmers_with_links;
+        if (nl) *nl = l->l.num_links;
+    });
+}
+ldbg_status ldbg_links_sample_name(const ldbg_links* l, int color, char* buf, int buflen) {
+    return guard([&] {
+        if (color < 0 || color >= (int)l->l.sample_names.size()) throw StatusError(LDBG_ERR_ARG, "colour out of range");
+        snprintf(buf, buflen, "%s", l->l.sample_names[color].c_str());
+    });
+}
+ldbg_status ldbg_links_get(const ldbg_links* l, const char* kmer, int* found, char* buf, int64_t buflen) {
+    return guard([&] {
+        const HostLinksRecord* r = l->l.get(std::string(kmer, l->l.k));
+        *found = r ? 1 : 0;
+        std::string s;
+        if (r) {
+            s = r->kmer + " " + std::to_string(r->juncs.size()) + "\n";
+            for (auto& j : r->juncs) {
+                s += j.is_fw ? "F " : "R ";
+                s += std::to_string(j.num_junctions) + " ";
+                for (size_t c = 0; c < j.cov.size(); c++) { if (c) s += ","; s += std::to_string(j.cov[c]); }
+                s += " " + j.junctions + "\n";
+            }
+        }
+        if ((int64_t)s.size() + 1 > buflen) throw StatusError(LDBG_ERR_CAPACITY, "buffer too small: need " + std::to_string(s.size() + 1));
+        memcpy(buf, s.c_str(), s.size() + 1);
+    });
+}
+
+// ---- engine
+void ldbg_engine_config_default(ldbg_engine_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->direction = LDBG_DIR_BOTH;
+    c->combination_operator = LDBG_OP_OR;
+    c->stopping_rule = LDBG_STOP_CONTIG;
+    c->max_branch_length = 75000;
+    c->connect_all_neighbors = 0;
+    c->strict_java_flip = 1;
+}
+ldbg_status ldbg_engine_create(const ldbg_engine_config* cfg, ldbg_engine** out) {
+    return guard([&] {
+        *out = nullptr;
+        if (cfg->n_traversal > LDBG_MAX_COLORS || cfg->n_joining > LDBG_MAX_COLORS || cfg->n_recruitment > LDBG_MAX_COLORS || cfg->n_secondary > LDBG_MAX_COLORS)
+            throw StatusError(LDBG_ERR_ARG, "too many colours");
+        std::vector<const ldbg_links*> keep;
+        ldbg_engine_config u = unwrap(*cfg, keep);
+        *out = new ldbg_engine(u);
+    });
+}
+ldbg_status ldbg_engine_destroy(ldbg_engine* e) { return guard([&] { delete e; }); }
+
+ldbg_status ldbg_engine_walk_batch_run(ldbg_engine* e, const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
+    return guard([&] {
+        // a full per-walk link store is retried with a larger one (exactness is never traded away)
+        for (int attempt = 0;; attempt++) {
+            try { e->e.walk_batch_run(seeds, n, total_bytes, traversed); return; }
+            catch (const StatusError& se) {
+                if (se.status == LDBG_ERR_CAPACITY && std::string(se.what()) == "LINKSTORE_FULL" && attempt < 8) { e->e.link_store_capacity *= 4; continue; }
+                throw;
+            }
+        }
+    });
+}
+ldbg_status ldbg_engine_walk_batch_fetch(ldbg_engine* e, char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len) {
+    return guard([&] { e->e.walk_batch_fetch(arena, cap, offsets, walk_len); });
+}
+ldbg_status ldbg_engine_walk_batch(ldbg_engine* e, const char* seeds, int64_t n, char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len, int64_t* traversed) {
+    int64_t total = 0;
+    ldbg_status st = ldbg_engine_walk_batch_run(e, seeds, n, &total, traversed);
+    if (st != LDBG_OK) return st;
+    return ldbg_engine_walk_batch_fetch(e, arena, cap, offsets, walk_len);
+}
+ldbg_status ldbg_engine_walk_vertices(ldbg_engine* e, int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index) {
+    return guard([&] { e->e.walk_vertices(walk, capacity, len, words, rec, copy, index); });
+}
+
+ldbg_status ldbg_engine_dfs_batch(ldbg_engine*, const char*, int64_t, const char*, const int64_t*, ldbg_dfs_result** out) {
+    return guard([&] { *out = nullptr; throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: the general DFS kernel is not built yet (DESIGN.md §Scope)"); });
+}
+ldbg_status ldbg_dfs_result_sizes(const ldbg_dfs_result*, int64_t, int*, int64_t*, int64_t*) { g_err = "no dfs result"; return LDBG_ERR_UNSUPPORTED; }
+ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result*, int64_t, uint64_t*, int64_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*) { g_err = "no dfs result"; return LDBG_ERR_UNSUPPORTED; }
+ldbg_status ldbg_dfs_result_walk(const ldbg_dfs_result*, int64_t, const char*, int, char*, int64_t, int64_t*) { g_err = "no dfs result"; return LDBG_ERR_UNSUPPORTED; }
+ldbg_status ldbg_dfs_result_free(ldbg_dfs_result* r) { delete r; return LDBG_OK; }
+ldbg_status ldbg_engine_dfs_kmers_traversed(const ldbg_engine*, int64_t* n) { *n = 0; return LDBG_OK; }
+
+// ---- cursor
+static CursorHost& cursor_of(ldbg_engine* e) {
+    if (!e->cursor) e->cursor.reset(new CursorHost(e->e));
+    return *e->cursor;
+}
+ldbg_status ldbg_engine_seek(ldbg_engine* e, const char* kmer) { return guard([&] { cursor_of(e).seek(kmer); }); }
+ldbg_status ldbg_engine_has_next(ldbg_engine* e, int* yes) { return guard([&] { *yes = cursor_of(e).has(true) ? 1 : 0; }); }
+ldbg_status ldbg_engine_has_previous(ldbg_engine* e, int* yes) { return guard([&] { *yes = cursor_of(e).has(false) ? 1 : 0; }); }
+ldbg_status ldbg_engine_next(ldbg_engine* e, char* kmer_out, int64_t* rec_out) { return guard([&] { cursor_of(e).step(true, kmer_out, rec_out); }); }
+ldbg_status ldbg_engine_previous(ldbg_engine* e, char* kmer_out, int64_t* rec_out) { return guard([&] { cursor_of(e).step(false, kmer_out, rec_out); }); }
+
+// ---- measurement
+ldbg_status ldbg_profile_reset(void) { profile_reset_all(); return LDBG_OK; }
+ldbg_status ldbg_profile_get(const char* family, double* total_ms, int64_t* launches) {
+    profile_get(family, total_ms, launches);
+    return LDBG_OK;
+}
+
+}  // extern "C"

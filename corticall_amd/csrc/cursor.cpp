@@ -1,0 +1,198 @@
+// Stateful cursor API: TraversalEngine.seek / next / previous / hasNext / hasPrevious
+// (J/utils/traversal/TraversalEngine.java:241-339).  The state lives in HBM; each call is a
+// one-thread kernel that reuses the device primitives of the batched walk (engine.h), so the cursor
+// and the walk cannot drift apart.
+#include "cursor.h"
+
+namespace ldbg {
+
+template <int W>
+struct CursorStateDev {
+    VRef<W> cur;
+    Adj<W> acur;
+    VRef<W> nxt, prv;
+    uint32_t has_next, has_prev, first, go_forward, status;
+    uint32_t ls_n, ls_java_cap, ls_nkeys, ls_next_seq;
+    uint32_t gen;
+    // outputs of the last step
+    uint64_t out_words[W];
+    int64_t out_rec;
+};
+
+template <int W>
+LDBG_DEV void cs_reseek(const EngineView& e, CursorStateDev<W>& st) {
+    // seek(sk) :321-335 — unique neighbours, fresh LinkStore, fresh `seen`
+    adj_of<W>(e, st.cur, st.acur);
+    st.has_next = popc4(st.acur.next_mask) == 1;
+    if (st.has_next) st.nxt = vref_find<W>(e, neighbour<W>(st.acur, e.g.k, true, lowbit4(st.acur.next_mask)));
+    st.has_prev = popc4(st.acur.prev_mask) == 1;
+    if (st.has_prev) st.prv = vref_find<W>(e, neighbour<W>(st.acur, e.g.k, false, lowbit4(st.acur.prev_mask)));
+    st.ls_n = st.ls_java_cap = st.ls_nkeys = st.ls_next_seq = 0;
+    st.first = 1;
+    st.gen++;
+    st.status = st.acur.npe ? (uint32_t)ST_NULLPTR : (uint32_t)ST_OK;
+}
+
+template <int W>
+LDBG_KERNEL void k_cursor_seek(EngineView e, CursorStateDev<W>* stp, const uint64_t* words, uint64_t* vtab, uint32_t vcap) {
+    if (global_tid() != 0) return;
+    CursorStateDev<W>& st = *stp;
+    Kmer<W> sk;
+    for (int i = 0; i < W; i++) sk.w[i] = words[i];
+    if (words[0] != ~0ull) st.cur = vref_find<W>(e, sk);
+    else { st.cur.sk = sk; st.cur.idx = -1; st.cur.flip = false; st.cur.copy = 0; }
+    if (st.gen >= 32766u) { for (uint32_t i = 0; i < vcap; i++) vtab[i] = 0; st.gen = 0; }
+    if (words[0] == ~0ull) {
+        st.acur.idx = -1; st.acur.flip = false; st.acur.o = sk; st.acur.next_mask = st.acur.prev_mask = 0;
+        st.acur.npe = e.recruit_mask != 0;
+        st.has_next = st.has_prev = 0;
+        st.ls_n = st.ls_java_cap = st.ls_nkeys = st.ls_next_seq = 0;
+        st.first = 1; st.gen++;
+        st.status = st.acur.npe ? (uint32_t)ST_NULLPTR : (uint32_t)ST_OK;
+    } else {
+        cs_reseek<W>(e, st);
+    }
+}
+
+template <int W>
+LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, uint64_t* vtab, uint32_t vcap, LsElem* els, uint32_t ecap) {
+    if (global_tid() != 0) return;
+    CursorStateDev<W>& st = *stp;
+    const bool fwd = fwd_i != 0;
+    st.status = ST_OK;
+    if (st.first || (st.go_forward != 0) != fwd) {      // :243-248 / :283-288
+        st.go_forward = fwd ? 1 : 0;
+        cs_reseek<W>(e, st);
+        if (st.status != ST_OK) return;
+    }
+    VisitedTable vt;
+    vt.tab = vtab; vt.mask = vcap - 1; vt.gen = st.gen;
+    LinkStoreDev ls;
+    ls.el = els; ls.cap = ecap; ls.n = st.ls_n; ls.java_cap = st.ls_java_cap; ls.nkeys = st.ls_nkeys; ls.next_seq = st.ls_next_seq;
+    ls.overflow = false;
+    Cursor<W> cu;
+    cu.cur = st.cur; cu.acur = st.acur; cu.first = st.first != 0; cu.status = ST_OK;
+    cu.has = fwd ? st.has_next != 0 : st.has_prev != 0;
+    if (!cu.has) { st.status = ST_NULLPTR; return; }   // target vanished after the re-seek: NPE in the reference
+    cu.nxt = fwd ? st.nxt : st.prv;
+    VRef<W> old = st.cur;
+    VRef<W> t = cursor_step<W>(e, cu, ls, vt, fwd);
+    st.first = 0;
+    st.cur = cu.cur; st.acur = cu.acur;
+    if (fwd) { st.prv = old; st.has_prev = 1; st.nxt = cu.nxt; st.has_next = cu.has ? 1 : 0; }
+    else { st.nxt = old; st.has_next = 1; st.prv = cu.nxt; st.has_prev = cu.has ? 1 : 0; }
+    st.ls_n = ls.n; st.ls_java_cap = ls.java_cap; st.ls_nkeys = ls.nkeys; st.ls_next_seq = ls.next_seq;
+    st.status = cu.status;
+    for (int i = 0; i < W; i++) st.out_words[i] = t.sk.w[i];
+    st.out_rec = t.idx;
+}
+
+// ------------------------------------------------------------------ host
+struct CursorHost::Impl {
+    void* d_state = nullptr;
+    void* d_vtab = nullptr;
+    void* d_ls = nullptr;
+    void* d_words = nullptr;
+    uint32_t vcap = 1u << 16, ecap = 256;
+    size_t state_bytes = 0;
+    bool sought = false;
+};
+
+template <int W>
+static size_t state_size() { return sizeof(CursorStateDev<W>); }
+
+CursorHost::CursorHost(Engine& e) : eng_(e), impl_(new Impl) {
+    rt::set_device(e.graph->device);
+    const int W = e.graph->hdr.W;
+    impl_->state_bytes = W == 1 ? state_size<1>() : W == 2 ? state_size<2>() : W == 3 ? state_size<3>() : state_size<4>();
+    impl_->d_state = rt::dmalloc(impl_->state_bytes);
+    impl_->d_vtab = rt::dmalloc((size_t)impl_->vcap * 8);
+    impl_->d_ls = rt::dmalloc((size_t)impl_->ecap * sizeof(LsElem));
+    impl_->d_words = rt::dmalloc((size_t)W * 8);
+    rt::dmemset(impl_->d_state, 0, impl_->state_bytes, e.graph->stream);
+    rt::dmemset(impl_->d_vtab, 0, (size_t)impl_->vcap * 8, e.graph->stream);
+    rt::stream_sync(e.graph->stream);
+}
+CursorHost::~CursorHost() {
+    rt::dfree(impl_->d_state); rt::dfree(impl_->d_vtab); rt::dfree(impl_->d_ls); rt::dfree(impl_->d_words);
+    delete impl_;
+}
+
+template <int W>
+static void read_state(void* d, CursorStateDev<W>& h, rt::stream_t s) {
+    rt::d2h(&h, d, sizeof(h), s);
+    rt::stream_sync(s);
+}
+
+void CursorHost::check_status(uint32_t st) {
+    if (st == ST_NULLPTR) throw StatusError(LDBG_ERR_NULLPOINTER, "cursor dereferenced a missing record / vanished target (NullPointerException in the reference)");
+    if (st == ST_LINKSTORE_FULL) throw StatusError(LDBG_ERR_CAPACITY, "cursor link store capacity exceeded");
+}
+
+void CursorHost::seek(const char* kmer) {
+    rt::set_device(eng_.graph->device);
+    const int W = eng_.graph->hdr.W, k = eng_.graph->hdr.k;
+    rt::stream_t s = eng_.graph->stream;
+    std::vector<uint64_t> w(W);
+    if (!ascii_to_words(kmer, k, w.data(), W)) w[0] = ~0ull;
+    rt::h2d(impl_->d_words, w.data(), (size_t)W * 8, s);
+    switch (W) {
+        case 1: LDBG_LAUNCH(k_cursor_seek<1>, 1, 64, s, eng_.view, (CursorStateDev<1>*)impl_->d_state, (const uint64_t*)impl_->d_words, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
+        case 2: LDBG_LAUNCH(k_cursor_seek<2>, 1, 64, s, eng_.view, (CursorStateDev<2>*)impl_->d_state, (const uint64_t*)impl_->d_words, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
+        case 3: LDBG_LAUNCH(k_cursor_seek<3>, 1, 64, s, eng_.view, (CursorStateDev<3>*)impl_->d_state, (const uint64_t*)impl_->d_words, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
+        default: LDBG_LAUNCH(k_cursor_seek<4>, 1, 64, s, eng_.view, (CursorStateDev<4>*)impl_->d_state, (const uint64_t*)impl_->d_words, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
+    }
+    rt::stream_sync(s);
+    impl_->sought = true;
+    bool hn, hp;
+    uint32_t st;
+    peek(&hn, &hp, &st, nullptr, nullptr);
+    check_status(st);
+}
+
+void CursorHost::peek(bool* has_next, bool* has_prev, uint32_t* status, uint64_t* out_words, int64_t* out_rec) {
+    const int W = eng_.graph->hdr.W;
+    rt::stream_t s = eng_.graph->stream;
+#define LDBG_PEEK(WW)                                                                       \
+    {                                                                                       \
+        CursorStateDev<WW> h;                                                               \
+        read_state<WW>(impl_->d_state, h, s);                                               \
+        *has_next = h.has_next != 0; *has_prev = h.has_prev != 0; *status = h.status;       \
+        if (out_words) for (int i = 0; i < WW; i++) out_words[i] = h.out_words[i];          \
+        if (out_rec) *out_rec = h.out_rec;                                                  \
+    }
+    switch (W) { case 1: LDBG_PEEK(1) break; case 2: LDBG_PEEK(2) break; case 3: LDBG_PEEK(3) break; default: LDBG_PEEK(4) break; }
+#undef LDBG_PEEK
+}
+
+bool CursorHost::has(bool fwd) {
+    rt::set_device(eng_.graph->device);
+    if (!impl_->sought) return false;
+    bool hn, hp; uint32_t st;
+    peek(&hn, &hp, &st, nullptr, nullptr);
+    return fwd ? hn : hp;
+}
+
+void CursorHost::step(bool fwd, char* kmer_out, int64_t* rec_out) {
+    rt::set_device(eng_.graph->device);
+    const int W = eng_.graph->hdr.W, k = eng_.graph->hdr.k;
+    if (!has(fwd))
+        throw StatusError(LDBG_ERR_NOSUCHELEMENT, std::string("No single ") + (fwd ? "advance" : "prev") + " kmer from cursor");
+    rt::stream_t s = eng_.graph->stream;
+    switch (W) {
+        case 1: LDBG_LAUNCH(k_cursor_step<1>, 1, 64, s, eng_.view, (CursorStateDev<1>*)impl_->d_state, fwd ? 1 : 0, (uint64_t*)impl_->d_vtab, impl_->vcap, (LsElem*)impl_->d_ls, impl_->ecap); break;
+        case 2: LDBG_LAUNCH(k_cursor_step<2>, 1, 64, s, eng_.view, (CursorStateDev<2>*)impl_->d_state, fwd ? 1 : 0, (uint64_t*)impl_->d_vtab, impl_->vcap, (LsElem*)impl_->d_ls, impl_->ecap); break;
+        case 3: LDBG_LAUNCH(k_cursor_step<3>, 1, 64, s, eng_.view, (CursorStateDev<3>*)impl_->d_state, fwd ? 1 : 0, (uint64_t*)impl_->d_vtab, impl_->vcap, (LsElem*)impl_->d_ls, impl_->ecap); break;
+        default: LDBG_LAUNCH(k_cursor_step<4>, 1, 64, s, eng_.view, (CursorStateDev<4>*)impl_->d_state, fwd ? 1 : 0, (uint64_t*)impl_->d_vtab, impl_->vcap, (LsElem*)impl_->d_ls, impl_->ecap); break;
+    }
+    rt::stream_sync(s);
+    bool hn, hp; uint32_t st;
+    std::vector<uint64_t> w(W);
+    int64_t rec = -1;
+    peek(&hn, &hp, &st, w.data(), &rec);
+    check_status(st);
+    if (kmer_out) { words_to_ascii(w.data(), k, W, kmer_out); kmer_out[k] = 0; }
+    if (rec_out) *rec_out = rec;
+}
+
+}  // namespace ldbg

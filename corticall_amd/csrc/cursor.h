@@ -1,0 +1,23 @@
+#pragma once
+#include "engine_host.h"
+
+namespace ldbg {
+
+// host handle of the device-resident cursor of one engine (TraversalEngine.java:241-339)
+class CursorHost {
+public:
+    explicit CursorHost(Engine& e);
+    ~CursorHost();
+    void seek(const char* kmer);
+    bool has(bool fwd);
+    void step(bool fwd, char* kmer_out, int64_t* rec_out);
+
+private:
+    struct Impl;
+    Engine& eng_;
+    Impl* impl_;
+    void peek(bool* has_next, bool* has_prev, uint32_t* status, uint64_t* out_words, int64_t* out_rec);
+    static void check_status(uint32_t st);
+};
+
+}  // namespace ldbg

@@ -1,0 +1,54 @@
+// Host side of the engine: configuration validation (TraversalEngineFactory.make), batching,
+// device scratch management and result storage.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace ldbg {
+
+struct WalkChunk {
+    int64_t first = 0, n = 0;              // seeds [first, first+n)
+    void* d_path = nullptr;                // dense u64 path entries of all strands of the chunk
+    std::vector<int64_t> strand_off;       // [2n+1] offsets into d_path (strand 2i = reverse, 2i+1 = forward)
+    std::vector<uint32_t> status;          // [2n]
+    void* d_contigs = nullptr;             // dense ASCII contigs
+    std::vector<int64_t> contig_off;       // [n+1]
+    std::vector<int64_t> walk_len;         // [n]
+    void* d_seed_words = nullptr;          // [n][W]
+    void* d_term = nullptr;                // [2n][W] k-mer of a trailing null-record vertex
+    std::vector<uint8_t> seed_ok;          // toWalk seed test: record present and coverage > 0
+};
+
+class Engine {
+public:
+    explicit Engine(const ldbg_engine_config& cfg);
+    ~Engine();
+    const Graph* graph = nullptr;
+    const Graph* rois = nullptr;
+    std::vector<const Links*> my_links;   // link sets whose colour-0 sample is a traversal sample (:553-557)
+    ldbg_engine_config cfg{};
+    EngineView view{};
+
+    void walk_batch_run(const char* seeds, int64_t n, int64_t* total_contig_bytes, int64_t* kmers_traversed);
+    void walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len);
+    void walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index);
+    void clear_batch();
+
+    int64_t batch_n = 0, batch_bytes = 0, batch_traversed = 0;
+    std::vector<WalkChunk> chunks;
+    uint32_t link_store_capacity = 64;
+
+private:
+    // per-slot scratch kept across batches: visited tables, link stores, table generations
+    void* d_vtabs_ = nullptr; void* d_ls_ = nullptr; void* d_slot_gen_ = nullptr;
+    int64_t n_slots_ = 0;
+    uint32_t vcap_ = 0, ecap_ = 0;
+    void ensure_scratch(int64_t want_slots, uint32_t vcap, uint32_t ecap);
+    void release_scratch();
+    void run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);
+};
+
+}  // namespace ldbg

@@ -1,0 +1,298 @@
+// Device graph: streaming upload of .ctx records, layout kernels, sortedness check, radix index,
+// and the two bulk DeBruijnGraph kernels (records = iteration/getRecord, find = findRecord).
+#include "graph.h"
+
+#include <fcntl.h>
+#include <strings.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+
+namespace ldbg {
+
+// ------------------------------------------------------------------ profile registry
+namespace {
+std::mutex g_prof_mu;
+std::map<std::string, std::pair<double, int64_t>> g_prof;
+}  // namespace
+void profile_add(const char* family, double ms) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    auto& e = g_prof[family];
+    e.first += ms;
+    e.second += 1;
+}
+void profile_reset_all() {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    g_prof.clear();
+}
+bool profile_get(const char* family, double* ms, int64_t* n) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    auto it = g_prof.find(family);
+    if (it == g_prof.end()) { *ms = 0; *n = 0; return false; }
+    *ms = it->second.first; *n = it->second.second;
+    return true;
+}
+
+// ------------------------------------------------------------------ kernels
+// One thread per record of a raw chunk (file layout: W×u64 LE key | C×u32 LE cov | C×u8 edges,
+// record_size = 8W+5C bytes, unaligned).  Writes the SoA arrays and the probe row.
+LDBG_KERNEL void k_layout(const uint8_t* raw, int64_t first, int64_t n, int64_t N, int W, int C, int rec_size,
+                          uint64_t* keys, uint32_t* cov, uint8_t* edges, uint8_t* probe, int stride, int edges_off,
+                          int cov_off) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        const uint8_t* r = raw + i * rec_size;
+        int64_t gi = first + i;
+        uint8_t* row = probe + (size_t)gi * (size_t)stride;
+        for (int w = 0; w < W; w++) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; b++) v |= (uint64_t)r[8 * w + b] << (8 * b);
+            keys[(size_t)w * (size_t)N + (size_t)gi] = v;
+            ((uint64_t*)row)[w] = v;
+        }
+        const uint8_t* rc = r + 8 * W;
+        for (int c = 0; c < C; c++) {
+            uint32_t v = (uint32_t)rc[4 * c] | ((uint32_t)rc[4 * c + 1] << 8) | ((uint32_t)rc[4 * c + 2] << 16) | ((uint32_t)rc[4 * c + 3] << 24);
+            cov[(size_t)c * (size_t)N + (size_t)gi] = v;
+            ((uint32_t*)(row + cov_off))[c] = v;
+        }
+        const uint8_t* re = rc + 4 * C;
+        for (int c = 0; c < C; c++) {
+            edges[(size_t)c * (size_t)N + (size_t)gi] = re[c];
+            row[edges_off + c] = re[c];
+        }
+        for (int b = edges_off + C; b < cov_off; b++) row[b] = 0;
+        for (int b = cov_off + 4 * C; b < stride; b++) row[b] = 0;
+    }
+}
+
+// first index i >= 1 with key[i-1] >= key[i] (records must be strictly ascending), else ~0
+LDBG_KERNEL void k_verify_sorted(const uint64_t* keys, int64_t N, int W, unsigned long long* first_bad) {
+    for (int64_t i = global_tid() + 1; i < N; i += global_nthreads()) {
+        int cmp = 0;
+        for (int w = 0; w < W && cmp == 0; w++) {
+            uint64_t a = keys[(size_t)w * N + i - 1], b = keys[(size_t)w * N + i];
+            cmp = a < b ? -1 : (a > b ? 1 : 0);
+        }
+        if (cmp >= 0) atomic_min_u64(first_bad, (unsigned long long)i);
+    }
+}
+
+template <int W>
+LDBG_KERNEL void k_prefix_index(GraphView g, uint32_t* pstart) {
+    const uint32_t np = 1u << (2 * g.p);
+    for (int64_t i = global_tid(); i <= g.N; i += global_nthreads()) {
+        // entries (prev_px, px] := i ; thread N fills the tail
+        int64_t lo, hi;
+        if (i == g.N) {
+            lo = g.N == 0 ? 0 : (int64_t)kmer_prefix<W>(graph_key<W>(g, g.N - 1), g.k, g.p) + 1;
+            hi = (int64_t)np;
+        } else {
+            hi = (int64_t)kmer_prefix<W>(graph_key<W>(g, i), g.k, g.p);
+            lo = i == 0 ? 0 : (int64_t)kmer_prefix<W>(graph_key<W>(g, i - 1), g.k, g.p) + 1;
+        }
+        for (int64_t x = lo; x <= hi; x++) pstart[x] = (uint32_t)i;
+    }
+}
+
+// Iterator<CortexRecord> / getRecord in bulk: SoA -> caller arrays (n×W, n×C, n×C)
+LDBG_KERNEL void k_records(GraphView g, int64_t first, int64_t n, uint64_t* words, uint32_t* cov, uint8_t* edges) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        int64_t gi = first + i;
+        for (int w = 0; w < g.W; w++) words[i * g.W + w] = g.keys[(size_t)w * g.N + gi];
+        if (cov) for (int c = 0; c < g.C; c++) cov[i * g.C + c] = g.cov[(size_t)c * g.N + gi];
+        if (edges) for (int c = 0; c < g.C; c++) edges[i * g.C + c] = g.edges[(size_t)c * g.N + gi];
+    }
+}
+
+// findRecord in bulk: one query per lane; canonicalise in registers, radix index, block search
+template <int W>
+LDBG_KERNEL void k_find(GraphView g, const uint64_t* packed, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        Kmer<W> q;
+#pragma unroll
+        for (int w = 0; w < W; w++) q.w[w] = packed[i * W + w];
+        int64_t idx = -1;
+        // a word with bits above 2k set marks "not a k-mer" (non-ACGT ASCII query, Q4)
+        const int top = 2 * g.k - 64 * (W - 1);
+        bool valid = top >= 64 || (q.w[0] >> top) == 0;
+        if (valid) {
+            bool f;
+            Kmer<W> c = kmer_canonical<W>(q, g.k, &f);
+            idx = graph_find_canonical<W>(g, c);
+        }
+        idx_out[i] = idx;
+        if (cov_out) for (int c = 0; c < g.C; c++) cov_out[i * g.C + c] = idx >= 0 ? graph_cov(g, idx, c) : 0u;
+        if (edges_out) for (int c = 0; c < g.C; c++) edges_out[i * g.C + c] = idx >= 0 ? graph_edges(g, idx, c) : (uint8_t)0;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 8) {
+    int64_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+Graph::Graph(const std::string& p, const void* image, int64_t nbytes, int dev) : device(dev), path(p) {
+    if (rt::device_count() <= dev) throw StatusError(LDBG_ERR_HIP, "no HIP device " + std::to_string(dev) + " available (libldbg has no CPU fallback)");
+    rt::set_device(dev);
+    const uint8_t* base = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    void* map = nullptr;
+    if (image) {
+        base = (const uint8_t*)image;
+        size = (size_t)nbytes;
+    } else {
+        fd = ::open(p.c_str(), O_RDONLY);
+        if (fd < 0) throw StatusError(LDBG_ERR_CORTEXJDK, "Cortex graph file '" + p + "' not found");
+        struct stat st;
+        fstat(fd, &st);
+        size = (size_t)st.st_size;
+        if (size > 0) {
+            map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map == MAP_FAILED) { ::close(fd); throw StatusError(LDBG_ERR_CORTEXJDK, "Error while parsing Cortex graph file '" + p + "': mmap failed"); }
+            base = (const uint8_t*)map;
+        }
+    }
+    try {
+        hdr = parse_ctx_header(base, size, (int64_t)size, p);
+        if (hdr.W > 4) throw StatusError(LDBG_ERR_UNSUPPORTED, "k > 128 is not supported (k=" + std::to_string(hdr.k) + ")");
+        if (hdr.num_records >= (1LL << 32)) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than 2^32-1 records per device shard");
+        stream = rt::stream_create();
+        upload(base + hdr.data_offset);
+    } catch (...) {
+        if (map) munmap(map, size);
+        if (fd >= 0) ::close(fd);
+        throw;
+    }
+    if (map) munmap(map, size);
+    if (fd >= 0) ::close(fd);
+}
+
+void Graph::upload(const uint8_t* recs) {
+    const int64_t N = hdr.num_records;
+    const int W = hdr.W, C = hdr.C;
+    view.k = hdr.k; view.W = W; view.C = C; view.N = N;
+    view.edges_off = 8 * W;
+    view.cov_off = 8 * W + ((C + 3) / 4) * 4;
+    view.stride = ((view.cov_off + 4 * C + 15) / 16) * 16;
+    // radix index width: ~1-2 records per block for uniform k-mers, capped so the table stays cache-sized
+    int p = 1;
+    while (p < hdr.k && p < 13 && (1LL << (2 * (p + 1))) <= std::max<int64_t>(N, 1)) p++;
+    view.p = p;
+    view.java_tiny = N <= 2 ? 1 : 0;
+
+    d_keys_ = rt::dmalloc((size_t)N * W * 8);
+    d_cov_ = rt::dmalloc((size_t)N * C * 4);
+    d_edges_ = rt::dmalloc((size_t)N * C);
+    d_probe_ = rt::dmalloc((size_t)N * view.stride);
+    d_pstart_ = rt::dmalloc(((size_t)1 << (2 * p)) * 4 + 4);
+    view.keys = (const uint64_t*)d_keys_;
+    view.cov = (const uint32_t*)d_cov_;
+    view.edges = (const uint8_t*)d_edges_;
+    view.probe = (const uint8_t*)d_probe_;
+    view.pstart = (const uint32_t*)d_pstart_;
+
+    // stream the records: pinned double buffer -> raw device chunk -> layout kernel
+    const int64_t chunk_recs = std::max<int64_t>(1, (64LL << 20) / hdr.record_size);
+    const size_t chunk_bytes = (size_t)chunk_recs * hdr.record_size;
+    void* pin[2] = {rt::hmalloc_pinned(chunk_bytes), rt::hmalloc_pinned(chunk_bytes)};
+    void* raw[2] = {rt::dmalloc(chunk_bytes), rt::dmalloc(chunk_bytes)};
+    rt::stream_t s2[2] = {rt::stream_create(), rt::stream_create()};
+    try {
+        int b = 0;
+        for (int64_t first = 0; first < N; first += chunk_recs, b ^= 1) {
+            int64_t n = std::min(chunk_recs, N - first);
+            rt::stream_sync(s2[b]);   // buffer b free again
+            memcpy(pin[b], recs + first * hdr.record_size, (size_t)n * hdr.record_size);
+            rt::h2d(raw[b], pin[b], (size_t)n * hdr.record_size, s2[b]);
+            LDBG_LAUNCH(k_layout, grid_for(n), 256, s2[b], (const uint8_t*)raw[b], first, n, N, W, C, (int)hdr.record_size,
+                        (uint64_t*)d_keys_, (uint32_t*)d_cov_, (uint8_t*)d_edges_, (uint8_t*)d_probe_, view.stride,
+                        view.edges_off, view.cov_off);
+        }
+        rt::stream_sync(s2[0]);
+        rt::stream_sync(s2[1]);
+    } catch (...) {
+        for (int i = 0; i < 2; i++) { rt::hfree_pinned(pin[i]); rt::dfree(raw[i]); rt::stream_destroy(s2[i]); }
+        throw;
+    }
+    for (int i = 0; i < 2; i++) { rt::hfree_pinned(pin[i]); rt::dfree(raw[i]); rt::stream_destroy(s2[i]); }
+
+    // strictly ascending? (the reference throws "Records are not sorted" lazily, CortexGraph.java:295-301)
+    unsigned long long* d_bad = (unsigned long long*)rt::dmalloc(8);
+    unsigned long long bad = ~0ULL;
+    rt::h2d(d_bad, &bad, 8, stream);
+    LDBG_LAUNCH(k_verify_sorted, grid_for(N), 256, stream, (const uint64_t*)d_keys_, N, W, d_bad);
+    rt::d2h(&bad, d_bad, 8, stream);
+    rt::stream_sync(stream);
+    rt::dfree(d_bad);
+    if (bad != ~0ULL) {
+        std::vector<uint64_t> a(W), b2(W);
+        for (int w = 0; w < W; w++) {
+            rt::d2h(&a[w], (const uint64_t*)d_keys_ + (size_t)w * N + bad - 1, 8, stream);
+            rt::d2h(&b2[w], (const uint64_t*)d_keys_ + (size_t)w * N + bad, 8, stream);
+        }
+        rt::stream_sync(stream);
+        std::string sa(hdr.k, 'A'), sb(hdr.k, 'A');
+        words_to_ascii(a.data(), hdr.k, W, &sa[0]);
+        words_to_ascii(b2.data(), hdr.k, W, &sb[0]);
+        throw StatusError(LDBG_ERR_CORTEXJDK, "Records are not sorted ('" + sa + "' is found before '" + sb + "' but is lexicographically greater)");
+    }
+    switch (W) {
+        case 1: LDBG_LAUNCH(k_prefix_index<1>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
+        case 2: LDBG_LAUNCH(k_prefix_index<2>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
+        case 3: LDBG_LAUNCH(k_prefix_index<3>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
+        default: LDBG_LAUNCH(k_prefix_index<4>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
+    }
+    rt::stream_sync(stream);
+}
+
+Graph::~Graph() {
+    rt::dfree(d_keys_); rt::dfree(d_cov_); rt::dfree(d_edges_); rt::dfree(d_probe_); rt::dfree(d_pstart_);
+    rt::stream_destroy(stream);
+}
+
+void Graph::records_dev(int64_t first, int64_t n, uint64_t* d_words, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const {
+    if (n <= 0) return;
+    rt::Event e0, e1;
+    e0.record(s);
+    LDBG_LAUNCH(k_records, grid_for(n), 256, s, view, first, n, d_words, d_cov, d_edges);
+    e1.record(s);
+    profile_add("records", rt::Event::elapsed_ms(e0, e1));
+}
+
+void Graph::find_dev(const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const {
+    if (n <= 0) return;
+    rt::Event e0, e1;
+    e0.record(s);
+    int grid = grid_for(n, 256, 256 * 16);
+    switch (view.W) {
+        case 1: LDBG_LAUNCH(k_find<1>, grid, 256, s, view, d_packed, n, d_idx, d_cov, d_edges); break;
+        case 2: LDBG_LAUNCH(k_find<2>, grid, 256, s, view, d_packed, n, d_idx, d_cov, d_edges); break;
+        case 3: LDBG_LAUNCH(k_find<3>, grid, 256, s, view, d_packed, n, d_idx, d_cov, d_edges); break;
+        default: LDBG_LAUNCH(k_find<4>, grid, 256, s, view, d_packed, n, d_idx, d_cov, d_edges); break;
+    }
+    e1.record(s);
+    profile_add("find", rt::Event::elapsed_ms(e0, e1));
+}
+
+int Graph::color_for_sample_name(const std::string& name) const {
+    int color = -1, copies = 0;
+    for (int c = 0; c < hdr.C; c++)
+        if (strcasecmp(hdr.colors[c].sample_name.c_str(), name.c_str()) == 0) { color = c; copies++; }
+    if (color == -1) {
+        // Integer.valueOf(sampleName) fallback, CortexGraph.java:348-353
+        char* end = nullptr;
+        long v = strtol(name.c_str(), &end, 10);
+        if (!name.empty() && end && *end == 0) { color = (int)v; copies = 1; }
+    }
+    return copies == 1 ? color : -1;
+}
+
+}  // namespace ldbg

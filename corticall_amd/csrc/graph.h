@@ -1,0 +1,91 @@
+// Device-resident Cortex graph: layout in HBM and the lookup primitive every kernel shares.
+//
+// HBM layout (DESIGN.md §Data layout).  For N records, W words per k-mer, C colours:
+//   keys  [W][N] u64   structure-of-arrays, word-major (word 0 = most significant)   -- scans
+//   cov   [C][N] u32   structure-of-arrays, colour-major                            -- scans / filters
+//   edges [C][N] u8    structure-of-arrays, colour-major                            -- scans / filters
+//   probe [N][stride]  one aligned row per record: W×u64 key | C×u8 edges | pad4 | C×u32 cov | pad16
+//                      -- random access: one 16/32-byte sector yields key + edges (+ coverage)
+//   pstart[4^p + 1] u32  radix index on the first p bases: records with that prefix are
+//                      [pstart[x], pstart[x+1]) -- replaces the top ~2p levels of the reference's
+//                      binary search (CortexGraph.java:282-313) with one cached load; the remaining
+//                      levels are a binary search over the probe rows of that block.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "ctx_host.h"
+#include "kmer.h"
+#include "rt.h"
+
+namespace ldbg {
+
+struct GraphView {
+    int k, W, C, p;
+    int64_t N;
+    const uint64_t* keys;
+    const uint32_t* cov;
+    const uint8_t* edges;
+    const uint8_t* probe;
+    int stride, edges_off, cov_off;
+    const uint32_t* pstart;
+    int java_tiny;   // N <= 2: findRecord's loop never runs -> every lookup misses
+};
+
+// Binary search of a canonical k-mer; returns record index or -1.  CortexGraph.findRecord
+// (J/utils/io/graph/cortex/CortexGraph.java:272-317) minus canonicalisation (done by callers).
+template <int W>
+LDBG_HOSTDEV int64_t graph_find_canonical(const GraphView& g, const Kmer<W>& q) {
+    if (g.java_tiny) return -1;
+    uint32_t px = kmer_prefix<W>(q, g.k, g.p);
+    uint32_t lo = g.pstart[px], hi = g.pstart[px + 1];
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint64_t* kp = (const uint64_t*)(g.probe + (size_t)mid * (size_t)g.stride);
+        Kmer<W> m;
+#pragma unroll
+        for (int i = 0; i < W; i++) m.w[i] = kp[i];
+        int c = kmer_cmp<W>(m, q);
+        if (c == 0) return (int64_t)mid;
+        if (c < 0) lo = mid + 1; else hi = mid;
+    }
+    return -1;
+}
+LDBG_HOSTDEV const uint8_t* graph_row(const GraphView& g, int64_t idx) { return g.probe + (size_t)idx * (size_t)g.stride; }
+LDBG_HOSTDEV uint8_t graph_edges(const GraphView& g, int64_t idx, int c) { return graph_row(g, idx)[g.edges_off + c]; }
+LDBG_HOSTDEV uint32_t graph_cov(const GraphView& g, int64_t idx, int c) {
+    return ((const uint32_t*)(graph_row(g, idx) + g.cov_off))[c];
+}
+template <int W>
+LDBG_HOSTDEV Kmer<W> graph_key(const GraphView& g, int64_t idx) {
+    const uint64_t* kp = (const uint64_t*)graph_row(g, idx);
+    Kmer<W> m;
+#pragma unroll
+    for (int i = 0; i < W; i++) m.w[i] = kp[i];
+    return m;
+}
+
+class Graph {
+public:
+    // file_or_image: if image != nullptr the graph is built from memory, else `path` is mmapped
+    Graph(const std::string& path, const void* image, int64_t nbytes, int device);
+    ~Graph();
+    CtxHeader hdr;
+    int device = 0;
+    GraphView view{};
+    rt::stream_t stream = nullptr;
+    std::string path;
+
+    void records_dev(int64_t first, int64_t n, uint64_t* d_words, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const;
+    void find_dev(const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const;
+    int color_for_sample_name(const std::string& name) const;
+
+private:
+    void* d_keys_ = nullptr; void* d_cov_ = nullptr; void* d_edges_ = nullptr; void* d_probe_ = nullptr; void* d_pstart_ = nullptr;
+    void upload(const uint8_t* records_host);
+};
+
+// timing registry for bench.py (ldbg_profile_get)
+void profile_add(const char* family, double ms);
+
+}  // namespace ldbg

@@ -1,0 +1,152 @@
+// 2-bit packed k-mer arithmetic shared by host and device code (product side).
+// Representation ("packed words"): W = ceil(k/32) uint64, word 0 most significant, bases right
+// aligned, A=0 C=1 G=2 T=3 — the value McCortex stores in a .ctx record.  Unsigned lexicographic
+// order of the words equals the byte-wise ASCII order the reference sorts and searches by
+// (CortexByteKmer.compareTo, J/utils/kmer/CortexByteKmer.java:41-49).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LDBG_HD __host__ __device__ __forceinline__
+#else
+#define LDBG_HD inline
+#endif
+
+namespace ldbg {
+
+template <int W>
+struct Kmer {
+    uint64_t w[W];
+};
+
+template <int W>
+LDBG_HD bool kmer_eq(const Kmer<W>& a, const Kmer<W>& b) {
+    bool e = true;
+#pragma unroll
+    for (int i = 0; i < W; i++) e &= a.w[i] == b.w[i];
+    return e;
+}
+// -1 / 0 / +1, unsigned lexicographic from word 0
+template <int W>
+LDBG_HD int kmer_cmp(const Kmer<W>& a, const Kmer<W>& b) {
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        if (a.w[i] < b.w[i]) return -1;
+        if (a.w[i] > b.w[i]) return 1;
+    }
+    return 0;
+}
+
+// reverse the order of the 32 two-bit groups of a word
+LDBG_HD uint64_t rev2(uint64_t x) {
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    return __builtin_bswap64(x);
+}
+
+// SequenceUtils.reverseComplement on packed words (J/utils/sequence/SequenceUtils.java:127-135)
+template <int W>
+LDBG_HD Kmer<W> kmer_revcomp(const Kmer<W>& a, int k) {
+    Kmer<W> r;
+#pragma unroll
+    for (int i = 0; i < W; i++) r.w[i] = rev2(~a.w[W - 1 - i]);
+    const int s = 64 * W - 2 * k;   // right-align: shift the 64W-bit string right by s (0 <= s < 64)
+    if (s > 0) {
+#pragma unroll
+        for (int i = W - 1; i > 0; i--) r.w[i] = (r.w[i] >> s) | (r.w[i - 1] << (64 - s));
+        r.w[0] >>= s;
+    }
+    return r;
+}
+
+// alphanumericallyLowestOrientation (SequenceUtils.java:206-225): min(kmer, revcomp), ties -> input
+template <int W>
+LDBG_HD Kmer<W> kmer_canonical(const Kmer<W>& a, int k, bool* flipped_by_compare) {
+    Kmer<W> rc = kmer_revcomp<W>(a, k);
+    bool f = kmer_cmp<W>(rc, a) < 0;
+    *flipped_by_compare = f;
+    return f ? rc : a;
+}
+
+// base i (0 = first / leftmost base) as 0..3
+template <int W>
+LDBG_HD unsigned kmer_base(const Kmer<W>& a, int k, int i) {
+    int bit = 2 * (k - 1 - i);
+    return (unsigned)((a.w[W - 1 - (bit >> 6)] >> (bit & 63)) & 3ULL);
+}
+
+// successor: drop the first base, append b   (TraversalUtils.getAllNextKmers, sk[1:]+e)
+template <int W>
+LDBG_HD Kmer<W> kmer_next(const Kmer<W>& a, int k, unsigned b) {
+    Kmer<W> r;
+#pragma unroll
+    for (int i = 0; i < W - 1; i++) r.w[i] = (a.w[i] << 2) | (a.w[i + 1] >> 62);
+    r.w[W - 1] = (a.w[W - 1] << 2) | (uint64_t)b;
+    const int top = 2 * k - 64 * (W - 1);   // bits used in word 0 (1..64)
+    if (top < 64) r.w[0] &= ((1ULL << top) - 1ULL);
+    return r;
+}
+// predecessor: prepend b, drop the last base   (getAllPrevKmers, e+sk[:-1])
+template <int W>
+LDBG_HD Kmer<W> kmer_prev(const Kmer<W>& a, int k, unsigned b) {
+    Kmer<W> r;
+#pragma unroll
+    for (int i = W - 1; i > 0; i--) r.w[i] = (a.w[i] >> 2) | (a.w[i - 1] << 62);
+    r.w[0] = a.w[0] >> 2;
+    int bit = 2 * (k - 1);
+    r.w[W - 1 - (bit >> 6)] |= (uint64_t)b << (bit & 63);
+    return r;
+}
+
+// java.util.Arrays.hashCode(byte[]) of the ASCII form (CanonicalKmer.java:16,23,33 — quirk Q6)
+template <int W>
+LDBG_HD uint32_t kmer_java_hash(const Kmer<W>& a, int k) {
+    uint32_t h = 1;
+    for (int i = 0; i < k; i++) {
+        unsigned b = kmer_base<W>(a, k, i);
+        // 'A'=65 'C'=67 'G'=71 'T'=84
+        uint32_t ch = b == 0 ? 65u : (b == 1 ? 67u : (b == 2 ? 71u : 84u));
+        h = 31u * h + ch;
+    }
+    return h;
+}
+
+// top 2p bits (first p bases) as an integer, p <= 16, p <= k
+template <int W>
+LDBG_HD uint32_t kmer_prefix(const Kmer<W>& a, int k, int p) {
+    int sh = 2 * (k - p);   // shift right by sh over the 64W-bit string
+    int wi = W - 1 - (sh >> 6);
+    int b = sh & 63;
+    uint64_t v = a.w[wi] >> b;
+    if (b != 0 && wi > 0) v |= a.w[wi - 1] << (64 - b);
+    return (uint32_t)(v & ((1ULL << (2 * p)) - 1ULL));
+}
+
+// ---- host-only ASCII conversion -------------------------------------------------------------
+// returns false when the string contains a non-ACGT byte (case-insensitive like charToBinaryNucleotide,
+// CortexRecord.java:347-360)
+inline bool ascii_to_words(const char* s, int k, uint64_t* w, int W) {
+    for (int i = 0; i < W; i++) w[i] = 0;
+    for (int i = 0; i < k; i++) {
+        uint64_t v;
+        switch (s[i]) {
+            case 'A': case 'a': v = 0; break;
+            case 'C': case 'c': v = 1; break;
+            case 'G': case 'g': v = 2; break;
+            case 'T': case 't': v = 3; break;
+            default: return false;
+        }
+        int bit = 2 * (k - 1 - i);
+        w[W - 1 - (bit >> 6)] |= v << (bit & 63);
+    }
+    return true;
+}
+inline void words_to_ascii(const uint64_t* w, int k, int W, char* out) {
+    for (int i = 0; i < k; i++) {
+        int bit = 2 * (k - 1 - i);
+        out[i] = "ACGT"[(w[W - 1 - (bit >> 6)] >> (bit & 63)) & 3ULL];
+    }
+}
+
+}  // namespace ldbg

@@ -1,0 +1,325 @@
+#include "links.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <map>
+#include <numeric>
+
+namespace ldbg {
+
+namespace {
+
+// ---- tiny JSON reader (objects / arrays / strings / numbers / literals); enough for the .ctp header
+struct JVal {
+    enum T { NUL, NUM, STR, BOOL, OBJ, ARR } t = NUL;
+    double num = 0; bool b = false; std::string str;
+    std::vector<std::pair<std::string, JVal>> obj;
+    std::vector<JVal> arr;
+    const JVal* get(const std::string& k) const {
+        for (auto& kv : obj) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+struct JParser {
+    const std::string& s; size_t i = 0;
+    void ws() { while (i < s.size() && isspace((unsigned char)s[i])) i++; }
+    [[noreturn]] void fail(const char* m) { throw StatusError(LDBG_ERR_CORTEXJDK, std::string("Cannot parse CortexLinks JSON header: ") + m); }
+    JVal parse() {
+        ws();
+        if (i >= s.size()) fail("unexpected end");
+        JVal v;
+        char c = s[i];
+        if (c == '{') {
+            v.t = JVal::OBJ; i++; ws();
+            if (s[i] == '}') { i++; return v; }
+            while (true) {
+                ws(); JVal k = parse(); if (k.t != JVal::STR) fail("object key");
+                ws(); if (s[i] != ':') fail("':' expected"); i++;
+                v.obj.push_back({k.str, parse()});
+                ws(); if (s[i] == ',') { i++; continue; }
+                if (s[i] == '}') { i++; break; }
+                fail("',' or '}' expected");
+            }
+        } else if (c == '[') {
+            v.t = JVal::ARR; i++; ws();
+            if (s[i] == ']') { i++; return v; }
+            while (true) {
+                v.arr.push_back(parse());
+                ws(); if (s[i] == ',') { i++; continue; }
+                if (s[i] == ']') { i++; break; }
+                fail("',' or ']' expected");
+            }
+        } else if (c == '"') {
+            v.t = JVal::STR; i++;
+            while (i < s.size() && s[i] != '"') {
+                if (s[i] == '\\' && i + 1 < s.size()) { i++; char e = s[i]; v.str.push_back(e == 'n' ? '\n' : e == 't' ? '\t' : e); }
+                else v.str.push_back(s[i]);
+                i++;
+            }
+            i++;
+        } else if (c == 't' || c == 'f') {
+            v.t = JVal::BOOL; v.b = c == 't'; i += v.b ? 4 : 5;
+        } else if (c == 'n') {
+            i += 4;
+        } else {
+            size_t e = i;
+            while (e < s.size() && (isdigit((unsigned char)s[e]) || strchr("+-.eE", s[e]))) e++;
+            if (e == i) fail("value expected");
+            v.t = JVal::NUM; v.num = strtod(s.substr(i, e - i).c_str(), nullptr); i = e;
+        }
+        return v;
+    }
+};
+int64_t jnum(const JVal* o, const char* key) {
+    const JVal* v = o ? o->get(key) : nullptr;
+    if (!v || v->t != JVal::NUM) throw StatusError(LDBG_ERR_CORTEXJDK, std::string("CortexLinks header field missing: ") + key);
+    return (int64_t)v->num;
+}
+
+std::string gunzip_file(const std::string& path) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to load Cortex links file '" + path + "'");
+    std::string out;
+    std::vector<char> buf(1 << 20);
+    int n;
+    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) out.append(buf.data(), n);
+    gzclose(f);
+    return out;
+}
+
+// java.lang.String.hashCode / java.util.Arrays.hashCode(int[])
+int32_t jstring_hash(const std::string& s) { uint32_t h = 0; for (unsigned char c : s) h = 31u * h + c; return (int32_t)h; }
+int32_t jints_hash(const std::vector<int32_t>& v) { uint32_t h = 1; for (int32_t e : v) h = 31u * h + (uint32_t)e; return (int32_t)h; }
+// CortexJunctionsRecord.hashCode (CortexJunctionsRecord.java:87-95)
+int32_t junction_hash(const HostJunction& j) {
+    uint32_t r = j.is_fw ? 1u : 0u;
+    r = 31u * r + (uint32_t)j.num_kmers;
+    r = 31u * r + (uint32_t)j.num_junctions;
+    r = 31u * r + (uint32_t)jints_hash(j.cov);
+    r = 31u * r + (uint32_t)jstring_hash(j.junctions);
+    return (int32_t)r;
+}
+bool junction_eq(const HostJunction& a, const HostJunction& b) {
+    return a.is_fw == b.is_fw && a.num_junctions == b.num_junctions && a.num_kmers == b.num_kmers && a.cov == b.cov && a.junctions == b.junctions;
+}
+// iteration order of a default-constructed java.util.HashSet after inserting distinct elements
+// with these hashCodes: bucket index first, insertion order inside a bucket
+void hashset_order(std::vector<HostJunction>& js) {
+    size_t n = js.size();
+    int cap = 16;
+    while (n > (size_t)cap * 3 / 4) cap *= 2;
+    std::vector<size_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    auto bucket = [&](size_t i) { uint32_t h = (uint32_t)junction_hash(js[i]); h ^= h >> 16; return h & (uint32_t)(cap - 1); };
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return bucket(a) < bucket(b); });
+    std::vector<HostJunction> out;
+    for (size_t i : idx) out.push_back(js[i]);
+    js.swap(out);
+}
+std::string complement_ascii(const std::string& s) {
+    std::string c(s);
+    for (auto& ch : c) {
+        switch (ch) {
+            case 'A': ch = 'T'; break; case 'C': ch = 'G'; break; case 'G': ch = 'C'; break; case 'T': ch = 'A'; break;
+            case 'a': ch = 't'; break; case 'c': ch = 'g'; break; case 'g': ch = 'c'; break; case 't': ch = 'a'; break;
+            default: break;
+        }
+    }
+    return c;
+}
+std::vector<std::string> split_fields(const std::string& s, bool commas) {
+    std::vector<std::string> out;
+    std::string cur;
+    for (char ch : s) {
+        if (isspace((unsigned char)ch) || (commas && ch == ',')) { if (!cur.empty()) { out.push_back(cur); cur.clear(); } }
+        else cur.push_back(ch);
+    }
+    if (!cur.empty()) out.push_back(cur);
+    return out;
+}
+
+}  // namespace
+
+Links::Links(const std::string& path, const Graph& g) : device(g.device) {
+    std::string text = gunzip_file(path);
+    // header = lines from "{" to "}" (CortexLinksIterable.java:58-67)
+    size_t pos = 0;
+    auto next_line = [&](std::string& line) -> bool {
+        if (pos >= text.size()) return false;
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        line.assign(text, pos, e - pos);
+        pos = e + 1;
+        return true;
+    };
+    std::string line, header;
+    bool in_header = false;
+    while (next_line(line)) {
+        if (line == "{") in_header = true;
+        if (in_header) header += line + "\n";
+        if (line == "}") break;
+    }
+    JParser jp{header};
+    JVal h = jp.parse();
+    const JVal* fv = h.get("formatVersion") ? h.get("formatVersion") : h.get("format_version");
+    if (!fv) throw StatusError(LDBG_ERR_CORTEXJDK, "Cannot parse CortexLinks format version field");
+    version = (int)fv->num;
+    if (version != 2 && version != 3 && version != 4)
+        throw StatusError(LDBG_ERR_CORTEXJDK, "Cannot parse CortexLinks format version '" + std::to_string(version) + "'");
+    const JVal* colours = nullptr;
+    if (version == 2) {
+        num_colors = (int)jnum(&h, "ncols");
+        k = (int)jnum(&h, "kmer_size");
+        num_kmers_in_graph = jnum(&h, "num_kmers_in_graph");
+        num_kmers_with_links = jnum(&h, "num_kmers_with_paths");
+        num_links = jnum(&h, "num_paths");
+        link_bytes = jnum(&h, "path_bytes");
+        colours = h.get("colours");
+    } else {
+        const JVal* gr = h.get("graph");
+        const JVal* pa = h.get("paths");
+        num_colors = (int)jnum(gr, "num_colours");
+        k = (int)jnum(gr, "kmer_size");
+        num_kmers_in_graph = jnum(gr, "num_kmers_in_graph");
+        num_kmers_with_links = jnum(pa, "num_kmers_with_paths");
+        num_links = jnum(pa, "num_paths");
+        link_bytes = jnum(pa, "path_bytes");
+        colours = gr ? gr->get("colours") : nullptr;
+    }
+    if (colours) for (auto& c : colours->arr) { const JVal* s = c.get("sample"); sample_names.push_back(s ? s->str : ""); }
+    if (k != g.hdr.k)
+        throw StatusError(LDBG_ERR_CORTEXJDK, "links k-mer size " + std::to_string(k) + " does not match the graph's " + std::to_string(g.hdr.k));
+
+    // skip comments and blank lines (:133-144), then numKmersWithLinks records (:172-226)
+    bool have = false;
+    while (next_line(line)) {
+        if (line.empty() || line[0] == '#') continue;
+        have = true;
+        break;
+    }
+    const int W = g.hdr.W;
+    std::map<std::vector<uint64_t>, HostLinksRecord> by_key;   // canonical packed words -> record (later replaces earlier)
+    for (int64_t r = 0; r < num_kmers_with_links && have; r++) {
+        auto kl = split_fields(line, false);
+        if (kl.size() < 2) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record");
+        HostLinksRecord rec;
+        rec.kmer = kl[0];
+        int n = atoi(kl[1].c_str());
+        for (int i = 0; i < n; i++) {
+            if (!next_line(line)) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record");
+            auto f = split_fields(line, true);
+            HostJunction j;
+            int off = version == 4 ? 2 : 3;
+            if ((int)f.size() < off + num_colors + 1) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record");
+            j.is_fw = f[0] == "F";
+            j.num_kmers = version == 4 ? -1 : atoi(f[1].c_str());
+            j.num_junctions = version == 4 ? atoi(f[1].c_str()) : atoi(f[2].c_str());
+            for (int c = 0; c < num_colors; c++) j.cov.push_back(atoi(f[off + c].c_str()));
+            j.junctions = f[off + num_colors];
+            bool dup = false;
+            for (auto& o : rec.juncs) dup |= junction_eq(o, j);
+            if (!dup) rec.juncs.push_back(j);
+        }
+        hashset_order(rec.juncs);
+        std::vector<uint64_t> w(W), rc(W);
+        if ((int)rec.kmer.size() != k || !ascii_to_words(rec.kmer.c_str(), k, w.data(), W))
+            throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record: bad k-mer '" + rec.kmer + "'");
+        // canonical key (CortexBinaryKmer(byte[]) canonicalises, CortexBinaryKmer.java:17-19)
+        std::string rcs(k, 'A');
+        for (int i = 0; i < k; i++) { char ch = rec.kmer[k - 1 - i]; rcs[i] = complement_ascii(std::string(1, ch))[0]; }
+        ascii_to_words(rcs.c_str(), k, rc.data(), W);
+        by_key[std::min(w, rc)] = rec;
+        have = next_line(line);
+        while (have && line.empty()) have = next_line(line);
+    }
+
+    // flatten in key order
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> off{0};
+    std::vector<uint8_t> kcanon, bases;
+    std::vector<JuncRec> junc;
+    for (auto& kv : by_key) {
+        record_keys.push_back(kv.first);
+        records.push_back(kv.second);
+        keys.insert(keys.end(), kv.first.begin(), kv.first.end());
+        std::vector<uint64_t> w(W);
+        ascii_to_words(kv.second.kmer.c_str(), k, w.data(), W);
+        kcanon.push_back(w == kv.first ? 1 : 0);
+        for (auto& j : kv.second.juncs) {
+            JuncRec jr;
+            jr.str_off = (uint32_t)bases.size();
+            jr.len = (uint32_t)j.junctions.size();
+            jr.hash_asis = jstring_hash(j.junctions);
+            jr.hash_comp = jstring_hash(complement_ascii(j.junctions));
+            jr.is_fw = j.is_fw ? 1u : 0u;
+            for (char ch : j.junctions) {
+                uint8_t code;
+                switch (ch) {
+                    case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break;
+                    default: throw StatusError(LDBG_ERR_UNSUPPORTED, std::string("junction string with a non-ACGT character '") + ch + "'");
+                }
+                bases.push_back(code);
+            }
+            junc.push_back(jr);
+        }
+        off.push_back((uint32_t)junc.size());
+    }
+    const int64_t M = (int64_t)records.size();
+    int p = 1;
+    while (p < k && p < 12 && (1LL << (2 * (p + 1))) <= std::max<int64_t>(M, 1)) p++;
+    std::vector<uint32_t> pstart(((size_t)1 << (2 * p)) + 1, (uint32_t)M);
+    {
+        // pstart[x] = first record whose prefix >= x
+        size_t x = 0;
+        for (int64_t i = 0; i < M; i++) {
+            uint32_t px;
+            switch (W) {
+                case 1: { Kmer<1> q; q.w[0] = keys[i]; px = kmer_prefix<1>(q, k, p); break; }
+                case 2: { Kmer<2> q; q.w[0] = keys[2 * i]; q.w[1] = keys[2 * i + 1]; px = kmer_prefix<2>(q, k, p); break; }
+                case 3: { Kmer<3> q; for (int w = 0; w < 3; w++) q.w[w] = keys[3 * i + w]; px = kmer_prefix<3>(q, k, p); break; }
+                default: { Kmer<4> q; for (int w = 0; w < 4; w++) q.w[w] = keys[4 * i + w]; px = kmer_prefix<4>(q, k, p); break; }
+            }
+            while (x <= px) pstart[x++] = (uint32_t)i;
+        }
+    }
+
+    rt::set_device(device);
+    rt::stream_t s = g.stream;
+    auto up = [&](const void* h, size_t n) { void* d = rt::dmalloc(n); rt::h2d(d, h, n, s); return d; };
+    d_keys_ = up(keys.data(), keys.size() * 8);
+    d_pstart_ = up(pstart.data(), pstart.size() * 4);
+    d_off_ = up(off.data(), off.size() * 4);
+    d_kcanon_ = up(kcanon.data(), kcanon.size());
+    d_junc_ = up(junc.data(), junc.size() * sizeof(JuncRec));
+    d_bases_ = up(bases.data(), bases.size());
+    rt::stream_sync(s);
+    view.M = M;
+    view.keys = (const uint8_t*)d_keys_;
+    view.pstart = (const uint32_t*)d_pstart_;
+    view.p = p;
+    view.off = (const uint32_t*)d_off_;
+    view.kcanon = (const uint8_t*)d_kcanon_;
+    view.junc = (const JuncRec*)d_junc_;
+    view.bases = (const uint8_t*)d_bases_;
+}
+
+Links::~Links() {
+    rt::dfree(d_keys_); rt::dfree(d_pstart_); rt::dfree(d_off_); rt::dfree(d_kcanon_); rt::dfree(d_junc_); rt::dfree(d_bases_);
+}
+
+const HostLinksRecord* Links::get(const std::string& kmer_ascii) const {
+    if (records.empty() || (int)kmer_ascii.size() != k) return nullptr;
+    const int W = (int)record_keys[0].size();
+    std::vector<uint64_t> w(W), rc(W);
+    if (!ascii_to_words(kmer_ascii.c_str(), k, w.data(), W)) return nullptr;
+    std::string rcs(k, 'A');
+    for (int i = 0; i < k; i++) rcs[i] = complement_ascii(std::string(1, kmer_ascii[k - 1 - i]))[0];
+    ascii_to_words(rcs.c_str(), k, rc.data(), W);
+    auto key = std::min(w, rc);
+    auto it = std::lower_bound(record_keys.begin(), record_keys.end(), key);
+    if (it == record_keys.end() || *it != key) return nullptr;
+    return &records[it - record_keys.begin()];
+}
+
+}  // namespace ldbg

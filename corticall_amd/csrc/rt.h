@@ -1,0 +1,138 @@
+// Runtime shim: the ONE place where kernels meet the HIP runtime.
+//
+// Product build (hipcc, gfx950): thin inline wrappers over hipMalloc / hipMemcpyAsync /
+// hipLaunchKernelGGL.  There is no CPU fallback in the product library: without a device every
+// allocation or launch fails with LDBG_ERR_HIP.
+//
+// LDBG_HOSTSIM build (plain g++, tests only — tests/hostsim/): the same kernel sources are
+// compiled as ordinary C++ and a "launch" runs the kernel body once per simulated thread.  This
+// exists so that the kernel logic can be unit-tested in the CPU-only CI container; it is never
+// linked into libldbg.so and never shipped.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/ldbg.h"
+#include "ctx_host.h"   // StatusError
+
+#ifndef LDBG_HOSTSIM
+#include <hip/hip_runtime.h>
+#define LDBG_KERNEL __global__
+#define LDBG_DEV __device__ __forceinline__
+#define LDBG_HOSTDEV __host__ __device__ __forceinline__
+
+namespace ldbg {
+namespace rt {
+
+inline void check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw StatusError(LDBG_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+inline int device_count() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+inline void set_device(int d) { check(hipSetDevice(d), "hipSetDevice"); }
+inline void* dmalloc(size_t n) { void* p = nullptr; check(hipMalloc(&p, n ? n : 1), "hipMalloc"); return p; }
+inline void dfree(void* p) { if (p) (void)hipFree(p); }
+inline void* hmalloc_pinned(size_t n) { void* p = nullptr; check(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault), "hipHostMalloc"); return p; }
+inline void hfree_pinned(void* p) { if (p) (void)hipHostFree(p); }
+typedef hipStream_t stream_t;
+inline stream_t stream_create() { hipStream_t s; check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); return s; }
+inline void stream_destroy(stream_t s) { if (s) (void)hipStreamDestroy(s); }
+inline void stream_sync(stream_t s) { check(hipStreamSynchronize(s), "hipStreamSynchronize"); }
+inline void h2d(void* d, const void* h, size_t n, stream_t s) { if (n) check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "hipMemcpyAsync H2D"); }
+inline void d2h(void* h, const void* d, size_t n, stream_t s) { if (n) check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "hipMemcpyAsync D2H"); }
+inline void d2d(void* d, const void* s_, size_t n, stream_t s) { if (n) check(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync D2D"); }
+inline void dmemset(void* d, int v, size_t n, stream_t s) { if (n) check(hipMemsetAsync(d, v, n, s), "hipMemsetAsync"); }
+inline void mem_info(size_t* free_b, size_t* total_b) { check(hipMemGetInfo(free_b, total_b), "hipMemGetInfo"); }
+inline void launch_check(const char* name) { check(hipGetLastError(), name); }
+
+struct Event {
+    hipEvent_t e = nullptr;
+    Event() { check(hipEventCreate(&e), "hipEventCreate"); }
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+    void record(stream_t s) { check(hipEventRecord(e, s), "hipEventRecord"); }
+    static float elapsed_ms(Event& a, Event& b) {
+        check(hipEventSynchronize(b.e), "hipEventSynchronize");
+        float ms = 0;
+        check(hipEventElapsedTime(&ms, a.e, b.e), "hipEventElapsedTime");
+        return ms;
+    }
+};
+
+}  // namespace rt
+}  // namespace ldbg
+
+#define LDBG_LAUNCH(kernel, grid, block, stream, ...)                               \
+    do {                                                                            \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, stream, __VA_ARGS__); \
+        ::ldbg::rt::launch_check(#kernel);                                          \
+    } while (0)
+
+namespace ldbg {
+LDBG_DEV int64_t global_tid() { return (int64_t)blockIdx.x * blockDim.x + threadIdx.x; }
+LDBG_DEV int64_t global_nthreads() { return (int64_t)gridDim.x * blockDim.x; }
+LDBG_DEV unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+LDBG_DEV unsigned atomic_add_u32(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+LDBG_DEV unsigned atomic_min_u32(unsigned* p, unsigned v) { return atomicMin(p, v); }
+LDBG_DEV unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
+}  // namespace ldbg
+
+#else  // ------------------------------------------------------------------ LDBG_HOSTSIM (tests only)
+#define LDBG_KERNEL static
+#define LDBG_DEV inline
+#define LDBG_HOSTDEV inline
+#ifndef __forceinline__
+#define __forceinline__
+#endif
+
+namespace ldbg {
+namespace rt {
+inline int device_count() { return 1; }
+inline void set_device(int) {}
+inline void* dmalloc(size_t n) { return calloc(n ? n : 1, 1); }
+inline void dfree(void* p) { free(p); }
+inline void* hmalloc_pinned(size_t n) { return malloc(n ? n : 1); }
+inline void hfree_pinned(void* p) { free(p); }
+typedef void* stream_t;
+inline stream_t stream_create() { return nullptr; }
+inline void stream_destroy(stream_t) {}
+inline void stream_sync(stream_t) {}
+inline void h2d(void* d, const void* h, size_t n, stream_t) { if (n) memcpy(d, h, n); }
+inline void d2h(void* h, const void* d, size_t n, stream_t) { if (n) memcpy(h, d, n); }
+inline void d2d(void* d, const void* s, size_t n, stream_t) { if (n) memmove(d, s, n); }
+inline void dmemset(void* d, int v, size_t n, stream_t) { if (n) memset(d, v, n); }
+inline void mem_info(size_t* free_b, size_t* total_b) { *free_b = (size_t)2 << 30; *total_b = (size_t)2 << 30; }
+struct Event {
+    void record(stream_t) {}
+    static float elapsed_ms(Event&, Event&) { return 0.0f; }
+};
+}  // namespace rt
+struct SimIdx { int64_t tid, nthreads; };
+inline SimIdx& sim_idx() { static thread_local SimIdx s{0, 1}; return s; }
+inline int64_t global_tid() { return sim_idx().tid; }
+inline int64_t global_nthreads() { return sim_idx().nthreads; }
+inline unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+inline unsigned atomic_add_u32(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
+inline unsigned atomic_min_u32(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
+}  // namespace ldbg
+
+// sequential "launch": every simulated thread runs to completion in turn.  Kernels must therefore
+// not wait on other threads (none of ours do: walks are independent units).
+#define LDBG_LAUNCH(kernel, grid, block, stream, ...)                      \
+    do {                                                                   \
+        int64_t nt__ = (int64_t)(grid) * (int64_t)(block);                 \
+        if (nt__ > 4096) nt__ = 4096;                                      \
+        ::ldbg::sim_idx().nthreads = nt__;                                 \
+        for (int64_t t__ = 0; t__ < nt__; t__++) {                         \
+            ::ldbg::sim_idx().tid = t__;                                   \
+            kernel(__VA_ARGS__);                                           \
+        }                                                                  \
+    } while (0)
+#endif

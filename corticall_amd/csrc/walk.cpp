@@ -1,0 +1,524 @@
+// Batched contig walks: TraversalEngine.walk(seed) = toWalk(dfs(seed)) with ContigStopper
+// (J/utils/traversal/TraversalEngine.java:64-110, 356-482; J/utils/stoppingrules/ContigStopper.java:12-19),
+// with or without link annotations.  One strand walk (seed, direction) per lane; lanes pull strand
+// walks from a queue until it is empty.
+#include <algorithm>
+#include <numeric>
+
+#include "engine_host.h"
+
+namespace ldbg {
+
+struct WalkArgs {
+    EngineView e;
+    const uint64_t* seeds;     // [n][W]; word 0 == ~0 marks a seed that is not a k-mer (non-ACGT)
+    int64_t n_strands;         // 2n: strand 2i = reverse, 2i+1 = forward
+    int64_t n_slots;
+    int run_rev, run_fwd;
+    unsigned long long* next_strand;
+    uint64_t* path;            // [n_strands][pcap]
+    int64_t pcap;
+    uint32_t* strand_n;        // vertices in the strand's branch graph (0 = empty graph)
+    uint32_t* status;
+    uint32_t* iters;
+    uint64_t* term;            // [n_strands][W]
+    uint64_t* vtabs;           // [n_slots][vcap]
+    uint32_t vcap;
+    LsElem* ls;                // [n_slots][ecap]
+    uint32_t ecap;
+    uint32_t* slot_gen;
+};
+
+template <int W>
+LDBG_DEV uint64_t pack_vertex(const VRef<W>& v, int k, bool fwd) {
+    unsigned base = kmer_base<W>(v.sk, k, fwd ? k - 1 : 0);
+    return path_pack(v.idx, v.flip, base, v.copy);
+}
+
+// private dfs(cv, goForward, 0, 0, {}, sinks) for ContigStopper (TraversalEngine.java:356-482)
+template <int W>
+LDBG_DEV void run_strand(const WalkArgs& a, int64_t s, VisitedTable& vt, LinkStoreDev& ls) {
+    const EngineView& e = a.e;
+    const int k = e.g.k;
+    const bool fwd = (s & 1) != 0;
+    uint64_t* path = a.path + s * a.pcap;
+    uint32_t status = ST_OK, n_path = 0, iters = 0;
+    bool branch_null = false;
+
+    VRef<W> cv;
+    Adj<W> A;
+    const uint64_t* sw = a.seeds + (s >> 1) * W;
+#pragma unroll
+    for (int i = 0; i < W; i++) cv.sk.w[i] = sw[i];
+    if (sw[0] != ~0ull) {
+        cv = vref_find<W>(e, cv.sk);
+        adj_of<W>(e, cv, A);
+    } else {   // not a k-mer: findRecord misses (Q4)
+        cv.idx = -1; cv.flip = false; cv.copy = 0;
+        A.idx = -1; A.flip = false; A.o = cv.sk; A.next_mask = A.prev_mask = 0; A.npe = e.recruit_mask != 0;
+    }
+    Cursor<W> cu;
+    cu.has = false; cu.status = ST_OK;
+    const bool links_on = e.cursor_on != 0;
+    ls_clear(ls);
+    if (A.npe) status = ST_NULLPTR;
+    else if (links_on) cursor_seek<W>(e, cu, ls, cv, A, fwd);   // :363-365
+
+    uint32_t gV = 0;
+    while (status == ST_OK) {
+        iters++;
+        const uint32_t m = fwd ? A.next_mask : A.prev_mask;
+        int adj = 0;
+        VRef<W> av = cv;
+        Adj<W> anext;
+        bool have_anext = false;
+        if (links_on && cu.has) {                       // :379-407
+            VRef<W> t = cursor_step<W>(e, cu, ls, vt, fwd);
+            if (cu.status != ST_OK) { status = cu.status; break; }
+            int cnt = vt_count(vt, t.idx, t.flip);      // first unused copyIndex
+            t.copy = fwd ? cnt : -cnt;
+            av = t; adj = 1;
+            anext = cu.acur; have_anext = true;
+        } else {
+            for (unsigned b = 0; b < 4; b++) {
+                if (!((m >> b) & 1u)) continue;
+                VRef<W> x = vref_find<W>(e, neighbour<W>(A, k, fwd, b));
+                if (vt_count(vt, x.idx, x.flip) > 0) continue;   // avs.removeAll(seen) :416-422
+                adj++;
+                av = x;
+            }
+        }
+        const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+        const bool previously = acopy < vt_count(vt, cv.idx, cv.flip);   // :424
+        if (!previously) {
+            if (acopy + 1 > 32767) { status = ST_COPY_OVERFLOW; break; }
+            vt_update(vt, cv.idx, cv.flip, acopy + 1, false);           // visited.add(cv) :425
+        }
+        const bool reached = gV > (uint32_t)e.max_len;                   // :428
+        if (previously) { branch_null = true; break; }                   // :470-478, traversalSucceeded() still false
+        if (adj != 1 || reached) break;                                  // ContigStopper succeeded -> return g
+        if (gV == 0) { path[n_path++] = pack_vertex<W>(cv, k, fwd); gV = 1; }   // connectVertex :494-516
+        if ((int64_t)n_path >= a.pcap) { status = ST_PATH_FULL; break; }
+        path[n_path++] = pack_vertex<W>(av, k, fwd);
+        gV++;
+        if (av.idx < 0) {
+            uint64_t* tk = a.term + s * W;
+#pragma unroll
+            for (int i = 0; i < W; i++) tk[i] = av.sk.w[i];
+        }
+        cv = av;
+        if (have_anext) A = anext; else adj_of<W>(e, cv, A);
+        if (A.npe) status = ST_NULLPTR;
+    }
+    a.strand_n[s] = (branch_null || status != ST_OK) ? 0u : n_path;
+    a.status[s] = status != ST_OK ? status : (branch_null ? (uint32_t)ST_BRANCH_NULL : (uint32_t)ST_OK);
+    a.iters[s] = iters;
+}
+
+template <int W>
+LDBG_KERNEL void k_walk(WalkArgs a) {
+    const int64_t slot = global_tid();
+    if (slot >= a.n_slots) return;
+    VisitedTable vt;
+    vt.tab = a.vtabs + (size_t)slot * a.vcap;
+    vt.mask = a.vcap - 1;
+    vt.gen = a.slot_gen[slot];
+    LinkStoreDev ls;
+    ls.el = a.ls + (size_t)slot * a.ecap;
+    ls.cap = a.ecap;
+    ls_clear(ls);
+    while (true) {
+        const int64_t s = (int64_t)atomic_add_u64(a.next_strand, 1ull);
+        if (s >= a.n_strands) break;
+        const bool fwd = (s & 1) != 0;
+        if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
+            a.strand_n[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0;
+            continue;
+        }
+        vt.gen++;
+        if (vt.gen > 32767u) {
+            for (uint32_t i = 0; i <= vt.mask; i++) vt.tab[i] = 0;
+            vt.gen = 1;
+        }
+        run_strand<W>(a, s, vt, ls);
+    }
+    a.slot_gen[slot] = vt.gen;
+}
+
+// ---- result assembly -------------------------------------------------------------------------
+struct AsmArgs {
+    EngineView e;
+    int64_t n;
+    int op_and;
+    const uint64_t* seeds;
+    const uint64_t* path; int64_t pcap;      // sparse arena
+    const uint32_t* strand_n; const uint32_t* status;
+    int64_t* walk_len;                       // [n]
+    uint8_t* seed_ok;                        // [n]
+};
+// toWalk's seed test (TraversalUtils.java:392-397) + OR/AND combination (TraversalEngine.java:85-99)
+LDBG_KERNEL void k_walk_lengths(AsmArgs a) {
+    for (int64_t i = global_tid(); i < a.n; i += global_nthreads()) {
+        uint32_t nr = a.strand_n[2 * i], nf = a.strand_n[2 * i + 1];
+        bool null_r = a.status[2 * i] == ST_BRANCH_NULL, null_f = a.status[2 * i + 1] == ST_BRANCH_NULL;
+        bool err = (a.status[2 * i] != ST_OK && !null_r) || (a.status[2 * i + 1] != ST_OK && !null_f);
+        bool is_null = a.op_and ? (null_r || null_f) : (null_r && null_f);
+        int64_t len = 0;
+        uint8_t ok = 0;
+        if (!err && !is_null && nr + nf > 0) {
+            uint64_t seed_entry = nr > 0 ? a.path[(2 * i) * a.pcap] : a.path[(2 * i + 1) * a.pcap];
+            int64_t idx = path_idx(seed_entry);
+            if (idx >= 0 && (int32_t)graph_cov(a.e.g, idx, a.e.first_trav) > 0) {   // Q5: coverage is a signed int
+                ok = 1;
+                len = (int64_t)(nr > 0 ? nr - 1 : 0) + (int64_t)(nf > 0 ? nf - 1 : 0) + 1;
+            }
+        }
+        a.walk_len[i] = len;
+        a.seed_ok[i] = ok;
+    }
+}
+
+LDBG_KERNEL void k_compact_paths(const uint64_t* sparse, int64_t pcap, const int64_t* strand_off, int64_t n_strands, uint64_t* dense) {
+    const int64_t wave = global_tid() >> 6, lane = global_tid() & 63, nwaves = (global_nthreads() + 63) >> 6;
+    for (int64_t s = wave; s < n_strands; s += nwaves) {
+        const int64_t o = strand_off[s], n = strand_off[s + 1] - o;
+        for (int64_t j = lane; j < n; j += 64) dense[o + j] = sparse[s * pcap + j];
+    }
+}
+
+// TraversalUtils.toContig (TraversalUtils.java:367-381) over walk = reverse strand (far end first), seed, forward strand
+template <int W>
+LDBG_KERNEL void k_contigs(int k, int64_t n, const uint64_t* seeds, const uint64_t* dense, const int64_t* strand_off,
+                           const int64_t* walk_len, const int64_t* contig_off, char* out) {
+    const int64_t wave = global_tid() >> 6, lane = global_tid() & 63, nwaves = (global_nthreads() + 63) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        if (walk_len[i] == 0) continue;
+        const int64_t L = contig_off[i + 1] - contig_off[i];
+        const int64_t ro = strand_off[2 * i], nr = strand_off[2 * i + 1] - ro;
+        const int64_t fo = strand_off[2 * i + 1];
+        const int64_t nrev = nr > 0 ? nr - 1 : 0;
+        Kmer<W> sk;
+#pragma unroll
+        for (int w = 0; w < W; w++) sk.w[w] = seeds[i * W + w];
+        char* o = out + contig_off[i];
+        for (int64_t p = lane; p < L; p += 64) {
+            unsigned b;
+            if (p < nrev) b = path_base(dense[ro + (nr - 1 - p)]);
+            else if (p < nrev + k) b = kmer_base<W>(sk, k, (int)(p - nrev));
+            else b = path_base(dense[fo + (p - nrev - k + 1)]);
+            o[p] = "ACGT"[b];
+        }
+    }
+}
+
+// vertices of one walk in walk order
+template <int W>
+LDBG_KERNEL void k_walk_vertices(GraphView g, const uint64_t* dense, int64_t ro, int64_t nr, int64_t fo, int64_t nf,
+                                 const uint64_t* term_r, const uint64_t* term_f, int64_t len, uint64_t* words, int64_t* rec,
+                                 int32_t* copy, int32_t* index) {
+    const int64_t nrev = nr > 0 ? nr - 1 : 0;
+    for (int64_t p = global_tid(); p < len; p += global_nthreads()) {
+        uint64_t e;
+        int idx_label;
+        const uint64_t* term;
+        if (p < nrev) { e = dense[ro + (nr - 1 - p)]; idx_label = -1; term = term_r; }
+        else if (p == nrev) { e = nr > 0 ? dense[ro] : dense[fo]; idx_label = 0; term = nullptr; }
+        else { e = dense[fo + (p - nrev)]; idx_label = 1; term = term_f; }
+        int64_t ri = path_idx(e);
+        Kmer<W> km;
+        if (ri >= 0) {
+            km = graph_key<W>(g, ri);
+            if (path_flip(e)) km = kmer_revcomp<W>(km, g.k);
+        } else {
+            for (int w = 0; w < W; w++) km.w[w] = term ? term[w] : 0;
+        }
+        for (int w = 0; w < W; w++) words[p * W + w] = km.w[w];
+        rec[p] = ri;
+        copy[p] = path_copy(e);
+        index[p] = idx_label;
+    }
+}
+
+// ------------------------------------------------------------------ host
+static uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)p; }
+static int grid_for(int64_t n, int block, int max_blocks) {
+    int64_t b = (n + block - 1) / block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, max_blocks));
+}
+
+Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
+    // TraversalEngineFactory.make :54-88
+    if (c.n_traversal <= 0) throw StatusError(LDBG_ERR_CORTEXJDK, "Traversal color(s) must be specified.");
+    if (!c.graph) throw StatusError(LDBG_ERR_CORTEXJDK, "Must provide graph to traverse.");
+    graph = (const Graph*)c.graph;
+    rois = (const Graph*)c.rois;
+    const int nc = graph->hdr.C;
+    auto fail = [&](const char* what, int col) {
+        throw StatusError(LDBG_ERR_CORTEXJDK, std::string(what) + " colors must be between 0 and " + std::to_string(nc) + " (provided " + std::to_string(col) + ")");
+    };
+    for (int i = 0; i < c.n_traversal; i++) if (c.traversal_colors[i] >= nc || c.traversal_colors[i] < 0) fail("Traversal", c.traversal_colors[i]);
+    for (int i = 0; i < c.n_joining; i++) if (c.joining_colors[i] < 0 || c.joining_colors[i] >= nc) fail("Joining", c.joining_colors[i]);
+    for (int i = 0; i < c.n_recruitment; i++) if (c.recruitment_colors[i] < 0 || c.recruitment_colors[i] >= nc) fail("Recruitment", c.recruitment_colors[i]);
+    for (int i = 0; i < c.n_secondary; i++) if (c.secondary_colors[i] < 0 || c.secondary_colors[i] >= nc) fail("Secondary", c.secondary_colors[i]);
+    if (c.stopping_rule < 0 || c.stopping_rule >= LDBG_STOP_COUNT) throw StatusError(LDBG_ERR_CORTEXJDK, "Must provide stopping rule for graph traversal");
+
+    view.g = graph->view;
+    view.trav_mask = view.recruit_mask = view.join_mask = 0;
+    for (int i = 0; i < c.n_traversal; i++) view.trav_mask |= 1u << c.traversal_colors[i];
+    for (int i = 0; i < c.n_recruitment; i++) view.recruit_mask |= 1u << c.recruitment_colors[i];
+    for (int i = 0; i < c.n_joining; i++) view.join_mask |= 1u << c.joining_colors[i];
+    view.first_trav = c.traversal_colors[0];
+    view.stopper = c.stopping_rule;
+    view.max_len = c.max_branch_length;
+    view.connect_all = c.connect_all_neighbors;
+    view.strict_flip = c.strict_java_flip;
+    // initializeLinkStore/updateLinkStore :548-597: only link sets whose colour-0 sample is a traversal sample
+    view.nlinks = 0;
+    for (int i = 0; i < c.nlinks; i++) {
+        const Links* l = (const Links*)c.links[i];
+        if (!l) continue;
+        bool mine = false;
+        for (int t = 0; t < c.n_traversal; t++)
+            if (!l->sample_names.empty() && l->sample_names[0] == graph->hdr.colors[c.traversal_colors[t]].sample_name) mine = true;
+        if (mine) {
+            if (view.nlinks >= LDBG_MAX_LINKS) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than " + std::to_string(LDBG_MAX_LINKS) + " link sets for one traversal");
+            view.links[view.nlinks++] = l->view;
+            my_links.push_back(l);
+        }
+    }
+    // ec.getLinks().isEmpty() (not "my links") decides whether dfs uses the cursor (:363, :379)
+    view.cursor_on = c.nlinks > 0 ? 1 : 0;
+}
+
+Engine::~Engine() { clear_batch(); release_scratch(); }
+
+void Engine::release_scratch() {
+    rt::dfree(d_vtabs_); rt::dfree(d_ls_); rt::dfree(d_slot_gen_);
+    d_vtabs_ = d_ls_ = d_slot_gen_ = nullptr;
+    n_slots_ = 0;
+}
+
+void Engine::clear_batch() {
+    for (auto& c : chunks) { rt::dfree(c.d_path); rt::dfree(c.d_contigs); rt::dfree(c.d_seed_words); rt::dfree(c.d_term); }
+    chunks.clear();
+    batch_n = batch_bytes = batch_traversed = 0;
+}
+
+void Engine::ensure_scratch(int64_t want_slots, uint32_t vcap, uint32_t ecap) {
+    if (d_vtabs_ && n_slots_ >= want_slots && vcap_ == vcap && ecap_ == ecap) return;
+    release_scratch();
+    rt::stream_t s = graph->stream;
+    d_vtabs_ = rt::dmalloc((size_t)want_slots * vcap * 8);
+    d_ls_ = rt::dmalloc((size_t)want_slots * ecap * sizeof(LsElem));
+    d_slot_gen_ = rt::dmalloc((size_t)want_slots * 4);
+    rt::dmemset(d_vtabs_, 0, (size_t)want_slots * vcap * 8, s);
+    rt::dmemset(d_slot_gen_, 0, (size_t)want_slots * 4, s);
+    n_slots_ = want_slots; vcap_ = vcap; ecap_ = ecap;
+}
+
+void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
+    if (cfg.stopping_rule != LDBG_STOP_CONTIG || cfg.connect_all_neighbors)
+        throw StatusError(LDBG_ERR_UNSUPPORTED, "walk_batch runs ContigStopper without connectAllNeighbors; use dfs_batch for other rules");
+    if (cfg.n_secondary > 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "secondary colours are not supported by walk_batch");
+    rt::set_device(graph->device);
+    clear_batch();
+    const int k = graph->hdr.k, W = graph->hdr.W;
+    std::vector<uint64_t> words((size_t)n * W);
+    for (int64_t i = 0; i < n; i++)
+        if (!ascii_to_words(seeds + i * k, k, &words[i * W], W)) words[i * W] = ~0ull;
+
+    // chunking: the sparse path arena holds the worst case (maxLength + 2 vertices per strand)
+    size_t free_b = 0, total_b = 0;
+    rt::mem_info(&free_b, &total_b);
+    const int64_t pcap = (int64_t)cfg.max_branch_length + 2;
+    const size_t per_seed = (size_t)2 * pcap * 8;
+    int64_t chunk = (int64_t)std::max<size_t>(1, (size_t)(free_b * 0.40) / per_seed);
+    chunk = std::min<int64_t>(chunk, std::max<int64_t>(n, 1));
+    batch_n = n;
+    int64_t trav = 0;
+    for (int64_t first = 0; first < n; first += chunk) {
+        chunks.emplace_back();
+        run_chunk(words, first, std::min(chunk, n - first), chunks.back(), &trav);
+    }
+    batch_traversed = trav;
+    batch_bytes = 0;
+    for (auto& c : chunks) batch_bytes += c.contig_off.back();
+    if (total_bytes) *total_bytes = batch_bytes;
+    if (traversed) *traversed = trav;
+}
+
+void Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed) {
+    const int W = graph->hdr.W, k = graph->hdr.k;
+    rt::stream_t s = graph->stream;
+    const int64_t ns = 2 * n;
+    const int64_t pcap = (int64_t)cfg.max_branch_length + 2;
+    out.first = first; out.n = n;
+
+    // scratch: per-slot visited table sized for the longest possible branch at load <= 1/2
+    const uint32_t vcap = std::max<uint32_t>(64u, next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 4)));
+    size_t free_b = 0, total_b = 0;
+    rt::mem_info(&free_b, &total_b);
+    uint32_t ecap = link_store_capacity;
+    const size_t sparse_bytes = (size_t)ns * pcap * 8;
+    size_t budget = free_b > sparse_bytes ? (size_t)((free_b - sparse_bytes) * 0.5) : 0;
+    if (n_slots_ > 0) budget += (size_t)n_slots_ * ((size_t)vcap_ * 8 + (size_t)ecap_ * sizeof(LsElem));
+    int64_t slots = (int64_t)(budget / ((size_t)vcap * 8 + (size_t)ecap * sizeof(LsElem) + 4));
+    slots = std::max<int64_t>(64, std::min<int64_t>(slots, 1 << 18));
+    slots = std::min<int64_t>(slots, ((ns + 63) / 64) * 64);
+    if (!(d_vtabs_ && n_slots_ >= slots && vcap_ == vcap && ecap_ == ecap)) ensure_scratch(slots, vcap, ecap);
+
+    out.d_seed_words = rt::dmalloc((size_t)n * W * 8);
+    rt::h2d(out.d_seed_words, &seed_words[first * W], (size_t)n * W * 8, s);
+    out.d_term = rt::dmalloc((size_t)ns * W * 8);
+    void* d_sparse = rt::dmalloc(sparse_bytes);
+    uint32_t* d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    uint32_t* d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    uint32_t* d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    unsigned long long* d_next = (unsigned long long*)rt::dmalloc(8);
+    rt::dmemset(d_next, 0, 8, s);
+    rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
+
+    WalkArgs a;
+    a.e = view;
+    a.seeds = (const uint64_t*)out.d_seed_words;
+    a.n_strands = ns;
+    a.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
+    a.run_rev = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_REVERSE;
+    a.run_fwd = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_FORWARD;
+    a.next_strand = d_next;
+    a.path = (uint64_t*)d_sparse; a.pcap = pcap;
+    a.strand_n = d_strand_n; a.status = d_status; a.iters = d_iters;
+    a.term = (uint64_t*)out.d_term;
+    a.vtabs = (uint64_t*)d_vtabs_; a.vcap = vcap_;
+    a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
+    a.slot_gen = (uint32_t*)d_slot_gen_;
+    rt::Event e0, e1;
+    e0.record(s);
+    const int block = 64;
+    const int grid = (int)((a.n_slots + block - 1) / block);
+    switch (W) {
+        case 1: LDBG_LAUNCH(k_walk<1>, grid, block, s, a); break;
+        case 2: LDBG_LAUNCH(k_walk<2>, grid, block, s, a); break;
+        case 3: LDBG_LAUNCH(k_walk<3>, grid, block, s, a); break;
+        default: LDBG_LAUNCH(k_walk<4>, grid, block, s, a); break;
+    }
+    e1.record(s);
+
+    // lengths + seed test
+    int64_t* d_walk_len = (int64_t*)rt::dmalloc((size_t)n * 8);
+    uint8_t* d_seed_ok = (uint8_t*)rt::dmalloc((size_t)n);
+    AsmArgs aa;
+    aa.e = view; aa.n = n; aa.op_and = cfg.combination_operator == LDBG_OP_AND;
+    aa.seeds = a.seeds; aa.path = a.path; aa.pcap = pcap; aa.strand_n = d_strand_n; aa.status = d_status;
+    aa.walk_len = d_walk_len; aa.seed_ok = d_seed_ok;
+    LDBG_LAUNCH(k_walk_lengths, grid_for(n, 256, 2048), 256, s, aa);
+
+    std::vector<uint32_t> strand_n(ns), iters(ns);
+    out.status.resize(ns);
+    out.walk_len.resize(n);
+    out.seed_ok.resize(n);
+    rt::d2h(strand_n.data(), d_strand_n, (size_t)ns * 4, s);
+    rt::d2h(out.status.data(), d_status, (size_t)ns * 4, s);
+    rt::d2h(iters.data(), d_iters, (size_t)ns * 4, s);
+    rt::d2h(out.walk_len.data(), d_walk_len, (size_t)n * 8, s);
+    rt::d2h(out.seed_ok.data(), d_seed_ok, (size_t)n, s);
+    rt::stream_sync(s);
+    profile_add("walk", rt::Event::elapsed_ms(e0, e1));
+    for (int64_t i = 0; i < ns; i++) *traversed += iters[i];
+
+    // dense paths + contigs
+    out.strand_off.assign(ns + 1, 0);
+    for (int64_t i = 0; i < ns; i++) out.strand_off[i + 1] = out.strand_off[i] + strand_n[i];
+    out.contig_off.assign(n + 1, 0);
+    for (int64_t i = 0; i < n; i++) out.contig_off[i + 1] = out.contig_off[i] + (out.walk_len[i] > 0 ? out.walk_len[i] + k - 1 : 0);
+    int64_t* d_strand_off = (int64_t*)rt::dmalloc((size_t)(ns + 1) * 8);
+    int64_t* d_contig_off = (int64_t*)rt::dmalloc((size_t)(n + 1) * 8);
+    rt::h2d(d_strand_off, out.strand_off.data(), (size_t)(ns + 1) * 8, s);
+    rt::h2d(d_contig_off, out.contig_off.data(), (size_t)(n + 1) * 8, s);
+    out.d_path = rt::dmalloc((size_t)out.strand_off[ns] * 8);
+    out.d_contigs = rt::dmalloc((size_t)out.contig_off[n]);
+    rt::Event c0, c1;
+    c0.record(s);
+    LDBG_LAUNCH(k_compact_paths, grid_for(ns * 64, 256, 4096), 256, s, (const uint64_t*)d_sparse, pcap, (const int64_t*)d_strand_off, ns, (uint64_t*)out.d_path);
+    const int cg = grid_for(n * 64, 256, 4096);
+    switch (W) {
+        case 1: LDBG_LAUNCH(k_contigs<1>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
+        case 2: LDBG_LAUNCH(k_contigs<2>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
+        case 3: LDBG_LAUNCH(k_contigs<3>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
+        default: LDBG_LAUNCH(k_contigs<4>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
+    }
+    c1.record(s);
+    rt::stream_sync(s);
+    profile_add("contig", rt::Event::elapsed_ms(c0, c1));
+    rt::dfree(d_sparse); rt::dfree(d_strand_n); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_next);
+    rt::dfree(d_walk_len); rt::dfree(d_seed_ok); rt::dfree(d_strand_off); rt::dfree(d_contig_off);
+
+    // errors the reference raises as exceptions abort the call
+    for (int64_t i = 0; i < ns; i++) {
+        if (out.status[i] == ST_NULLPTR)
+            throw StatusError(LDBG_ERR_NULLPOINTER, "getNextVertices: record missing while recruitment colours are set (seed " + std::to_string(first + i / 2) + ")");
+        if (out.status[i] == ST_LINKSTORE_FULL) {
+            throw StatusError(LDBG_ERR_CAPACITY, "LINKSTORE_FULL");
+        }
+        if (out.status[i] == ST_COPY_OVERFLOW || out.status[i] == ST_PATH_FULL)
+            throw StatusError(LDBG_ERR_UNSUPPORTED, "walk exceeded an internal limit (status " + std::to_string(out.status[i]) + ")");
+    }
+}
+
+void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len) {
+    rt::set_device(graph->device);
+    if (offsets) {
+        int64_t o = 0;
+        offsets[0] = 0;
+        for (auto& c : chunks)
+            for (int64_t i = 0; i < c.n; i++) { o += c.contig_off[i + 1] - c.contig_off[i]; offsets[c.first + i + 1] = o; }
+    }
+    if (walk_len) for (auto& c : chunks) for (int64_t i = 0; i < c.n; i++) walk_len[c.first + i] = c.walk_len[i];
+    if (cap < batch_bytes) throw StatusError(LDBG_ERR_CAPACITY, "contig arena too small: need " + std::to_string(batch_bytes) + " bytes");
+    if (arena) {
+        int64_t o = 0;
+        for (auto& c : chunks) {
+            rt::d2h(arena + o, c.d_contigs, (size_t)c.contig_off.back(), graph->stream);
+            o += c.contig_off.back();
+        }
+        rt::stream_sync(graph->stream);
+    }
+}
+
+void Engine::walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index) {
+    rt::set_device(graph->device);
+    if (walk < 0 || walk >= batch_n) throw StatusError(LDBG_ERR_ARG, "walk index out of range");
+    const int W = graph->hdr.W;
+    for (auto& c : chunks) {
+        if (walk < c.first || walk >= c.first + c.n) continue;
+        int64_t i = walk - c.first;
+        int64_t L = c.walk_len[i];
+        *len = L;
+        if (L == 0) return;
+        if (capacity < L) throw StatusError(LDBG_ERR_CAPACITY, "vertex buffers too small: need " + std::to_string(L));
+        rt::stream_t s = graph->stream;
+        uint64_t* d_words = (uint64_t*)rt::dmalloc((size_t)L * W * 8);
+        int64_t* d_rec = (int64_t*)rt::dmalloc((size_t)L * 8);
+        int32_t* d_copy = (int32_t*)rt::dmalloc((size_t)L * 4);
+        int32_t* d_index = (int32_t*)rt::dmalloc((size_t)L * 4);
+        int64_t ro = c.strand_off[2 * i], nr = c.strand_off[2 * i + 1] - ro, fo = c.strand_off[2 * i + 1], nf = c.strand_off[2 * i + 2] - fo;
+        const uint64_t* tr = (const uint64_t*)c.d_term + (2 * i) * W;
+        const uint64_t* tf = (const uint64_t*)c.d_term + (2 * i + 1) * W;
+        const int g = grid_for(L, 256, 1024);
+        switch (W) {
+            case 1: LDBG_LAUNCH(k_walk_vertices<1>, g, 256, s, graph->view, (const uint64_t*)c.d_path, ro, nr, fo, nf, tr, tf, L, d_words, d_rec, d_copy, d_index); break;
+            case 2: LDBG_LAUNCH(k_walk_vertices<2>, g, 256, s, graph->view, (const uint64_t*)c.d_path, ro, nr, fo, nf, tr, tf, L, d_words, d_rec, d_copy, d_index); break;
+            case 3: LDBG_LAUNCH(k_walk_vertices<3>, g, 256, s, graph->view, (const uint64_t*)c.d_path, ro, nr, fo, nf, tr, tf, L, d_words, d_rec, d_copy, d_index); break;
+            default: LDBG_LAUNCH(k_walk_vertices<4>, g, 256, s, graph->view, (const uint64_t*)c.d_path, ro, nr, fo, nf, tr, tf, L, d_words, d_rec, d_copy, d_index); break;
+        }
+        if (words) rt::d2h(words, d_words, (size_t)L * W * 8, s);
+        if (rec) rt::d2h(rec, d_rec, (size_t)L * 8, s);
+        if (copy) rt::d2h(copy, d_copy, (size_t)L * 4, s);
+        if (index) rt::d2h(index, d_index, (size_t)L * 4, s);
+        rt::stream_sync(s);
+        rt::dfree(d_words); rt::dfree(d_rec); rt::dfree(d_copy); rt::dfree(d_index);
+        return;
+    }
+}
+
+}  // namespace ldbg

@@ -1,0 +1,222 @@
+"""Host-side mirror of Corticall's graph API over libldbg (no compute here: every lookup and record
+fetch is a HIP kernel behind the C ABI).
+
+Mirrors  uk.ac.ox.well.cortexjdk.utils.io.graph.DeBruijnGraph          (J/utils/io/graph/DeBruijnGraph.java:16-53)
+         ...utils.io.graph.cortex.CortexGraph / CortexRecord / CortexHeader / CortexColor
+Method names follow the Java ones so that reference tests read the same here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+_ALPHA = b"ACGT"
+
+
+def _as_bytes(k):
+    return k.encode() if isinstance(k, str) else bytes(k)
+
+
+class CortexRecord:
+    """J/utils/io/graph/cortex/CortexRecord.java — value object (packed k-mer words, coverages, edge bytes)."""
+
+    def __init__(self, words, coverages, edges, kmer_size, index=-1):
+        self.words = tuple(int(w) for w in words)
+        self.coverages = tuple(int(np.int32(np.uint32(c))) for c in coverages)   # Java int view of the u32 (Q5)
+        self.edges = tuple(int(e) & 0xFF for e in edges)
+        self.kmerSize = kmer_size
+        self.index = index
+
+    def getKmerSize(self): return self.kmerSize
+    def getKmerBits(self): return (self.kmerSize + 31) // 32
+    def getNumColors(self): return len(self.coverages)
+    def getCoverage(self, c): return self.coverages[c]
+    def getCoverages(self): return list(self.coverages)
+    def getEdges(self): return list(self.edges)
+
+    def getKmerAsString(self):
+        k, W = self.kmerSize, len(self.words)
+        out = bytearray(k)
+        for i in range(k):
+            bit = 2 * (k - 1 - i)
+            out[i] = _ALPHA[(self.words[W - 1 - (bit >> 6)] >> (bit & 63)) & 3]
+        return out.decode()
+
+    def getKmerAsBytes(self): return self.getKmerAsString().encode()
+
+    def getEdgesAsString(self, c):
+        e = self.edges[c]
+        left, right = e >> 4, e & 0xF
+        s = bytearray(b"........")
+        for i in range(4):
+            if left & (1 << (3 - i)):
+                s[i] = b"acgt"[i]
+            if right & (1 << i):
+                s[i + 4] = b"ACGT"[i]
+        return s.decode()
+
+    def getInEdgesAsStrings(self, c, complement=False):
+        alpha = "TGCA" if complement else "ACGT"
+        left = self.edges[c] >> 4
+        return [alpha[i] for i in range(4) if left & (1 << (3 - i))]
+
+    def getOutEdgesAsStrings(self, c, complement=False):
+        alpha = "TGCA" if complement else "ACGT"
+        right = self.edges[c] & 0xF
+        return [alpha[i] for i in range(4) if right & (1 << i)]
+
+    def getInDegree(self, c): return len(self.getInEdgesAsStrings(c))
+    def getOutDegree(self, c): return len(self.getOutEdgesAsStrings(c))
+
+    def toString(self):
+        return " ".join([self.getKmerAsString()] + [str(c) for c in self.coverages] +
+                        [self.getEdgesAsString(c) for c in range(len(self.edges))])
+
+    __str__ = toString
+
+    def __eq__(self, o):
+        return isinstance(o, CortexRecord) and (self.words, self.coverages, self.edges) == (o.words, o.coverages, o.edges)
+
+    def __hash__(self):
+        return hash((self.words, self.coverages, self.edges))
+
+
+class CortexGraph:
+    """J/utils/io/graph/cortex/CortexGraph.java — here: a .ctx file resident in MI355X HBM."""
+
+    def __init__(self, path, device=0, lib=None):
+        self._lib = lib or _native.default_lib()
+        self._d = self._lib.dll
+        self.path = str(path)
+        h = C.c_void_p()
+        self._lib.check(self._d.ldbg_graph_open(self.path.encode(), int(device), C.byref(h)))
+        self._h = h
+        k, W, Cc, N, v = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        self._lib.check(self._d.ldbg_graph_info(h, C.byref(k), C.byref(W), C.byref(Cc), C.byref(N), C.byref(v)))
+        self._k, self._W, self._C, self._N, self._version = k.value, W.value, Cc.value, N.value, v.value
+        self._pos = 0
+
+    # ---- header getters (CortexGraph.java:323-336)
+    def getFile(self): return self.path
+    def getVersion(self): return self._version
+    def getKmerSize(self): return self._k
+    def getKmerBits(self): return self._W
+    def getNumColors(self): return self._C
+    def getNumRecords(self): return self._N
+    def hasColor(self, c): return 0 <= c < self._C
+
+    def getSampleName(self, color):
+        buf = C.create_string_buffer(4096)
+        self._lib.check(self._d.ldbg_graph_sample_name(self._h, int(color), buf, 4096))
+        return buf.value.decode()
+
+    def getColor(self, color):
+        info = _native.ColorInfo()
+        name = C.create_string_buffer(4096)
+        self._lib.check(self._d.ldbg_graph_color_info(self._h, int(color), C.byref(info), name, 4096))
+        return {
+            "sampleName": self.getSampleName(color), "meanReadLength": info.mean_read_length,
+            "totalSequence": info.total_sequence, "tipClippingApplied": bool(info.tip_clipping),
+            "lowCovgSupernodesRemoved": bool(info.low_covg_supernodes_removed),
+            "lowCovgKmersRemoved": bool(info.low_covg_kmers_removed),
+            "cleanedAgainstGraph": bool(info.cleaned_against_graph),
+            "lowCovSupernodesThreshold": info.low_cov_supernodes_threshold,
+            "lowCovKmerThreshold": info.low_cov_kmer_threshold,
+            "cleanedAgainstGraphName": name.value.decode(),
+        }
+
+    def getColors(self): return [self.getColor(c) for c in range(self._C)]
+
+    def getColorForSampleName(self, name):
+        c = C.c_int()
+        self._lib.check(self._d.ldbg_graph_color_for_sample_name(self._h, str(name).encode(), C.byref(c)))
+        return c.value
+
+    def getColorsForSampleNames(self, names):
+        return [self.getColorForSampleName(n) for n in (names or [])]
+
+    # ---- bulk forms (the batch-first boundary)
+    def records(self, first, n):
+        """records [first, first+n) -> (words u64[n,W], cov i32[n,C], edges u8[n,C])"""
+        n = int(n)
+        words = np.empty((n, self._W), dtype=np.uint64)
+        cov = np.empty((n, self._C), dtype=np.uint32)
+        edges = np.empty((n, self._C), dtype=np.uint8)
+        self._lib.check(self._d.ldbg_graph_records(self._h, C.c_int64(first), C.c_int64(n),
+                                                   words.ctypes.data_as(C.c_void_p), cov.ctypes.data_as(C.c_void_p),
+                                                   edges.ctypes.data_as(C.c_void_p)))
+        return words, cov.view(np.int32), edges
+
+    def find_batch(self, kmers, with_payload=True):
+        """kmers: list of str/bytes, or np.uint8[n,k] ASCII -> (idx i64[n], cov i32[n,C], edges u8[n,C]); -1 = null"""
+        if isinstance(kmers, np.ndarray):
+            a = np.ascontiguousarray(kmers, dtype=np.uint8)
+        else:
+            a = np.frombuffer(b"".join(_as_bytes(x) for x in kmers), dtype=np.uint8).reshape(len(kmers), self._k)
+        n = a.shape[0]
+        if a.ndim != 2 or a.shape[1] != self._k:
+            raise ValueError("k-mers must all have length k=%d" % self._k)
+        idx = np.empty(n, dtype=np.int64)
+        cov = np.zeros((n, self._C), dtype=np.uint32) if with_payload else None
+        edges = np.zeros((n, self._C), dtype=np.uint8) if with_payload else None
+        self._lib.check(self._d.ldbg_graph_find_ascii(
+            self._h, a.ctypes.data_as(C.c_char_p), C.c_int64(n), idx.ctypes.data_as(C.c_void_p),
+            cov.ctypes.data_as(C.c_void_p) if with_payload else None,
+            edges.ctypes.data_as(C.c_void_p) if with_payload else None))
+        return idx, (cov.view(np.int32) if with_payload else None), edges
+
+    def find_packed(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1, self._W)
+        idx = np.empty(w.shape[0], dtype=np.int64)
+        self._lib.check(self._d.ldbg_graph_find(self._h, w.ctypes.data_as(C.c_void_p), C.c_int64(w.shape[0]),
+                                                idx.ctypes.data_as(C.c_void_p), None, None))
+        return idx
+
+    # ---- scalar DeBruijnGraph methods = batch of one
+    def getRecord(self, i):
+        if i < 0:
+            raise _native.CortexJDKException("Record index is prefix of range (%d vs 0-%d)" % (i, self._N - 1))
+        if i >= self._N:
+            return None    # Q2
+        w, c, e = self.records(i, 1)
+        return CortexRecord(w[0], c[0], e[0], self._k, i)
+
+    def findRecord(self, kmer):
+        kb = _as_bytes(kmer.getKmerAsBytes() if hasattr(kmer, "getKmerAsBytes") else kmer)
+        idx, cov, edges = self.find_batch([kb])
+        if idx[0] < 0:
+            return None
+        w, _, _ = self.records(int(idx[0]), 1)
+        return CortexRecord(w[0], cov[0], edges[0], self._k, int(idx[0]))
+
+    # ---- Iterable<CortexRecord>, Iterator<CortexRecord>
+    def position(self, i=None):
+        if i is None:
+            return self._pos
+        if i < 0:
+            raise _native.CortexJDKException("Record index is prefix of range (%d vs 0-%d)" % (i, self._N - 1))
+        self._pos = i
+
+    def __iter__(self):
+        chunk = 1 << 16
+        for first in range(0, self._N, chunk):
+            n = min(chunk, self._N - first)
+            w, c, e = self.records(first, n)
+            for j in range(n):
+                self._pos = first + j + 1
+                yield CortexRecord(w[j], c[j], e[j], self._k, first + j)
+
+    def remove(self):
+        raise NotImplementedError("UnsupportedOperationException")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.check(self._d.ldbg_graph_close(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,333 @@
+"""Host-side mirror of Corticall's traversal API over libldbg.
+
+Mirrors  uk.ac.ox.well.cortexjdk.utils.traversal.TraversalEngineFactory / TraversalEngine /
+         TraversalEngineConfiguration / CortexVertex / TraversalUtils.toContig
+         uk.ac.ox.well.cortexjdk.utils.io.graph.links.CortexLinks
+         uk.ac.ox.well.cortexjdk.utils.stoppingrules.*  (as names; the rules run on the device)
+All traversal work happens in HIP kernels behind the C ABI (include/ldbg.h).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from .graph import CortexGraph, CortexRecord, _as_bytes
+
+# J/utils/stoppingrules/*.java, in the order of ldbg_stopper
+STOPPING_RULES = [
+    "ContigStopper", "CycleCollapsingContigStopper", "DestinationStopper", "ExplorationStopper",
+    "NovelPartitionStopper", "NovelKmerLimitedContigStopper", "NovelContinuationStopper",
+    "BubbleClosingStopper", "BubbleOpeningStopper", "ContaminantStopper", "DustStopper",
+    "GapClosingStopper", "NahrStopper", "NovelKmerAggregationStopper", "OrphanStopper",
+    "PairedReadClosingStopper", "TipBeginningStopper", "TipEndStopper", "VisualizationStopper",
+]
+globals().update({name: name for name in STOPPING_RULES})   # ContigStopper = "ContigStopper", ...
+
+BOTH, FORWARD, REVERSE = 0, 1, 2      # TraversalEngineConfiguration.TraversalDirection
+OR, AND = 0, 1                        # TraversalEngineConfiguration.GraphCombinationOperator
+
+
+class CortexLinks:
+    """J/utils/io/graph/links/CortexLinks.java (un-indexed .ctp.gz -> CortexLinksMap)"""
+
+    def __init__(self, path, graph, lib=None):
+        self._lib = lib or graph._lib
+        self._d = self._lib.dll
+        self.path = str(path)
+        h = C.c_void_p()
+        self._lib.check(self._d.ldbg_links_open(self.path.encode(), graph._h, C.byref(h)))
+        self._h = h
+        self._graph = graph
+        v, nc, k = C.c_int(), C.c_int(), C.c_int()
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._lib.check(self._d.ldbg_links_info(h, C.byref(v), C.byref(nc), C.byref(k), C.byref(a), C.byref(b), C.byref(c)))
+        self.version, self.numColors, self.kmerSize = v.value, nc.value, k.value
+        self.numKmersInGraph, self.numKmersWithLinks, self.numLinks = a.value, b.value, c.value
+
+    def getFile(self): return self.path
+    def size(self): return self.numKmersWithLinks
+    def isEmpty(self): return self.numKmersWithLinks == 0
+    def getSource(self): return "unknown"
+
+    def getSampleNameForColor(self, c):
+        buf = C.create_string_buffer(4096)
+        self._lib.check(self._d.ldbg_links_sample_name(self._h, int(c), buf, 4096))
+        return buf.value.decode()
+
+    def _get(self, key):
+        kb = _as_bytes(key.getKmerAsBytes() if hasattr(key, "getKmerAsBytes") else key)
+        found = C.c_int()
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            st = self._d.ldbg_links_get(self._h, kb, C.byref(found), buf, C.c_int64(cap))
+            if st == 7:
+                cap *= 8
+                continue
+            self._lib.check(st)
+            return bool(found.value), buf.value.decode()
+
+    def containsKey(self, key): return self._get(key)[0]
+
+    def get(self, key):
+        """-> (record k-mer, [(isForward, numJunctions, coverages, junctions)]) in the reference's HashSet order, or None"""
+        found, text = self._get(key)
+        if not found:
+            return None
+        lines = [l for l in text.split("\n") if l]
+        kmer = lines[0].split()[0]
+        out = []
+        for l in lines[1:]:
+            f = l.split()
+            out.append((f[0] == "F", int(f[1]), [int(x) for x in f[2].split(",")], f[3]))
+        return kmer, out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.check(self._d.ldbg_links_close(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CortexVertex:
+    """J/utils/traversal/CortexVertex.java"""
+
+    def __init__(self, kmer, record, copyIndex=0, index=0):
+        self._kmer, self._record, self._copyIndex, self._index = kmer, record, copyIndex, index
+
+    def getKmerAsString(self): return self._kmer
+    def getCortexRecord(self): return self._record
+    def getCanonicalKmer(self): return self._record.getKmerAsString() if self._record is not None else None
+    def getCopyIndex(self): return self._copyIndex
+    def getIndex(self): return self._index
+
+    def _key(self): return (self._kmer, self._record, self._copyIndex, self._index)
+    def __eq__(self, o): return isinstance(o, CortexVertex) and self._key() == o._key()
+    def __hash__(self): return hash(self._key())
+    def __repr__(self): return "CortexVertex{sk=%s, index=%d, copyIndex=%d}" % (self._kmer, self._index, self._copyIndex)
+
+
+class TraversalUtils:
+    """J/utils/traversal/TraversalUtils.java (the members on the hot path)"""
+
+    @staticmethod
+    def toContig(walk):    # :367-381
+        s = ""
+        for v in walk:
+            sk = v.getKmerAsString()
+            s = sk if not s else s + sk[-1]
+        return s
+
+
+class TraversalEngineFactory:
+    """J/utils/traversal/TraversalEngineFactory.java:12-88 — builder; make() validates like the reference."""
+
+    def __init__(self, lib=None):
+        self._lib = lib
+        self._trav, self._join, self._recruit, self._secondary = [], set(), set(), set()
+        self._op, self._dir, self._connect, self._maxlen = OR, BOTH, False, 75000
+        self._stopper = "ContigStopper"
+        self._graph = self._rois = None
+        self._links = []
+        self._strict = True
+
+    def combinationOperator(self, op): self._op = op; return self
+    def traversalDirection(self, td): self._dir = td; return self
+    def connectAllNeighbors(self, b): self._connect = bool(b); return self
+    def maxBranchLength(self, n): self._maxlen = int(n); return self
+
+    @staticmethod
+    def _flat(colors):
+        out = []
+        for c in colors:
+            out.extend(c) if isinstance(c, (list, tuple, set)) else out.append(c)
+        return [int(c) for c in out]
+
+    def traversalColors(self, *colors):
+        if not colors:
+            self._trav = []
+        for c in self._flat(colors):
+            if c not in self._trav:
+                self._trav.append(c)
+        return self
+
+    def joiningColors(self, *colors):
+        self._join = set() if not colors else self._join | set(self._flat(colors)); return self
+
+    def recruitmentColors(self, *colors):
+        self._recruit = set() if not colors else self._recruit | set(self._flat(colors)); return self
+
+    def secondaryColors(self, *colors):
+        self._secondary = set() if not colors else self._secondary | set(self._flat(colors)); return self
+
+    def stoppingRule(self, rule): self._stopper = rule; return self
+    def graph(self, g): self._graph = g; return self
+    def rois(self, g): self._rois = g; return self
+
+    def links(self, *links):
+        if not links:
+            self._links = []
+        for l in links:
+            if l is None:
+                continue
+            for x in (l if isinstance(l, (list, tuple, set)) else [l]):
+                if x not in self._links:
+                    self._links.append(x)
+        return self
+
+    def strictJavaFlip(self, b): self._strict = bool(b); return self
+
+    def make(self):
+        if self._graph is None:
+            raise _native.CortexJDKException("Must provide graph to traverse.")
+        return TraversalEngine(self)
+
+
+class TraversalEngine:
+    """J/utils/traversal/TraversalEngine.java"""
+
+    def __init__(self, f):
+        g = f._graph
+        self._lib = f._lib or g._lib
+        self._d = self._lib.dll
+        self._graph = g
+        cfg = _native.EngineConfig()
+        self._d.ldbg_engine_config_default(C.byref(cfg))
+        cfg.graph = g._h
+        cfg.rois = f._rois._h if f._rois is not None else None
+        self._links = list(f._links)
+        self._link_arr = (C.c_void_p * max(1, len(self._links)))(*[l._h for l in self._links])
+        cfg.links = C.cast(self._link_arr, C.POINTER(C.c_void_p))
+        cfg.nlinks = len(self._links)
+        for name, vals in (("traversal", f._trav), ("joining", sorted(f._join)), ("recruitment", sorted(f._recruit)),
+                           ("secondary", sorted(f._secondary))):
+            arr = getattr(cfg, name + "_colors")
+            for i, c in enumerate(vals[:_native.MAX_COLORS]):
+                arr[i] = c
+            setattr(cfg, "n_" + name, len(vals))
+        cfg.direction, cfg.combination_operator = f._dir, f._op
+        cfg.stopping_rule = STOPPING_RULES.index(f._stopper) if isinstance(f._stopper, str) else int(f._stopper)
+        cfg.max_branch_length = f._maxlen
+        cfg.connect_all_neighbors = 1 if f._connect else 0
+        cfg.strict_java_flip = 1 if f._strict else 0
+        self._cfg = cfg
+        self._trav = list(f._trav)
+        h = C.c_void_p()
+        self._lib.check(self._d.ldbg_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.kmers_traversed = 0
+
+    # ---- batch forms
+    def walk_batch(self, seeds):
+        """seeds: list of str or np.uint8[n,k] -> (contigs list[str], walk_len i64[n]); device-resident until fetched"""
+        arena, offs, wl = self.walk_batch_arrays(seeds)
+        raw = arena.tobytes()
+        return [raw[offs[i]:offs[i + 1]].decode() for i in range(len(wl))], wl
+
+    def walk_batch_arrays(self, seeds, fetch=True):
+        k = self._graph.getKmerSize()
+        if isinstance(seeds, np.ndarray):
+            a = np.ascontiguousarray(seeds, dtype=np.uint8)
+        else:
+            a = np.frombuffer(b"".join(_as_bytes(s) for s in seeds), dtype=np.uint8).reshape(len(seeds), k)
+        n = a.shape[0]
+        total, trav = C.c_int64(), C.c_int64()
+        self._lib.check(self._d.ldbg_engine_walk_batch_run(self._h, a.ctypes.data_as(C.c_char_p), C.c_int64(n),
+                                                           C.byref(total), C.byref(trav)))
+        self.kmers_traversed = trav.value
+        self.last_total_bytes = total.value
+        if not fetch:
+            return None, None, None
+        arena = np.empty(max(1, total.value), dtype=np.uint8)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        wl = np.zeros(max(1, n), dtype=np.int64)
+        self._lib.check(self._d.ldbg_engine_walk_batch_fetch(self._h, arena.ctypes.data_as(C.c_char_p), C.c_int64(total.value),
+                                                             offs.ctypes.data_as(C.c_void_p), wl.ctypes.data_as(C.c_void_p)))
+        return arena[:total.value], offs, wl[:n]
+
+    def walk_vertices(self, i):
+        """vertices of walk i of the last batch -> list[CortexVertex]"""
+        W, k = self._graph.getKmerBits(), self._graph.getKmerSize()
+        ln = C.c_int64()
+        st = self._d.ldbg_engine_walk_vertices(self._h, C.c_int64(i), C.c_int64(0), C.byref(ln), None, None, None, None)
+        if st not in (0, 7):
+            self._lib.check(st)
+        n = ln.value
+        if n == 0:
+            return []
+        words = np.empty((n, W), dtype=np.uint64)
+        rec = np.empty(n, dtype=np.int64)
+        copy = np.empty(n, dtype=np.int32)
+        index = np.empty(n, dtype=np.int32)
+        self._lib.check(self._d.ldbg_engine_walk_vertices(self._h, C.c_int64(i), C.c_int64(n), C.byref(ln),
+                                                          words.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p),
+                                                          copy.ctypes.data_as(C.c_void_p), index.ctypes.data_as(C.c_void_p)))
+        out = []
+        cache = {}
+        for j in range(n):
+            r = int(rec[j])
+            if r >= 0 and r not in cache:
+                cache[r] = self._graph.getRecord(r)
+            kmer = CortexRecord(words[j], [0], [0], k).getKmerAsString()
+            out.append(CortexVertex(kmer, cache.get(r), int(copy[j]), int(index[j])))
+        return out
+
+    # ---- TraversalEngine members
+    def walk(self, seed):        # :108-110
+        self.walk_batch_arrays([seed], fetch=False)
+        return self.walk_vertices(0)
+
+    def dfs(self, source, *sinks):   # :64-106
+        res = C.c_void_p()
+        self._lib.check(self._d.ldbg_engine_dfs_batch(self._h, _as_bytes(source), C.c_int64(1), None, None, C.byref(res)))
+        raise NotImplementedError
+
+    def seek(self, sk):          # :321-335
+        self._lib.check(self._d.ldbg_engine_seek(self._h, _as_bytes(sk)))
+
+    def hasNext(self):
+        y = C.c_int()
+        self._lib.check(self._d.ldbg_engine_has_next(self._h, C.byref(y)))
+        return bool(y.value)
+
+    def hasPrevious(self):
+        y = C.c_int()
+        self._lib.check(self._d.ldbg_engine_has_previous(self._h, C.byref(y)))
+        return bool(y.value)
+
+    def _step(self, fn):
+        k = self._graph.getKmerSize()
+        buf = C.create_string_buffer(k + 1)
+        rec = C.c_int64()
+        self._lib.check(fn(self._h, buf, C.byref(rec)))
+        r = self._graph.getRecord(rec.value) if rec.value >= 0 else None
+        return CortexVertex(buf.value.decode(), r)
+
+    def next(self): return self._step(self._d.ldbg_engine_next)           # :241-279
+    def previous(self): return self._step(self._d.ldbg_engine_previous)   # :281-319
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.check(self._d.ldbg_engine_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def profile_reset(lib=None):
+    (lib or _native.default_lib()).dll.ldbg_profile_reset()
+
+
+def profile_get(family, lib=None):
+    ms, n = C.c_double(), C.c_int64()
+    (lib or _native.default_lib()).dll.ldbg_profile_get(family.encode(), C.byref(ms), C.byref(n))
+    return ms.value, n.value

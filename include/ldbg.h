@@ -1,0 +1,204 @@
+/* ldbg.h — C ABI of libldbg.so, the MI355X-native LdBG traversal engine.
+ *
+ * This is the drop-in boundary for ONE hot path of mcveanlab/Corticall: CortexGraph record
+ * iteration, binary-search random access (findRecord) and the link-guided walk / DFS of
+ * TraversalEngine.  The reference has no FFI for this path; the seam is two Java interfaces
+ * and one façade, so every entry point below cites the Java member it replaces
+ * (J/ = public/java/src/uk/ac/ox/well/cortexjdk/).  A JNI / ctypes binding calls exactly
+ * these functions.
+ *
+ * Conventions
+ *   - every function returns an ldbg_status; on failure ldbg_last_error() (thread-local)
+ *     holds the message the reference would have put in its exception.
+ *   - k-mers cross the boundary either as ASCII (n × k bytes, no terminators) or as
+ *     "packed words": W = ceil(k/32) uint64 per k-mer, word 0 most significant, 2 bits per
+ *     base (A=0,C=1,G=2,T=3), right aligned — the value McCortex stores in a .ctx record
+ *     (docs/ctx_spec.md "Binary kmer specification").
+ *   - plain pointers and sizes only; "_dev" variants take device pointers (HBM resident
+ *     inputs/outputs) and a hipStream_t passed as void*; all others take host pointers.
+ *   - handles are not thread-safe (neither are the reference's objects); distinct handles
+ *     may be used from distinct threads.
+ *   - there is NO CPU fallback: every call that computes runs HIP kernels on the handle's
+ *     device and fails with LDBG_ERR_HIP when no GPU is present.
+ */
+#ifndef LDBG_H
+#define LDBG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LDBG_OK = 0,
+    LDBG_ERR_CORTEXJDK = 1,      /* J/utils/exceptions/CortexJDKException (bad magic/version/unsorted/IO/config) */
+    LDBG_ERR_NULLPOINTER = 2,    /* input on which the reference throws NullPointerException */
+    LDBG_ERR_NOSUCHELEMENT = 3,  /* TraversalEngine.next()/previous() without a successor (TraversalEngine.java:242,282) */
+    LDBG_ERR_UNSUPPORTED = 4,
+    LDBG_ERR_HIP = 5,            /* no device / HIP runtime failure */
+    LDBG_ERR_ARG = 6,
+    LDBG_ERR_CAPACITY = 7        /* caller-provided output buffer too small; required size is reported */
+} ldbg_status;
+
+typedef struct ldbg_graph ldbg_graph;     /* DeBruijnGraph backed by a .ctx file, resident in HBM */
+typedef struct ldbg_links ldbg_links;     /* ConnectivityAnnotations (.ctp.gz), resident in HBM */
+typedef struct ldbg_engine ldbg_engine;   /* TraversalEngine */
+typedef struct ldbg_dfs_result ldbg_dfs_result;
+
+const char* ldbg_last_error(void);
+const char* ldbg_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; no compute entry point works then) */
+ldbg_status ldbg_device_count(int* count);
+
+/* ------------------------------------------------------------------ k-mer helpers (host, no GPU needed)
+ * CortexRecord.encodeBinaryKmer / decodeBinaryKmer (J/utils/io/graph/cortex/CortexRecord.java:291-334) */
+ldbg_status ldbg_kmer_encode(const char* ascii, int k, uint64_t* words_out);
+ldbg_status ldbg_kmer_decode(const uint64_t* words, int k, char* ascii_out /* k bytes + NUL */);
+
+/* ------------------------------------------------------------------ graph: G1-G3
+ * new CortexGraph(path)              J/utils/io/graph/cortex/CortexGraph.java:40-48, 66-168
+ * The file is parsed on the host, streamed to the device, verified strictly ascending
+ * (the reference asserts sortedness lazily at :295-301) and laid out in HBM. */
+ldbg_status ldbg_graph_open(const char* path, int device, ldbg_graph** out);
+/* same, from an in-memory image of a .ctx file (header + records) */
+ldbg_status ldbg_graph_open_memory(const void* image, int64_t nbytes, int device, ldbg_graph** out);
+ldbg_status ldbg_graph_close(ldbg_graph* g);                                     /* DeBruijnGraph.close() */
+/* getKmerSize/getKmerBits/getNumColors/getNumRecords/getVersion   CortexGraph.java:325-335 */
+ldbg_status ldbg_graph_info(const ldbg_graph* g, int* k, int* W, int* C, int64_t* N, int* version);
+ldbg_status ldbg_graph_device(const ldbg_graph* g, int* device);
+/* getSampleName(color) / getColor(color)                          CortexGraph.java:329,335 */
+ldbg_status ldbg_graph_sample_name(const ldbg_graph* g, int color, char* buf, int buflen);
+typedef struct {
+    uint32_t mean_read_length;
+    uint64_t total_sequence;            /* as the reference reads it (big-endian) */
+    uint8_t tip_clipping, low_covg_supernodes_removed, low_covg_kmers_removed, cleaned_against_graph;
+    uint32_t low_cov_supernodes_threshold, low_cov_kmer_threshold;
+} ldbg_color_info;
+ldbg_status ldbg_graph_color_info(const ldbg_graph* g, int color, ldbg_color_info* out,
+                                  char* cleaned_against_name, int buflen);
+/* getColorForSampleName(name)                                     CortexGraph.java:337-357 ; -1 if none/ambiguous */
+ldbg_status ldbg_graph_color_for_sample_name(const ldbg_graph* g, const char* name, int* color);
+
+/* Iterator<CortexRecord>.next() / getRecord(i) in bulk             CortexGraph.java:183-258
+ * records [first, first+n): kmer_words n×W, cov n×C (the reference's signed int view of the
+ * LE u32), edges n×C.  Indices >= N yield LDBG_ERR_ARG (the reference returns null, Q2). */
+ldbg_status ldbg_graph_records(const ldbg_graph* g, int64_t first, int64_t n,
+                               uint64_t* kmer_words, uint32_t* cov, uint8_t* edges);
+ldbg_status ldbg_graph_records_dev(const ldbg_graph* g, int64_t first, int64_t n,
+                                   uint64_t* d_kmer_words, uint32_t* d_cov, uint8_t* d_edges, void* stream);
+
+/* findRecord(byte[] | CortexByteKmer | CanonicalKmer | String)    CortexGraph.java:272-321
+ * Queries are canonicalised on the device (SequenceUtils.alphanumericallyLowestOrientation).
+ * idx_out[i] = record index, or -1 where the reference returns null: absent k-mer, non-ACGT
+ * query (ASCII form, Q4), or N <= 2 (Q1, cold cache).  cov_out / edges_out (n×C) may be NULL;
+ * rows of misses are zero. */
+ldbg_status ldbg_graph_find(const ldbg_graph* g, const uint64_t* packed, int64_t n,
+                            int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out);
+ldbg_status ldbg_graph_find_ascii(const ldbg_graph* g, const char* kmers, int64_t n,
+                                  int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out);
+ldbg_status ldbg_graph_find_dev(const ldbg_graph* g, const uint64_t* d_packed, int64_t n,
+                                int64_t* d_idx_out, uint32_t* d_cov_out, uint8_t* d_edges_out, void* stream);
+
+/* ------------------------------------------------------------------ links: L3-L4
+ * new CortexLinks(path) -> CortexLinksMap        J/utils/io/graph/links/CortexLinks.java:16-25,
+ * CortexLinksIterable.java:49-226 (.ctp.gz text, JSON header v2/3/4).  Bound to a graph for k / device. */
+ldbg_status ldbg_links_open(const char* path, const ldbg_graph* g, ldbg_links** out);
+ldbg_status ldbg_links_close(ldbg_links* l);
+ldbg_status ldbg_links_info(const ldbg_links* l, int* version, int* num_colors, int* k,
+                            int64_t* num_kmers_in_graph, int64_t* num_kmers_with_links, int64_t* num_links);
+ldbg_status ldbg_links_sample_name(const ldbg_links* l, int color, char* buf, int buflen);
+/* ConnectivityAnnotations.containsKey / get     J/utils/io/graph/ConnectivityAnnotations.java:23-25
+ * Writes the record as text "KMER n\n(F|R) len cov[,cov] junctions\n..." in the reference's HashSet
+ * iteration order; *found = 0 and empty text when the k-mer has no links. */
+ldbg_status ldbg_links_get(const ldbg_links* l, const char* kmer_ascii, int* found, char* buf, int64_t buflen);
+
+/* ------------------------------------------------------------------ engine: C1, E1-E3, D1-D2, W1, S1-S3 */
+typedef enum {   /* J/utils/stoppingrules/ (one enumerator per rule class) */
+    LDBG_STOP_CONTIG = 0, LDBG_STOP_CYCLE_COLLAPSING_CONTIG, LDBG_STOP_DESTINATION, LDBG_STOP_EXPLORATION,
+    LDBG_STOP_NOVEL_PARTITION, LDBG_STOP_NOVEL_KMER_LIMITED_CONTIG, LDBG_STOP_NOVEL_CONTINUATION,
+    LDBG_STOP_BUBBLE_CLOSING, LDBG_STOP_BUBBLE_OPENING, LDBG_STOP_CONTAMINANT, LDBG_STOP_DUST,
+    LDBG_STOP_GAP_CLOSING, LDBG_STOP_NAHR, LDBG_STOP_NOVEL_KMER_AGGREGATION, LDBG_STOP_ORPHAN,
+    LDBG_STOP_PAIRED_READ_CLOSING, LDBG_STOP_TIP_BEGINNING, LDBG_STOP_TIP_END, LDBG_STOP_VISUALIZATION,
+    LDBG_STOP_COUNT
+} ldbg_stopper;
+enum { LDBG_DIR_BOTH = 0, LDBG_DIR_FORWARD = 1, LDBG_DIR_REVERSE = 2 };   /* TraversalDirection */
+enum { LDBG_OP_OR = 0, LDBG_OP_AND = 1 };                                 /* GraphCombinationOperator */
+#define LDBG_MAX_COLORS 32
+
+/* TraversalEngineConfiguration (J/utils/traversal/TraversalEngineConfiguration.java:19-37) as a POD;
+ * ldbg_engine_config_default() fills the reference's defaults (BOTH, OR, ContigStopper, 75000). */
+typedef struct {
+    const ldbg_graph* graph;
+    const ldbg_graph* rois;                 /* may be NULL */
+    const ldbg_links* const* links;         /* nlinks entries; order = order of addition */
+    int nlinks;
+    int traversal_colors[LDBG_MAX_COLORS]; int n_traversal;      /* LinkedHashSet: insertion order */
+    int joining_colors[LDBG_MAX_COLORS]; int n_joining;          /* TreeSet */
+    int recruitment_colors[LDBG_MAX_COLORS]; int n_recruitment;  /* TreeSet */
+    int secondary_colors[LDBG_MAX_COLORS]; int n_secondary;      /* TreeSet */
+    int direction;                          /* LDBG_DIR_* */
+    int combination_operator;               /* LDBG_OP_* */
+    int stopping_rule;                      /* ldbg_stopper */
+    int max_branch_length;                  /* maxLength, default 75000 */
+    int connect_all_neighbors;
+    int strict_java_flip;                   /* 1: CanonicalKmer.isFlipped by Arrays.hashCode inequality (Q6) */
+} ldbg_engine_config;
+void ldbg_engine_config_default(ldbg_engine_config* cfg);
+
+/* TraversalEngineFactory.make()                 J/utils/traversal/TraversalEngineFactory.java:54-88 */
+ldbg_status ldbg_engine_create(const ldbg_engine_config* cfg, ldbg_engine** out);
+ldbg_status ldbg_engine_destroy(ldbg_engine* e);
+
+/* walk(seed) + TraversalUtils.toContig, for n seeds at once       TraversalEngine.java:108-110,
+ * TraversalUtils.java:367-488.  seeds: n × k ASCII.  The contigs are written back to back into
+ * contig_arena (ASCII); offsets[n+1]; walk_len[i] = number of vertices of walk i (0: empty walk,
+ * empty contig).  kmers_traversed (may be NULL) receives the number of dfs loop iterations + cursor
+ * steps the batch performed (SURVEY §8d's unit).  If the arena is too small, LDBG_ERR_CAPACITY is
+ * returned and offsets[n] holds the required size. */
+ldbg_status ldbg_engine_walk_batch(ldbg_engine* e, const char* seeds, int64_t n,
+                                   char* contig_arena, int64_t arena_capacity, int64_t* offsets,
+                                   int64_t* walk_len, int64_t* kmers_traversed);
+/* two-phase device form: run the batch (results stay in HBM), then query sizes / copy out */
+ldbg_status ldbg_engine_walk_batch_run(ldbg_engine* e, const char* seeds, int64_t n,
+                                       int64_t* total_contig_bytes, int64_t* kmers_traversed);
+ldbg_status ldbg_engine_walk_batch_fetch(ldbg_engine* e, char* contig_arena, int64_t arena_capacity,
+                                         int64_t* offsets, int64_t* walk_len);
+/* vertices of walk i of the last batch: packed k-mer words (len × W), record index (-1 = null
+ * CortexRecord), copyIndex, index (CortexVertex.java:20-35) */
+ldbg_status ldbg_engine_walk_vertices(ldbg_engine* e, int64_t walk, int64_t capacity, int64_t* len,
+                                      uint64_t* kmer_words, int64_t* rec, int32_t* copy_index, int32_t* index);
+
+/* dfs(source, sinks...) for n sources                               TraversalEngine.java:64-106, 356-482
+ * sources n × k ASCII; sinks as CSR over ASCII k-mers (sink_offsets[n+1] counts k-mers; may be NULL). */
+ldbg_status ldbg_engine_dfs_batch(ldbg_engine* e, const char* sources, int64_t n,
+                                  const char* sinks, const int64_t* sink_offsets, ldbg_dfs_result** out);
+/* result i: is_null = dfs returned null; vertices in insertion order; edges (src,dst index into vertices, colour) */
+ldbg_status ldbg_dfs_result_sizes(const ldbg_dfs_result* r, int64_t i, int* is_null, int64_t* n_vertices, int64_t* n_edges);
+ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result* r, int64_t i,
+                                uint64_t* kmer_words, int64_t* rec, int32_t* copy_index, int32_t* index,
+                                int32_t* edge_src, int32_t* edge_dst, int32_t* edge_color);
+/* TraversalUtils.toWalk(g, seed, colour) + toContig on result i    TraversalUtils.java:367-488 */
+ldbg_status ldbg_dfs_result_walk(const ldbg_dfs_result* r, int64_t i, const char* seed, int color,
+                                 char* contig, int64_t capacity, int64_t* len);
+ldbg_status ldbg_dfs_result_free(ldbg_dfs_result* r);
+ldbg_status ldbg_engine_dfs_kmers_traversed(const ldbg_engine* e, int64_t* n);
+
+/* cursor: seek / next / previous / hasNext / hasPrevious          TraversalEngine.java:241-339
+ * (stateful, batch of one; each call runs on the device) */
+ldbg_status ldbg_engine_seek(ldbg_engine* e, const char* kmer);
+ldbg_status ldbg_engine_has_next(ldbg_engine* e, int* yes);
+ldbg_status ldbg_engine_has_previous(ldbg_engine* e, int* yes);
+ldbg_status ldbg_engine_next(ldbg_engine* e, char* kmer_out, int64_t* rec_out);
+ldbg_status ldbg_engine_previous(ldbg_engine* e, char* kmer_out, int64_t* rec_out);
+
+/* ------------------------------------------------------------------ measurement hooks (bench.py)
+ * average device time (ms, HIP events on the launch stream) and launch count of the named kernel
+ * family since the last reset: "find", "records", "walk", "dfs", "contig". */
+ldbg_status ldbg_profile_reset(void);
+ldbg_status ldbg_profile_get(const char* family, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDBG_H */

@@ -296,7 +296,8 @@ public:
     std::vector<Vertex> next_vertices(const std::string& sk);                                           // :194-239
     std::vector<Vertex> prev_vertices(const std::string& sk);                                           // :147-192
     const std::string& cursor() const { return cur_; }
-    uint64_t kmers_traversed = 0;      // dfs loop iterations + cursor steps (SURVEY §8d metric)
+    uint64_t dfs_iterations = 0;       // dfs loop iterations: the "k-mers traversed" unit of walk/dfs batches
+    uint64_t cursor_steps = 0;         // next()/previous() calls (also made from inside dfs when links are present)
     Record record_of(const Vertex& v);
     int32_t vertex_jhash(const Vertex& v);
 

@@ -458,7 +458,7 @@ Vertex TraversalEngine::step(bool fwd) {
     }
     if (fwd) { has_next_ = have; next_ = target; } else { has_prev_ = have; prev_ = target; }
     if (store_.num_new_paths() > 0) store_.increment_ages();    // Q12
-    kmers_traversed++;
+    cursor_steps++;
     return cv;
 }
 Vertex TraversalEngine::next() { return step(true); }
@@ -490,7 +490,7 @@ std::unique_ptr<PGraph> TraversalEngine::dfs_branch(Vertex cv, bool fwd, int gra
 
     std::vector<Vertex> avs, rvs;
     do {
-        kmers_traversed++;
+        dfs_iterations++;
         std::vector<Vertex> pvs = prev_vertices(cv.sk);
         std::vector<Vertex> nvs = next_vertices(cv.sk);
         avs = fwd ? nvs : pvs;

@@ -205,7 +205,8 @@ static int step(void* ep, bool fwd, char* kmer_out, int64_t* rec_out) {
 }
 int orc_engine_next(void* ep, char* kmer_out, int64_t* rec_out) { return step(ep, true, kmer_out, rec_out); }
 int orc_engine_previous(void* ep, char* kmer_out, int64_t* rec_out) { return step(ep, false, kmer_out, rec_out); }
-uint64_t orc_engine_kmers_traversed(void* ep) { return ((Engine*)ep)->e.kmers_traversed; }
+uint64_t orc_engine_kmers_traversed(void* ep) { return ((Engine*)ep)->e.dfs_iterations; }
+uint64_t orc_engine_cursor_steps(void* ep) { return ((Engine*)ep)->e.cursor_steps; }
 
 // walk(seed) -> contig string; *nverts = walk length (0 = empty walk, contig "")
 int orc_engine_walk(void* ep, const char* seed, char* contig_out, int64_t cap, int64_t* len_out, int64_t* nverts) {

@@ -1,0 +1,333 @@
+"""Parity cases shared by the CPU host-simulation run (tests/test_hostsim_parity.py, `-m "not gpu"`)
+and the real-hardware run (tests/test_gpu_parity.py, `-m gpu`).  Every case drives the product API
+(corticall_amd over the C ABI) and compares bit-exactly with the CPU oracle on the same inputs.
+Cases named test_ref_* restate the reference's own tests
+(T/ = public/java/tests/uk/ac/ox/well/cortexjdk/)."""
+import os
+import random
+
+import numpy as np
+
+import corticall_amd as ca
+from corticall_amd import (AND, BOTH, FORWARD, OR, REVERSE, ContigStopper, CortexGraph, CortexLinks,
+                           TraversalEngineFactory, TraversalUtils)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rand_seq(rng, n, gc=0.5):
+    return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(n))
+
+
+def mutate(rng, s, snv=0.01, indel=0.002):
+    out = []
+    i = 0
+    while i < len(s):
+        r = rng.random()
+        if r < snv:
+            out.append(rng.choice([b for b in "ACGT" if b != s[i]]))
+        elif r < snv + indel:
+            if rng.random() < 0.5:
+                out.append(s[i] + rand_seq(rng, rng.randint(1, 4)))
+            # else: deletion
+        else:
+            out.append(s[i])
+        i += 1
+    return "".join(out)
+
+
+def genome_with_repeats(rng, n, n_rep=6, rep_len=(8, 60), copies=(2, 4), gc=0.5):
+    s = rand_seq(rng, n, gc)
+    for _ in range(n_rep):
+        L = rng.randint(*rep_len)
+        rep = rand_seq(rng, L, gc)
+        for _ in range(rng.randint(*copies)):
+            p = rng.randint(0, len(s))
+            s = s[:p] + rep + s[p:]
+    # a tandem repeat (forces cycles)
+    unit = rand_seq(rng, rng.randint(3, 12), gc)
+    p = rng.randint(0, len(s))
+    s = s[:p] + unit * rng.randint(3, 6) + s[p:]
+    return s
+
+
+class Case:
+    """a small multi-colour graph (+ optional links) built with the oracle's fixture tools"""
+
+    def __init__(self, orc, tmp, lib, haps, k, link_samples=(), reads=None, name="g"):
+        self.orc, self.lib, self.k = orc, lib, k
+        self.path = str(tmp / (name + ".ctx"))
+        orc.build_graph(self.path, haps, k)
+        self.og = orc.Graph(self.path, tuned=True)
+        self.g = CortexGraph(self.path, lib=lib)
+        self.haps = dict(haps)
+        self.olinks, self.links = {}, {}
+        for s in link_samples:
+            lp = str(tmp / (name + "." + s + ".ctp.gz"))
+            orc.build_links(self.og, lp, s, (reads or self.haps)[s])
+            self.olinks[s] = orc.Links(lp)
+            self.links[s] = CortexLinks(lp, self.g)
+
+    def all_kmers(self):
+        return [self.og.record_string(i).split()[0] for i in range(self.og.N)]
+
+    def engines(self, trav, links=(), recruit=(), op=OR, direction=BOTH, max_len=75000):
+        oe = self.orc.Engine(self.og, trav, links=[self.olinks[s] for s in links], recruitment_colors=recruit,
+                             op_and=(op == AND), direction=direction, max_length=max_len, stopper="ContigStopper")
+        f = (TraversalEngineFactory(lib=self.lib).traversalColors(*trav).graph(self.g).combinationOperator(op)
+             .traversalDirection(direction).maxBranchLength(max_len).stoppingRule(ContigStopper))
+        if recruit:
+            f.recruitmentColors(*recruit)
+        if links:
+            f.links(*[self.links[s] for s in links])
+        return oe, f.make()
+
+
+def compare_walks(case, seeds, **cfg):
+    oe, e = case.engines(**cfg)
+    seeds = list(seeds)
+    got, wl = e.walk_batch(seeds)
+    km = np.frombuffer("".join(seeds).encode(), dtype=np.uint8).reshape(len(seeds), case.k)
+    arena, offs, nv = oe.walk_batch(km)
+    raw = arena.tobytes()
+    exp = [raw[offs[i]:offs[i + 1]].decode() for i in range(len(seeds))]
+    for i, s in enumerate(seeds):
+        assert got[i] == exp[i], (s, cfg, got[i], exp[i])
+    assert (wl == nv).all()
+    assert e.kmers_traversed == oe.kmers_traversed(), (e.kmers_traversed, oe.kmers_traversed())
+    return exp
+
+
+# ------------------------------------------------------------------ graph / records / find
+def case_fixture_graph(orc, lib, tmp):
+    g = CortexGraph(os.path.join(GOLDEN, "two_short_contigs.ctx"), lib=lib)
+    rows = [l.split() for l in open(os.path.join(GOLDEN, "two_short_contigs.expected.txt"))]
+    assert (g.getKmerSize(), g.getKmerBits(), g.getNumColors(), g.getNumRecords(), g.getVersion()) == (31, 1, 2, 66, 6)
+    assert g.getSampleName(0) == "one" and g.getSampleName(1) == "two"            # CortexGraphTest.java:140-145
+    assert g.getColorForSampleName("two") == 1 and g.getColorForSampleName("nope") == -1
+    recs = [cr.toString() for cr in g]                                             # :187-198
+    assert recs == [" ".join(r) for r in rows]
+    for i in range(10, -1, -1):                                                    # :256-265
+        assert g.getRecord(i).toString() == " ".join(rows[i])
+    assert g.getRecord(66) is None
+    for i, r in enumerate(rows):                                                   # :311-320
+        cr = g.findRecord(r[0])
+        assert cr.toString() == " ".join(r) and cr.index == i
+        assert g.findRecord(orc.revcomp(r[0])).index == i
+    assert g.findRecord("NTTTTGGGGTATTTGCAGTATTTGGAATAAA") is None                 # :323-331
+    assert g.findRecord("A" * 31) is None
+    w, c, e = g.records(0, 66)
+    for i, r in enumerate(rows):
+        assert [int(x) for x in w[i]] == orc.encode_kmer(r[0])
+    g.close()
+
+
+def case_random_find(orc, lib, tmp, k, ncol, n=3000, seed=1):
+    rng = random.Random(seed * 1000 + k)
+    base = genome_with_repeats(rng, n)
+    haps = [("s%d" % c, [base if c == 0 else mutate(rng, base)]) for c in range(ncol)]
+    cs = Case(orc, tmp, lib, haps, k, name="f%d_%d" % (k, ncol))
+    kmers = cs.all_kmers()
+    q = []
+    for _ in range(2000):
+        r = rng.random()
+        if r < 0.4:
+            s = rng.choice(kmers)
+            q.append(s if rng.random() < 0.5 else orc.revcomp(s))
+        elif r < 0.8:
+            q.append(rand_seq(rng, k))
+        elif r < 0.9:
+            s = list(rng.choice(kmers)); s[rng.randrange(k)] = rng.choice("ACGT"); q.append("".join(s))
+        else:
+            s = list(rng.choice(kmers)); s[rng.randrange(k)] = "N"; q.append("".join(s))
+    idx, cov, edges = cs.g.find_batch(q)
+    km = np.frombuffer("".join(q).encode(), dtype=np.uint8).reshape(len(q), k)
+    exp = cs.og.find_batch(km, tuned=False)
+    assert (idx == exp).all()
+    w, c, e = cs.g.records(0, cs.g.getNumRecords())
+    for i in range(len(q)):
+        if idx[i] >= 0:
+            assert (cov[i] == c[idx[i]]).all() and (edges[i] == e[idx[i]]).all()
+        else:
+            assert not cov[i].any() and not edges[i].any()
+    # iteration == oracle records
+    for i in range(0, cs.og.N, max(1, cs.og.N // 50)):
+        ow, oc, oe_ = cs.og.get_record(i)
+        assert [int(x) for x in w[i]] == ow and list(c[i]) == oc and list(e[i]) == oe_
+
+
+def case_q1_tiny(orc, lib, tmp):
+    p = str(tmp / "tiny.ctx")
+    orc.build_graph(p, [("s", ["ACGTT"])], 4)
+    g = CortexGraph(p, lib=lib)
+    assert g.getNumRecords() == 2
+    assert g.findRecord("ACGT") is None and g.findRecord("AACG") is None      # Q1
+    assert g.getRecord(0).getKmerAsString() == "AACG"
+
+
+def case_unsorted_rejected(orc, lib, tmp):
+    src = open(os.path.join(GOLDEN, "two_short_contigs.ctx"), "rb").read()
+    off, rs = 148, 18
+    recs = [src[off + i * rs: off + (i + 1) * rs] for i in range(66)]
+    recs[10], recs[40] = recs[40], recs[10]
+    p = str(tmp / "unsorted.ctx")
+    open(p, "wb").write(src[:off] + b"".join(recs))
+    try:
+        CortexGraph(p, lib=lib)
+        raise AssertionError("unsorted graph accepted")
+    except ca.CortexJDKException as ex:
+        assert "Records are not sorted" in str(ex)
+    open(p, "wb").write(b"NOTCTX" + src[6:])
+    try:
+        CortexGraph(p, lib=lib)
+        raise AssertionError("bad magic accepted")
+    except ca.CortexJDKException as ex:
+        assert "does not appear to be a Cortex graph" in str(ex)
+
+
+# ------------------------------------------------------------------ reference tests through the product API
+def test_ref_short_contig_reconstruction(orc, lib, tmp):     # T/utils/traversal/TraversalEngineTest.java:98-122
+    cs = Case(orc, tmp, lib, [("mom", ["AGTTCTGATCTGGGCTATATGCT"]), ("dad", ["AGTTCGAATCTGGGCTATATGCT"]),
+                              ("kid", ["AGTTCTGATCTGGGCTATGGCTA"])], 5)
+    exp = {"mom": "AGTTCTGATCTGGGCTATATGCT", "dad": "TTCGAATCTGGGCTATATGCT", "kid": "AGTTCTGATCTGGGCTATGGCT"}
+    for c in range(3):
+        e = TraversalEngineFactory(lib=lib).traversalColors(c).graph(cs.g).stoppingRule(ContigStopper).make()
+        assert TraversalUtils.toContig(e.walk("CTGGG")) == exp[cs.g.getSampleName(c)]
+
+
+def test_ref_recruitment(orc, lib, tmp):                     # TraversalEngineTest.java:125-157
+    h = "AGTTCTGATCTGGGCTATATGCT"
+    cs = Case(orc, tmp, lib, [("mom", [h]), ("dad", [h]), ("kid", ["AGTTCTG", "ATGGCTA"])], 5)
+    g = cs.g
+    f = (TraversalEngineFactory(lib=lib).traversalColors(g.getColorForSampleName("kid")).combinationOperator(AND)
+         .traversalDirection(BOTH).connectAllNeighbors(False).stoppingRule(ContigStopper).graph(g))
+    er = f.recruitmentColors(g.getColorsForSampleNames(["mom", "dad"])).make()
+    assert TraversalUtils.toContig(er.walk("GTTCT")) == h
+    er = f.recruitmentColors().make()
+    assert TraversalUtils.toContig(er.walk("GTTCT")) == "AGTTCTG"
+
+
+FIG1, FIG1_READ = "ACTGATTTCGATGCGATGCGATGCCACGGTGG", "TTTCGATGCGATGCGATGCCACG"
+
+
+def test_ref_cycles_without_and_with_links(orc, lib, tmp):   # TraversalEngineTest.java:210-250
+    cs = Case(orc, tmp, lib, [("test", [FIG1])], 5, link_samples=["test"], reads={"test": [FIG1_READ]})
+    e = TraversalEngineFactory(lib=lib).traversalColors(0).stoppingRule(ContigStopper).graph(cs.g).make()
+    assert TraversalUtils.toContig(e.walk("ACTGA")) == "ACTGATTTCGATGC"
+    l = cs.links["test"]
+    assert (l.version, l.numColors, l.kmerSize, l.numKmersInGraph, l.numKmersWithLinks, l.numLinks) == (4, 1, 5, 21, 4, 6)   # CortexLinksTest.java:32-51
+    assert l.get("ATCGC")[1] == [(j[0] == "F", len(j[1]), [1], j[1]) for j in dict(cs.olinks["test"].records())["ATCGC"]]
+    assert l.containsKey("GCGAT") and not l.containsKey("AAAAA")
+    e = TraversalEngineFactory(lib=lib).traversalColors(0).stoppingRule(ContigStopper).graph(cs.g).links(l).make()
+    w = e.walk("ACTGA")
+    assert TraversalUtils.toContig(w) == FIG1
+    assert max(v.getCopyIndex() for v in w) >= 1      # the cycle is traversed through copies of its vertices
+
+
+def test_ref_iterate_fwd_rev(orc, lib, tmp):                  # TraversalEngineTest.java:253-358
+    hap = "AGTTCGAATCTGGGCTATATGCT"
+    cs = Case(orc, tmp, lib, [("mom", [hap])], 7)
+    e = TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).make()
+    sk = "AGTTCGA"; sb = sk
+    e.seek(sk)
+    while e.hasNext():
+        sb += e.next().getKmerAsString()[-1]
+    assert sb == hap
+    sk = "ATATGCT"; sb = sk
+    e.seek(sk)
+    while e.hasPrevious():
+        sb = e.previous().getKmerAsString()[0] + sb
+    assert sb == hap
+    cs = Case(orc, tmp, lib, [("kid", ["AGTTCGAATCTGGGCTATATGCT", "AGTTCGAATCTGAGCTATATGCT"])], 7, name="fork")
+    e = TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).make()
+    sb = "AGTTCGA"
+    e.seek(sb)
+    while e.hasNext():
+        sb += e.next().getKmerAsString()[-1]
+    assert sb == "AGTTCGAATCTG"
+    sb = "ATATGCT"
+    e.seek(sb)
+    while e.hasPrevious():
+        sb = e.previous().getKmerAsString()[0] + sb
+    assert sb == "GCTATATGCT"
+    try:
+        e.previous()
+        raise AssertionError("previous() past the fork must throw")
+    except ca.NoSuchElementException:
+        pass
+
+
+def test_ref_go_forward_and_backward(orc, lib, tmp):          # TraversalEngineTest.java:361-386
+    hap, k = "AGTTCGAATCTGAGCTATATGCT", 7
+    cs = Case(orc, tmp, lib, [("kid", [hap])], k)
+    e = TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).make()
+    n = 0
+    for i in range(1, len(hap) - k):
+        sk = hap[i:i + k]
+        e.seek(sk)
+        if e.hasPrevious() and e.hasNext():
+            e.next()
+            assert e.previous().getKmerAsString() == sk
+            n += 1
+    assert n > 5
+
+
+def test_ref_link_guided_walk(orc, lib, tmp):                 # T/utils/traversal/TraversalUtilsTest.java:19-47, 56-84
+    kid = ["TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"]
+    for mom in (["TGGCTAGGTCATTATGATATTAAAATGCTAGCGC"], ["TGGCTAGGTCATTATGATATTAAAATGCTAGCGC", kid[0]]):
+        haps = {"mom": mom, "kid": kid}
+        order = orc.java_string_hashmap_order(["mom", "kid"])
+        cs = Case(orc, tmp, lib, [(s, haps[s]) for s in order], 7, link_samples=["kid"], name="tu%d" % len(mom))
+        e = (TraversalEngineFactory(lib=lib).traversalColors(cs.g.getColorForSampleName("kid")).traversalDirection(BOTH)
+             .combinationOperator(OR).stoppingRule(ContigStopper).graph(cs.g).links(cs.links["kid"]).make())
+        assert TraversalUtils.toContig(e.walk("TGAGATT")) == kid[0]
+
+
+# ------------------------------------------------------------------ differential: random graphs vs oracle
+def case_random_walks(orc, lib, tmp, k, seed, with_links, n=1500):
+    rng = random.Random(seed * 7919 + k)
+    base = genome_with_repeats(rng, n, n_rep=8, rep_len=(k // 2 + 1, 4 * k), copies=(2, 3))
+    kid = mutate(rng, base, snv=0.01, indel=0.003)
+    dad = mutate(rng, base, snv=0.02, indel=0.003)
+    haps = [("kid", [kid]), ("mom", [base]), ("dad", [dad, mutate(rng, dad)])]
+    reads = None
+    if with_links:
+        rl = max(3 * k, 60)
+        reads = {"kid": [kid[i:i + rl] for i in range(0, max(1, len(kid) - rl + 1), max(1, rl // 4))] + [kid[-rl:]],
+                 "mom": [base[i:i + rl] for i in range(0, max(1, len(base) - rl + 1), max(1, rl // 3))]}
+    cs = Case(orc, tmp, lib, haps, k, link_samples=(["kid", "mom"] if with_links else []), reads=reads,
+              name="w%d_%d_%d" % (k, seed, int(with_links)))
+    kmers = cs.all_kmers()
+    seeds = rng.sample(kmers, min(120, len(kmers)))
+    seeds = [s if rng.random() < 0.5 else orc.revcomp(s) for s in seeds]
+    seeds += [rand_seq(rng, k), "N" * k, kid[:k], kid[-k:]]
+    L = ["kid"] if with_links else []
+    # with links a walk keeps circling a tandem repeat until maxLength (the reference does too), so the
+    # differential runs cap maxLength to keep the oracle's share of the test in seconds
+    ML = 400 if with_links else 75000
+    compare_walks(cs, seeds, trav=[0], links=L, max_len=ML)
+    compare_walks(cs, seeds[:40], trav=[0], links=L, op=AND, direction=FORWARD, max_len=ML)
+    compare_walks(cs, seeds[:40], trav=[0], links=L, direction=REVERSE, max_len=ML)
+    compare_walks(cs, seeds[:40], trav=[1], links=(["mom"] if with_links else []), max_len=ML)
+    compare_walks(cs, seeds[:40], trav=[0, 2], links=L, max_len=ML)
+    compare_walks(cs, seeds[:40], trav=[0], recruit=[1, 2], links=L, op=AND, max_len=ML)
+    compare_walks(cs, seeds[:40], trav=[0], links=L, max_len=7)
+    if with_links:
+        compare_walks(cs, seeds[:40], trav=[0], links=["kid", "mom"], max_len=ML)   # only kid's links belong to the traversal sample
+        compare_walks(cs, seeds[:40], trav=[2], links=["kid"], max_len=ML)          # cursor driven, no usable links
+
+
+def case_dense_cycles(orc, lib, tmp, seed):
+    """tiny k on a low-complexity genome: junctions and cycles everywhere"""
+    rng = random.Random(seed)
+    k = rng.choice([4, 5, 6])
+    g1 = "".join(rng.choice("ACGT") for _ in range(rng.randint(40, 160)))
+    g2 = mutate(rng, g1, snv=0.05)
+    reads = {"a": [g1[i:i + 5 * k] for i in range(0, len(g1), k)], "b": [g2]}
+    cs = Case(orc, tmp, lib, [("a", [g1]), ("b", [g2])], k, link_samples=["a", "b"], reads=reads, name="d%d" % seed)
+    seeds = cs.all_kmers()
+    seeds = seeds + [orc.revcomp(s) for s in seeds]
+    compare_walks(cs, seeds, trav=[0])
+    compare_walks(cs, seeds, trav=[0], links=["a"], max_len=150)
+    compare_walks(cs, seeds, trav=[1], links=["b"], recruit=[0], max_len=150)
+    compare_walks(cs, seeds, trav=[0, 1], links=["a", "b"], max_len=12)

@@ -1,0 +1,40 @@
+"""THE parity gate: every case of tests/parity_cases.py through the HIP library (libldbg.so, gfx950)
+on a real MI355X, compared bit-exactly with the CPU oracle.  Run with `pytest -m gpu`."""
+import pytest
+
+from tests import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import corticall_amd as ca
+    l = ca.default_lib()
+    assert l.device_count() >= 1, "no MI355X visible: the product has no CPU fallback"
+    return l
+
+
+def test_fixture_graph(orc, lib, tmp_path): pc.case_fixture_graph(orc, lib, tmp_path)
+
+
+@pytest.mark.parametrize("k,ncol", [(5, 1), (21, 2), (31, 3), (32, 1), (33, 2), (47, 3), (63, 3), (64, 1), (65, 2), (95, 1)])
+def test_random_find(orc, lib, tmp_path, k, ncol): pc.case_random_find(orc, lib, tmp_path, k, ncol)
+
+
+def test_q1_tiny(orc, lib, tmp_path): pc.case_q1_tiny(orc, lib, tmp_path)
+def test_unsorted_rejected(orc, lib, tmp_path): pc.case_unsorted_rejected(orc, lib, tmp_path)
+def test_ref_short_contig_reconstruction(orc, lib, tmp_path): pc.test_ref_short_contig_reconstruction(orc, lib, tmp_path)
+def test_ref_recruitment(orc, lib, tmp_path): pc.test_ref_recruitment(orc, lib, tmp_path)
+def test_ref_cycles_without_and_with_links(orc, lib, tmp_path): pc.test_ref_cycles_without_and_with_links(orc, lib, tmp_path)
+def test_ref_iterate_fwd_rev(orc, lib, tmp_path): pc.test_ref_iterate_fwd_rev(orc, lib, tmp_path)
+def test_ref_go_forward_and_backward(orc, lib, tmp_path): pc.test_ref_go_forward_and_backward(orc, lib, tmp_path)
+def test_ref_link_guided_walk(orc, lib, tmp_path): pc.test_ref_link_guided_walk(orc, lib, tmp_path)
+
+
+@pytest.mark.parametrize("k,seed,links", [(9, 1, False), (9, 2, True), (21, 3, False), (31, 4, True), (47, 5, True), (63, 6, False)])
+def test_random_walks(orc, lib, tmp_path, k, seed, links): pc.case_random_walks(orc, lib, tmp_path, k, seed, links)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_dense_cycles(orc, lib, tmp_path, seed): pc.case_dense_cycles(orc, lib, tmp_path, seed)

@@ -1,0 +1,59 @@
+"""CPU-side checks of the shipped library: it loads, exports every symbol include/ldbg.h declares,
+and refuses to compute without a GPU (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def product_lib():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "corticall_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
+    import corticall_amd as ca
+    return ca.default_lib()
+
+
+def test_exports_every_declared_symbol(product_lib):
+    hdr = open(os.path.join(ROOT, "include", "ldbg.h")).read()
+    declared = set(re.findall(r"\b(ldbg_[a-z_0-9]+)\s*\(", hdr))
+    from corticall_amd import _native
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    for name in declared:
+        assert hasattr(product_lib.dll, name), name
+
+
+def test_kmer_helpers_roundtrip(product_lib, orc):
+    import ctypes as C
+    for kmer in ["ACGTT", "A" * 31, "GATTACA" * 9, "T" * 64, "ACGT" * 16 + "C"]:
+        k = len(kmer)
+        w = (C.c_uint64 * 4)()
+        assert product_lib.dll.ldbg_kmer_encode(kmer.encode(), k, w) == 0
+        assert [int(w[i]) for i in range((k + 31) // 32)] == orc.encode_kmer(kmer)
+        out = C.create_string_buffer(k + 1)
+        assert product_lib.dll.ldbg_kmer_decode(w, k, out) == 0 and out.value.decode() == kmer
+    w = (C.c_uint64 * 4)()
+    assert product_lib.dll.ldbg_kmer_encode(b"ACGNT", 5, w) != 0
+
+
+def test_no_cpu_fallback(product_lib, golden_dir):
+    import corticall_amd as ca
+    if product_lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(ca.LdbgError) as ei:
+        ca.CortexGraph(os.path.join(golden_dir, "two_short_contigs.ctx"))
+    assert ei.value.status == 5 and "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_links_the_oracle():
+    so = os.path.join(ROOT, "corticall_amd", "_build", "libldbg.so")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    assert "orc_" not in out and "oracle" not in out.lower()
+    for f in os.listdir(os.path.join(ROOT, "corticall_amd", "csrc")):
+        src = open(os.path.join(ROOT, "corticall_amd", "csrc", f)).read()
+        assert "oracle" not in src.lower().replace("no oracle", ""), f
+    for f in os.listdir(os.path.join(ROOT, "corticall_amd")):
+        if f.endswith(".py"):
+            assert "oracle" not in open(os.path.join(ROOT, "corticall_amd", f)).read().lower(), f
