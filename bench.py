@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+
+metric   : k-mers traversed / s (whole job), contigs / s alongside
+workload : configs[2] — synthetic P. falciparum-scale (23,332,839 bp) 3-colour k=47 LdBG with child links,
+           link-guided contig walks (ContigStopper, BOTH, OR: the `Partition` configuration,
+           Partition.java:85-94) from 50,000 seed k-mers (de novo mutation k-mers padded with random
+           child k-mers).  One "step" = one walk_batch over all seeds of the rank; the graph and the
+           links are resident in HBM before the timed region, the seeds (2.35 MB of ASCII) enter through
+           the C ABI's host pointer inside it.
+N > 1    : one process per GPU (torchrun); every rank holds a replica of the graph (it fits: ~2 GB) and
+           walks its own 50,000 seeds — independent units, no data-path collective, weak scaling.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GENOME_LEN = 23332839          # AssembleReads.wdl:530
+K = 47                         # AssembleReads.wdl:140
+N_SEEDS = 50000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def workload_files(args, rank):
+    """generate (or reuse) the synthetic inputs; returns (prefix, stats)"""
+    from tools import synth
+    tag = "c3_L%d_k%d_s%d_r%d" % (args.genome_len, args.k, args.seeds, rank)
+    d = os.environ.get("LDBG_BENCH_DIR", "/tmp/ldbg_bench")
+    os.makedirs(d, exist_ok=True)
+    prefix = os.path.join(d, tag)
+    meta = prefix + ".json"
+    if os.path.exists(meta) and os.path.exists(prefix + ".ctx"):
+        return prefix, json.load(open(meta))
+    t = time.time()
+    # every rank builds the same graph (same seed); only the seed-list RNG stream differs per rank
+    st = synth.generate(prefix, args.genome_len, args.k, colours=3, with_links=True, seed=0xC0FFEE03, n_chrom=14,
+                        n_repeat_families=args.repeat_families, repeat_copies=4, repeat_len=(50, 300),
+                        n_seeds=args.seeds, threads=min(16, os.cpu_count() or 1))
+    st["gen_seconds"] = round(time.time() - t, 1)
+    json.dump(st, open(meta, "w"))
+    return prefix, st
+
+
+def cpu_baseline(prefix, args, gpu_contigs, seeds_ascii):
+    """oracle ("port" of the reference algorithm: ASCII 3-point search, LRU, link store) on a bounded sample"""
+    import numpy as np
+    from oracle import pyoracle as orc
+    g = orc.Graph(prefix + ".ctx", use_cache=True, tuned=False)
+    l = orc.Links(prefix + ".ctp.gz")
+    e = orc.Engine(g, [0], links=[l], stopper="ContigStopper", max_length=args.max_len)
+    budget = args.cpu_seconds
+    t0 = time.time()
+    n = 0
+    mismatches = 0
+    while n < len(seeds_ascii) and time.time() - t0 < budget:
+        contig, _ = e.walk(seeds_ascii[n].tobytes().decode())
+        if contig != gpu_contigs[n]:
+            mismatches += 1
+        n += 1
+    dt = time.time() - t0
+    trav = e.kmers_traversed()
+    return {
+        "value": trav / dt, "unit": "k-mers traversed/s", "cores": 1, "kind": "port",
+        "sample": "first %d of the %d seeds of rank 0 (%d k-mers traversed in %.1f s), oracle in faithful mode "
+                  "(ASCII 3-point binary search + 1M-entry LRU, CortexGraph.java:272-317)" % (n, len(seeds_ascii), trav, dt),
+        "contigs_per_s": n / dt,
+    }, n, mismatches
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-len", type=int, default=GENOME_LEN)
+    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--seeds", type=int, default=N_SEEDS)
+    ap.add_argument("--max-len", type=int, default=75000)
+    ap.add_argument("--repeat-families", type=int, default=4000)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import corticall_amd as ca
+    from corticall_amd import BOTH, OR, ContigStopper, CortexGraph, CortexLinks, TraversalEngineFactory
+
+    prefix, st = workload_files(args, 0)        # same graph on every rank
+    seeds = np.fromfile(prefix + ".seeds", dtype=np.uint8).reshape(-1, args.k)
+    if world > 1:                               # weak scaling: each rank walks its own seeds
+        rng = np.random.default_rng(1000 + rank)
+        seeds = seeds[rng.permutation(len(seeds))]
+
+    t_load = time.time()
+    g = CortexGraph(prefix + ".ctx", device=local_rank)
+    links = CortexLinks(prefix + ".ctp.gz", g)
+    eng = (TraversalEngineFactory().traversalColors(g.getColorForSampleName("child")).traversalDirection(BOTH)
+           .combinationOperator(OR).stoppingRule(ContigStopper).maxBranchLength(args.max_len).graph(g).links(links).make())
+    t_load = time.time() - t_load
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.walk_batch_arrays(seeds, fetch=False)
+    ca.profile_reset()
+    sync()
+    t0 = time.time()
+    traversed = 0
+    for _ in range(args.steps):
+        eng.walk_batch_arrays(seeds, fetch=False)      # results stay in HBM (contigs + vertex lists)
+        traversed += eng.kmers_traversed
+    sync()
+    dt = time.time() - t0
+    walk_ms, walk_launches = ca.profile_get("walk")
+    contig_ms, _ = ca.profile_get("contig")
+
+    tot_trav, tot_seeds, max_dt = traversed, len(seeds) * args.steps, dt
+    if dist is not None:
+        t = torch.tensor([float(traversed), float(len(seeds) * args.steps)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        tot_trav, tot_seeds, max_dt = int(t[0].item()), int(t[1].item()), m[0].item()
+
+    if rank == 0:
+        N, W, C = g.getNumRecords(), g.getKmerBits(), g.getNumColors()
+        # algorithmic bytes per k-mer traversed: one findRecord of the successor
+        # = ceil(log2 N) keys of 8W bytes + the record's 5C payload bytes, plus one link-table lookup
+        M = max(2, links.numKmersWithLinks)
+        b_find = math.ceil(math.log2(N)) * 8 * W + 5 * C
+        b_link = math.ceil(math.log2(M)) * 8 * W
+        per_launch_units = traversed / max(1, walk_launches)
+        avg_ms = walk_ms / max(1, walk_launches)
+        achieved = per_launch_units * (b_find + b_link) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "walk_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "k-mers traversed/sec (whole node) + contigs/sec, k=47 3-color LdBG",
+            "value": tot_trav / max_dt, "unit": "k-mers traversed/s", "contigs_per_s": tot_seeds / max_dt,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": "configs[2]: synthetic %.1f Mb 3-colour k=%d LdBG with child links (read 250 bp / stride 8), "
+                            "link-guided ContigStopper walks BOTH/OR from %d seeds per GPU (%d de novo), maxLength %d"
+                            % (args.genome_len / 1e6, args.k, len(seeds), st["n_novel_seeds"], args.max_len),
+                "records": N, "record_bytes": 8 * W + 5 * C, "link_kmers": links.numKmersWithLinks, "links": links.numLinks,
+                "seeds_per_gpu": len(seeds), "kmers_traversed_per_step": traversed // args.steps,
+                "multi_gpu": "replicated graph, seeds partitioned, no data-path collective" if world > 1 else "single GPU",
+                "load_seconds": round(t_load, 2),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_walk<%d>" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_kmer": b_find + b_link, "avg_launch_ms": avg_ms, "launches": walk_launches,
+                "contig_kernels_ms_per_step": contig_ms / max(1, args.steps),
+            },
+        }
+        if not args.no_cpu_baseline:
+            contigs, _ = eng.walk_batch(seeds[:2000])
+            base, n_cmp, mism = cpu_baseline(prefix, args, contigs, seeds)
+            out["cpu_baseline"] = base
+            out["parity"] = "%d/%d sampled contigs bit-exact vs oracle" % (n_cmp - mism, n_cmp)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

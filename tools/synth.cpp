@@ -51,18 +51,6 @@ typedef std::vector<uint8_t> Seq;   // base codes 0..3
 
 uint8_t rand_base(Rng& r, double gc) { bool g = r.uniform() < gc; bool hi = r.next() & 1; return g ? (hi ? 1 : 2) : (hi ? 0 : 3); }
 
-void parallel_for(int threads, int64_t n, const std::function<void(int64_t, int64_t, int)>& f) {
-    threads = std::max(1, threads);
-    std::vector<std::thread> th;
-    int64_t chunk = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; t++) {
-        int64_t lo = t * chunk, hi = std::min(n, lo + chunk);
-        if (lo >= hi) break;
-        th.emplace_back(f, lo, hi, t);
-    }
-    for (auto& x : th) x.join();
-}
-
 struct Occ { u128 key; uint8_t colour; uint8_t edge; };
 struct Rec { u128 key; uint32_t cov[3]; uint8_t edges[3]; };
 
@@ -171,7 +159,11 @@ extern "C" int ldbg_synth_generate(const SynthParams* pp, const char* out_prefix
                 if (u < p.snv_rate) b.push_back((uint8_t)((a[i] + 1 + rng.below(3)) & 3));
                 else if (u < p.snv_rate + indel_rate) {
                     if (rng.next() & 1) { b.push_back(a[i]); int n = 1 + (int)rng.below(10); for (int j = 0; j < n; j++) b.push_back(rand_base(rng, p.gc)); }
-                    else { i += (int64_t)rng.below(10); }   // deletion
+                    else {                                   // deletion
+                        int64_t n = (int64_t)rng.below(10);
+                        for (int64_t j = 1; j <= n && i + j < (int64_t)a.size(); j++) m[i + j] = (int32_t)b.size();
+                        i += n;
+                    }
                 } else b.push_back(a[i]);
             }
         }
@@ -204,6 +196,15 @@ extern "C" int ldbg_synth_generate(const SynthParams* pp, const char* out_prefix
     }
     int64_t child_len = 0;
     for (auto& s : child) child_len += (int64_t)s.size();
+
+    if (child_len <= 5000000) {   // small runs: keep the child chromosomes so tests can re-derive reads
+        std::string path = std::string(out_prefix) + ".child.txt";
+        FILE* f = fopen(path.c_str(), "wb");
+        if (f) {
+            for (auto& s : child) { std::string a(s.size(), 'A'); for (size_t i = 0; i < s.size(); i++) a[i] = "ACGT"[s[i]]; fwrite(a.data(), 1, a.size(), f); fputc('\n', f); }
+            fclose(f);
+        }
+    }
 
     // ---- k-mer occurrences, sorted, reduced to records
     std::vector<std::pair<const Seq*, int>> jobs;
