@@ -8,9 +8,8 @@ namespace ldbg {
 
 template <int W>
 struct CursorStateDev {
-    VRef<W> cur;
-    Adj<W> acur;
-    VRef<W> nxt, prv;
+    Node<W> cur;
+    Node<W> nxt, prv;
     uint32_t has_next, has_prev, first, go_forward, status;
     uint32_t ls_n, ls_java_cap, ls_nkeys, ls_next_seq;
     uint32_t gen;
@@ -20,17 +19,20 @@ struct CursorStateDev {
 };
 
 template <int W>
-LDBG_DEV void cs_reseek(const EngineView& e, CursorStateDev<W>& st) {
+LDBG_DEV void cs_reseek(const EngineView& e, CursorStateDev<W>& st, uint64_t* vtab, uint32_t vcap) {
     // seek(sk) :321-335 — unique neighbours, fresh LinkStore, fresh `seen`
-    adj_of<W>(e, st.cur, st.acur);
-    st.has_next = popc4(st.acur.next_mask) == 1;
-    if (st.has_next) st.nxt = vref_find<W>(e, neighbour<W>(st.acur, e.g.k, true, lowbit4(st.acur.next_mask)));
-    st.has_prev = popc4(st.acur.prev_mask) == 1;
-    if (st.has_prev) st.prv = vref_find<W>(e, neighbour<W>(st.acur, e.g.k, false, lowbit4(st.acur.prev_mask)));
+    if (st.gen >= 32766u) { for (uint32_t i = 0; i < vcap; i++) vtab[i] = 0; st.gen = 0; }
+    st.gen++;
+    VisitedTable vt;
+    vt.tab = vtab; vt.mask = vcap - 1; vt.gen = st.gen;
+    node_locate<W>(vt, st.cur);
+    st.has_next = popc4(st.cur.next_mask) == 1;
+    if (st.has_next) { node_find<W>(e, node_neighbour<W>(st.cur, e.g.k, true, lowbit4(st.cur.next_mask)), st.nxt); node_locate<W>(vt, st.nxt); }
+    st.has_prev = popc4(st.cur.prev_mask) == 1;
+    if (st.has_prev) { node_find<W>(e, node_neighbour<W>(st.cur, e.g.k, false, lowbit4(st.cur.prev_mask)), st.prv); node_locate<W>(vt, st.prv); }
     st.ls_n = st.ls_java_cap = st.ls_nkeys = st.ls_next_seq = 0;
     st.first = 1;
-    st.gen++;
-    st.status = st.acur.npe ? (uint32_t)ST_NULLPTR : (uint32_t)ST_OK;
+    st.status = st.cur.npe ? (uint32_t)ST_NULLPTR : (uint32_t)ST_OK;
 }
 
 template <int W>
@@ -39,19 +41,9 @@ LDBG_KERNEL void k_cursor_seek(EngineView e, CursorStateDev<W>* stp, const uint6
     CursorStateDev<W>& st = *stp;
     Kmer<W> sk;
     for (int i = 0; i < W; i++) sk.w[i] = words[i];
-    if (words[0] != ~0ull) st.cur = vref_find<W>(e, sk);
-    else { st.cur.sk = sk; st.cur.idx = -1; st.cur.flip = false; st.cur.copy = 0; }
-    if (st.gen >= 32766u) { for (uint32_t i = 0; i < vcap; i++) vtab[i] = 0; st.gen = 0; }
-    if (words[0] == ~0ull) {
-        st.acur.idx = -1; st.acur.flip = false; st.acur.o = sk; st.acur.next_mask = st.acur.prev_mask = 0;
-        st.acur.npe = e.recruit_mask != 0;
-        st.has_next = st.has_prev = 0;
-        st.ls_n = st.ls_java_cap = st.ls_nkeys = st.ls_next_seq = 0;
-        st.first = 1; st.gen++;
-        st.status = st.acur.npe ? (uint32_t)ST_NULLPTR : (uint32_t)ST_OK;
-    } else {
-        cs_reseek<W>(e, st);
-    }
+    if (words[0] != ~0ull) node_find<W>(e, sk, st.cur);
+    else node_null<W>(e, sk, st.cur);
+    cs_reseek<W>(e, st, vtab, vcap);
 }
 
 template <int W>
@@ -62,7 +54,7 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
     st.status = ST_OK;
     if (st.first || (st.go_forward != 0) != fwd) {      // :243-248 / :283-288
         st.go_forward = fwd ? 1 : 0;
-        cs_reseek<W>(e, st);
+        cs_reseek<W>(e, st, vtab, vcap);
         if (st.status != ST_OK) return;
     }
     VisitedTable vt;
@@ -71,14 +63,14 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
     ls.el = els; ls.cap = ecap; ls.n = st.ls_n; ls.java_cap = st.ls_java_cap; ls.nkeys = st.ls_nkeys; ls.next_seq = st.ls_next_seq;
     ls.overflow = false;
     Cursor<W> cu;
-    cu.cur = st.cur; cu.acur = st.acur; cu.first = st.first != 0; cu.status = ST_OK;
+    cu.cur = st.cur; cu.first = st.first != 0; cu.status = ST_OK;
     cu.has = fwd ? st.has_next != 0 : st.has_prev != 0;
     if (!cu.has) { st.status = ST_NULLPTR; return; }   // target vanished after the re-seek: NPE in the reference
     cu.nxt = fwd ? st.nxt : st.prv;
-    VRef<W> old = st.cur;
-    VRef<W> t = cursor_step<W>(e, cu, ls, vt, fwd);
+    Node<W> old = st.cur;
+    Node<W> t = cursor_step<W>(e, cu, ls, vt, fwd);
     st.first = 0;
-    st.cur = cu.cur; st.acur = cu.acur;
+    st.cur = cu.cur;
     if (fwd) { st.prv = old; st.has_prev = 1; st.nxt = cu.nxt; st.has_next = cu.has ? 1 : 0; }
     else { st.nxt = old; st.has_next = 1; st.prv = cu.nxt; st.has_prev = cu.has ? 1 : 0; }
     st.ls_n = ls.n; st.ls_java_cap = ls.java_cap; st.ls_nkeys = ls.nkeys; st.ls_next_seq = ls.next_seq;

@@ -1,23 +1,25 @@
-// TraversalEngine on the device: shared device-side primitives (neighbourhood of an oriented k-mer,
-// per-walk visited table, per-walk LinkStore, cursor step) used by the walk and DFS kernels.
+// TraversalEngine on the device: shared device-side primitives (vertex lookup with its neighbourhood,
+// per-walk visited table, per-walk LinkStore, cursor step) used by the walk and cursor kernels.
 // Every function cites the Java it restates (J/ = public/java/src/uk/ac/ox/well/cortexjdk/).
+//
+// Memory discipline of one traversal step (DESIGN.md §Walk kernel): the dependent chain is
+//   radix-index load -> probe row (key + edges + link flags in one sector) -> visited-table slot
+// Everything else (link table search, link store) only runs where the row's link flags say so.
 #pragma once
 #include "graph.h"
 #include "links.h"
 
 namespace ldbg {
 
-#define LDBG_MAX_LINKS 4
-
 struct EngineView {
     GraphView g;
     uint32_t trav_mask, recruit_mask, join_mask;
     int first_trav;
     int stopper, max_len, connect_all, strict_flip;
-    int cursor_on;   // !ec.getLinks().isEmpty(): dfs drives the cursor (TraversalEngine.java:363, 379) even when
-                     // none of the configured link sets belongs to a traversal sample (nlinks == 0)
-    int nlinks;
-    LinksView links[LDBG_MAX_LINKS];
+    int cursor_on;        // !ec.getLinks().isEmpty(): dfs drives the cursor (TraversalEngine.java:363, 379) even
+                          // when none of the configured link sets belongs to a traversal sample
+    uint32_t link_flag_mask;   // probe-row link-flag bits of the link sets merged into `links`
+    LinksView links;      // the traversal's link sets merged into one table (links.h)
 };
 
 // strand status codes (per seed and direction)
@@ -27,7 +29,7 @@ enum : uint32_t {
     ST_LINKSTORE_FULL = 2, // per-walk link store capacity exceeded -> host retries with a larger store
     ST_BRANCH_NULL = 3,    // dfs branch returned null
     ST_COPY_OVERFLOW = 4,  // more than 32767 copies of one vertex
-    ST_PATH_FULL = 5
+    ST_POOL_FULL = 5       // path block pool exhausted -> host splits the batch
 };
 
 // ---- path entry: one vertex of a branch, 8 bytes
@@ -44,94 +46,82 @@ LDBG_HOSTDEV bool path_flip(uint64_t e) { return (e >> 33) & 1ull; }
 LDBG_HOSTDEV unsigned path_base(uint64_t e) { return (unsigned)((e >> 34) & 3ull); }
 LDBG_HOSTDEV int path_copy(uint64_t e) { int32_t v = (int32_t)((e >> 36) & 0xFFFFFFull); return (v << 8) >> 8; }
 
-// ---- neighbourhood of an oriented k-mer: TraversalUtils.getAllNextKmers/getAllPrevKmers
-// (J/utils/traversal/TraversalUtils.java:510-590) + TraversalEngine.getNextVertices/getPrevVertices
-// (J/utils/traversal/TraversalEngine.java:147-239), as 4-bit base masks.
-template <int W>
-struct Adj {
-    int64_t idx;        // record of the k-mer, -1 = null
-    bool flip;          // k-mer != canonical orientation (by comparison): vertex identity
-    Kmer<W> o;          // orientation the neighbours are built from (record k-mer, or its revcomp when
-                        // CanonicalKmer.isFlipped() — hash-based, quirk Q6)
-    uint32_t next_mask; // bit b set: successor o[1:]+b
-    uint32_t prev_mask; // bit b set: predecessor b+o[:-1]
-    bool npe;           // record missing while recruitment colours are set (Q14)
-};
+LDBG_HOSTDEV int popc4(uint32_t m) { return (int)((m & 1u) + ((m >> 1) & 1u) + ((m >> 2) & 1u) + ((m >> 3) & 1u)); }
+LDBG_HOSTDEV unsigned lowbit4(uint32_t m) { return (m & 1u) ? 0u : ((m & 2u) ? 1u : ((m & 4u) ? 2u : 3u)); }
 
+// ---- a vertex with its neighbourhood: CortexVertex + TraversalUtils.getAllNextKmers/getAllPrevKmers
+// (J/utils/traversal/TraversalUtils.java:510-590) + TraversalEngine.getNextVertices/getPrevVertices
+// (J/utils/traversal/TraversalEngine.java:147-239) folded into 4-bit base masks.
 template <int W>
-LDBG_HOSTDEV void adj_from_idx(const EngineView& e, const Kmer<W>& sk, const Kmer<W>& canon, bool flip_cmp, int64_t idx, Adj<W>& a) {
+struct Node {
+    Kmer<W> sk;          // the vertex's k-mer, in the orientation it was reached
+    int64_t idx;         // record index, -1 = null CortexRecord
+    int32_t copy;        // CortexVertex.copyIndex
+    uint32_t vslot;      // slot of this vertex in the walk's visited table (valid once located; idx >= 0)
+    uint8_t flip;        // sk != canonical orientation (by comparison): part of the vertex identity
+    uint8_t fj;          // CanonicalKmer.isFlipped() — by Arrays.hashCode inequality (quirk Q6)
+    uint8_t npe;         // record missing while recruitment colours are set (Q14)
+    uint8_t lflags;      // link-flag byte of the record's probe row
+    uint8_t next_mask;   // bit b: successor o[1:]+b
+    uint8_t prev_mask;   // bit b: predecessor b+o[:-1]
+};
+// orientation the neighbours are built from: the record's k-mer, or its reverse complement when
+// isFlipped() (TraversalUtils.java:514, 539).  Equals sk except under a Q6 hash collision.
+template <int W>
+LDBG_HOSTDEV Kmer<W> node_o(const Node<W>& n, int k) {
+    return (n.flip && !n.fj) ? kmer_revcomp<W>(n.sk, k) : n.sk;
+}
+template <int W>
+LDBG_HOSTDEV Kmer<W> node_neighbour(const Node<W>& n, int k, bool fwd, unsigned base) {
+    Kmer<W> o = node_o<W>(n, k);
+    return fwd ? kmer_next<W>(o, k, base) : kmer_prev<W>(o, k, base);
+}
+template <int W>
+LDBG_HOSTDEV void node_null(const EngineView& e, const Kmer<W>& sk, Node<W>& n) {   // not a k-mer / no record
+    n.sk = sk; n.idx = -1; n.copy = 0; n.vslot = 0; n.flip = 0; n.fj = 0; n.lflags = 0;
+    n.next_mask = n.prev_mask = 0;
+    n.npe = e.recruit_mask != 0 ? 1 : 0;
+}
+// findRecord(sk) + neighbourhood: one radix-index load, then probe rows; the matching row yields edges and
+// link flags from the same sector as its key.
+template <int W>
+LDBG_HOSTDEV void node_find(const EngineView& e, const Kmer<W>& sk, Node<W>& n) {
     const GraphView& g = e.g;
-    bool fj = flip_cmp;
-    if (e.strict_flip && flip_cmp) fj = kmer_java_hash<W>(canon, g.k) != kmer_java_hash<W>(sk, g.k);
-    a.idx = idx;
-    a.flip = flip_cmp;
-    a.o = fj ? sk : canon;
-    a.npe = false;
+    bool fc;
+    Kmer<W> c = kmer_canonical<W>(sk, g.k, &fc);
+    n.sk = sk; n.copy = 0; n.vslot = 0; n.flip = fc ? 1 : 0; n.npe = 0; n.lflags = 0;
+    bool fj = fc;
+    if (e.strict_flip && fc) fj = kmer_java_hash<W>(c, g.k) != kmer_java_hash<W>(sk, g.k);
+    n.fj = fj ? 1 : 0;
+    const int64_t idx = graph_find_canonical<W>(g, c);
+    n.idx = idx;
     uint32_t tf = 0, tr = 0, rf = 0, rr = 0;
     if (idx >= 0) {
-        const uint8_t* ed = graph_row(g, idx) + g.edges_off;
-        for (int c = 0; c < g.C; c++) {
-            uint32_t ebyte = ed[c];
+        const uint8_t* row = graph_row(g, idx);
+        const uint8_t* ed = row + g.edges_off;
+        n.lflags = row[g.flags_off];
+        for (int col = 0; col < g.C; col++) {
+            uint32_t ebyte = ed[col];
             uint32_t lo = ebyte & 0xf, hi = ebyte >> 4;
             // CortexRecord.getOutEdgesAsBytes: bit i <-> base i ; getInEdgesAsBytes: bit (3-i) <-> base i ;
             // complement=true relabels base b as 3-b (CortexRecord.java:214-275)
             uint32_t fwd = !fj ? lo : hi;                      // successor base = bit position
             uint32_t revn = !fj ? hi : lo;                     // predecessor base = 3 - bit position
             uint32_t rev = ((revn & 1u) << 3) | ((revn & 2u) << 1) | ((revn & 4u) >> 1) | ((revn & 8u) >> 3);
-            if ((e.trav_mask >> c) & 1u) { tf |= fwd; tr |= rev; }
-            if ((e.recruit_mask >> c) & 1u) { rf |= fwd; rr |= rev; }
+            if ((e.trav_mask >> col) & 1u) { tf |= fwd; tr |= rev; }
+            if ((e.recruit_mask >> col) & 1u) { rf |= fwd; rr |= rev; }
         }
     } else if (e.recruit_mask != 0) {
-        a.npe = true;
+        n.npe = 1;
     }
-    a.next_mask = tf ? tf : rf;
-    a.prev_mask = tr ? tr : rr;
+    n.next_mask = (uint8_t)(tf ? tf : rf);    // recruitment colours only where the traversal colours give nothing
+    n.prev_mask = (uint8_t)(tr ? tr : rr);
 }
-
-template <int W>
-LDBG_HOSTDEV void adj_lookup(const EngineView& e, const Kmer<W>& sk, Adj<W>& a) {
-    bool fc;
-    Kmer<W> c = kmer_canonical<W>(sk, e.g.k, &fc);
-    int64_t idx = graph_find_canonical<W>(e.g, c);
-    adj_from_idx<W>(e, sk, c, fc, idx, a);
-}
-
-// a vertex reference carried between iterations
-template <int W>
-struct VRef {
-    Kmer<W> sk;
-    int64_t idx;
-    bool flip;
-    int copy;
-};
-
-template <int W>
-LDBG_HOSTDEV VRef<W> vref_find(const EngineView& e, const Kmer<W>& sk) {
-    VRef<W> v;
-    v.sk = sk;
-    bool fc;
-    Kmer<W> c = kmer_canonical<W>(sk, e.g.k, &fc);
-    v.idx = graph_find_canonical<W>(e.g, c);
-    v.flip = fc;
-    v.copy = 0;
-    return v;
-}
-template <int W>
-LDBG_HOSTDEV void adj_of(const EngineView& e, const VRef<W>& v, Adj<W>& a) {
-    bool fc;
-    Kmer<W> c = kmer_canonical<W>(v.sk, e.g.k, &fc);
-    adj_from_idx<W>(e, v.sk, c, fc, v.idx, a);
-}
-template <int W>
-LDBG_HOSTDEV Kmer<W> neighbour(const Adj<W>& a, int k, bool fwd, unsigned base) {
-    return fwd ? kmer_next<W>(a.o, k, base) : kmer_prev<W>(a.o, k, base);
-}
-LDBG_HOSTDEV int popc4(uint32_t m) { return (int)((m & 1u) + ((m >> 1) & 1u) + ((m >> 2) & 1u) + ((m >> 3) & 1u)); }
-LDBG_HOSTDEV unsigned lowbit4(uint32_t m) { return (m & 1u) ? 0u : ((m & 2u) ? 1u : ((m & 4u) ? 2u : 3u)); }
 
 // ---- per-walk visited table (HashSet<CortexVertex> visited, TraversalEngine.java:360-425, plus the
 // cursor's `seen` set :27,262-265): open addressing over 8-byte entries in HBM, generation-tagged so
-// a slot is reused by the next walk without clearing.
+// a slot is reused by the next walk without clearing.  A vertex is located once (when it is first looked
+// up as a neighbour); later updates go straight to its slot.
 //  bits 0..32 key = (record index << 1) | flip ; bits 33..47 generation ; bits 48..62 copies visited ; bit 63 seen
 struct VisitedTable {
     uint64_t* tab;
@@ -142,48 +132,32 @@ LDBG_HOSTDEV uint32_t vt_hash(uint64_t key) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(x >> 32);
 }
-LDBG_HOSTDEV uint64_t vt_key(int64_t idx, bool flip) { return ((uint64_t)idx << 1) | (flip ? 1ull : 0ull); }
-// returns slot position of the key, or of the first free slot
-LDBG_HOSTDEV uint32_t vt_slot(const VisitedTable& t, uint64_t key, bool* found) {
+// slot of (idx, flip); claims a free slot (count 0, not seen) if the vertex is not in the table yet
+LDBG_HOSTDEV uint32_t vt_locate(VisitedTable& t, int64_t idx, bool flip) {
+    const uint64_t key = ((uint64_t)idx << 1) | (flip ? 1ull : 0ull);
     uint32_t h = vt_hash(key) & t.mask;
     while (true) {
         uint64_t e = t.tab[h];
-        if (((e >> 33) & 0x7FFFull) != t.gen) { *found = false; return h; }
-        if ((e & 0x1FFFFFFFFull) == key) { *found = true; return h; }
+        if (((e >> 33) & 0x7FFFull) != t.gen) { t.tab[h] = key | ((uint64_t)t.gen << 33); return h; }
+        if ((e & 0x1FFFFFFFFull) == key) return h;
         h = (h + 1) & t.mask;
     }
 }
-LDBG_HOSTDEV int vt_count(const VisitedTable& t, int64_t idx, bool flip) {
-    if (idx < 0) return 0;
-    bool f;
-    uint32_t s = vt_slot(t, vt_key(idx, flip), &f);
-    return f ? (int)((t.tab[s] >> 48) & 0x7FFFull) : 0;
-}
-LDBG_HOSTDEV bool vt_seen(const VisitedTable& t, int64_t idx, bool flip) {
-    if (idx < 0) return false;
-    bool f;
-    uint32_t s = vt_slot(t, vt_key(idx, flip), &f);
-    return f ? (t.tab[s] >> 63) != 0 : false;
-}
-LDBG_HOSTDEV void vt_update(VisitedTable& t, int64_t idx, bool flip, int new_count, bool set_seen) {
-    if (idx < 0) return;
-    uint64_t key = vt_key(idx, flip);
-    bool f;
-    uint32_t s = vt_slot(t, key, &f);
-    uint64_t e = f ? t.tab[s] : (key | ((uint64_t)t.gen << 33));
-    if (new_count >= 0) e = (e & ~(0x7FFFull << 48)) | ((uint64_t)(new_count & 0x7FFF) << 48);
-    if (set_seen) e |= 1ull << 63;
-    t.tab[s] = e;
-}
+LDBG_HOSTDEV int vt_count_e(uint64_t e) { return (int)((e >> 48) & 0x7FFFull); }
+LDBG_HOSTDEV bool vt_seen_e(uint64_t e) { return (e >> 63) != 0; }
+LDBG_HOSTDEV uint64_t vt_with_count(uint64_t e, int c) { return (e & ~(0x7FFFull << 48)) | ((uint64_t)(c & 0x7FFF) << 48); }
+template <int W>
+LDBG_HOSTDEV void node_locate(VisitedTable& t, Node<W>& n) { if (n.idx >= 0) n.vslot = vt_locate(t, n.idx, n.flip != 0); }
+template <int W>
+LDBG_HOSTDEV int node_count(const VisitedTable& t, const Node<W>& n) { return n.idx >= 0 ? vt_count_e(t.tab[n.vslot]) : 0; }
 
 // ---- per-walk LinkStore (J/utils/traversal/LinkStore.java), elements kept in insertion order
 struct LsElem {
-    uint32_t jrec;     // index into LinksView.junc of link set `set`
+    uint32_t jrec;     // index into LinksView.junc
     uint32_t age;
     uint32_t key_seq;  // insertion sequence number of this element's key in the Java HashMap
     uint16_t pos;
-    uint8_t set;
-    uint8_t comp;      // junction string is used complemented (LinkStore.java:25)
+    uint16_t comp;     // junction string is used complemented (LinkStore.java:25)
 };
 struct LinkStoreDev {
     LsElem* el;
@@ -195,34 +169,30 @@ struct LinkStoreDev {
     bool overflow;
 };
 LDBG_HOSTDEV void ls_clear(LinkStoreDev& s) { s.n = 0; s.java_cap = 0; s.nkeys = 0; s.next_seq = 0; s.overflow = false; }
-LDBG_HOSTDEV unsigned ls_char(const EngineView& e, const LsElem& x, uint32_t i) {
-    unsigned b = e.links[x.set].bases[e.links[x.set].junc[x.jrec].str_off + i];
+LDBG_HOSTDEV unsigned ls_char(const LinksView& L, const LsElem& x, uint32_t i) {
+    unsigned b = L.bases[L.junc[x.jrec].str_off + i];
     return x.comp ? 3u - b : b;
 }
-LDBG_HOSTDEV uint32_t ls_len(const EngineView& e, const LsElem& x) { return e.links[x.set].junc[x.jrec].len; }
-LDBG_HOSTDEV int32_t ls_hash(const EngineView& e, const LsElem& x) {
-    const JuncRec& j = e.links[x.set].junc[x.jrec];
-    return x.comp ? j.hash_comp : j.hash_asis;
-}
-LDBG_HOSTDEV bool ls_same_string(const EngineView& e, const LsElem& a, const LsElem& b) {
-    if (a.set == b.set && a.jrec == b.jrec && a.comp == b.comp) return true;
-    uint32_t la = ls_len(e, a);
-    if (la != ls_len(e, b) || ls_hash(e, a) != ls_hash(e, b)) return false;
-    for (uint32_t i = 0; i < la; i++) if (ls_char(e, a, i) != ls_char(e, b, i)) return false;
+LDBG_HOSTDEV uint32_t ls_len(const LinksView& L, const LsElem& x) { return L.junc[x.jrec].len; }
+LDBG_HOSTDEV int32_t ls_hash(const LinksView& L, const LsElem& x) { return x.comp ? L.junc[x.jrec].hash_comp : L.junc[x.jrec].hash_asis; }
+LDBG_HOSTDEV bool ls_same_string(const LinksView& L, const LsElem& a, const LsElem& b) {
+    if (a.jrec == b.jrec && a.comp == b.comp) return true;
+    uint32_t la = ls_len(L, a);
+    if (la != ls_len(L, b) || ls_hash(L, a) != ls_hash(L, b)) return false;
+    for (uint32_t i = 0; i < la; i++) if (ls_char(L, a, i) != ls_char(L, b, i)) return false;
     return true;
 }
-// LinkStore.add :17-35 for link record m of set `set`; `matches` = record k-mer string equals the cursor k-mer
-LDBG_HOSTDEV void ls_add(const EngineView& e, LinkStoreDev& s, int set, int64_t m, bool matches, bool fwd) {
-    const LinksView& L = e.links[set];
+// LinkStore.add :17-35 for merged link record m.  `query_flipped`: the cursor k-mer is the reverse complement
+// of the canonical key; JuncRec.is_fw is stored as "link goes forward when the query is the canonical k-mer".
+LDBG_HOSTDEV void ls_add(const LinksView& L, LinkStoreDev& s, int64_t m, bool query_flipped, bool fwd) {
     for (uint32_t j = L.off[m]; j < L.off[m + 1]; j++) {
-        bool is_fw = L.junc[j].is_fw != 0;
-        bool lgf = matches == is_fw;
+        bool lgf = (L.junc[j].is_fw != 0) != query_flipped;    // recordOrientationMatchesKmer == cjr.isForward() :24
         if (lgf != fwd) continue;
         LsElem x;
-        x.jrec = j; x.age = 0; x.pos = 0; x.set = (uint8_t)set; x.comp = lgf ? 0 : 1; x.key_seq = 0;
+        x.jrec = j; x.age = 0; x.pos = 0; x.comp = lgf ? 0 : 1; x.key_seq = 0;
         bool have = false;
         for (uint32_t i = 0; i < s.n; i++)
-            if (ls_same_string(e, s.el[i], x)) { x.key_seq = s.el[i].key_seq; have = true; break; }
+            if (ls_same_string(L, s.el[i], x)) { x.key_seq = s.el[i].key_seq; have = true; break; }
         if (!have) {
             x.key_seq = s.next_seq++;
             s.nkeys++;
@@ -236,36 +206,35 @@ LDBG_HOSTDEV void ls_add(const EngineView& e, LinkStoreDev& s, int set, int64_t 
 LDBG_HOSTDEV void ls_increment_ages(LinkStoreDev& s) { for (uint32_t i = 0; i < s.n; i++) s.el[i].age++; }
 LDBG_HOSTDEV int ls_num_new(const LinkStoreDev& s) { int c = 0; for (uint32_t i = 0; i < s.n; i++) c += s.el[i].age == 0; return c; }
 // LinkStore.getNextJunctionChoice :122-144 (+ getOldestLink :92-119, incrementPositionsAndExpire :58-90)
-LDBG_HOSTDEV bool ls_next_choice(const EngineView& e, LinkStoreDev& s, unsigned* choice) {
+LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* choice) {
     if (s.n == 0) return false;
     uint32_t maxage = 0;
     for (uint32_t i = 0; i < s.n; i++) if (s.el[i].age > maxage) maxage = s.el[i].age;
     // first oldest element in java.util.HashMap iteration order: (bucket, key insertion order, list order)
     bool have = false, agree = true;
     unsigned ch0 = 0;
-    uint32_t best_b = 0, best_seq = 0, best_i = 0;
+    uint32_t best_b = 0, best_seq = 0;
     for (uint32_t i = 0; i < s.n; i++) {
         const LsElem& x = s.el[i];
         if (x.age != maxage) continue;
-        unsigned c = ls_char(e, x, x.pos);
-        uint32_t h = (uint32_t)ls_hash(e, x);
+        unsigned c = ls_char(L, x, x.pos);
+        uint32_t h = (uint32_t)ls_hash(L, x);
         uint32_t b = (h ^ (h >> 16)) & (s.java_cap - 1);
-        if (!have) { have = true; ch0 = c; best_b = b; best_seq = x.key_seq; best_i = i; }
+        if (!have) { have = true; ch0 = c; best_b = b; best_seq = x.key_seq; }
         else {
             if (c != ch0) agree = false;
-            if (b < best_b || (b == best_b && x.key_seq < best_seq)) { best_b = b; best_seq = x.key_seq; best_i = i; }
+            if (b < best_b || (b == best_b && x.key_seq < best_seq)) { best_b = b; best_seq = x.key_seq; }
         }
     }
     if (!have || !agree) return false;
-    (void)best_i;
     unsigned ch = ch0;
     for (uint32_t i = 0; i < s.n; i++)   // last element of that key's list wins (:129-133)
-        if (s.el[i].key_seq == best_seq) ch = ls_char(e, s.el[i], s.el[i].pos);
+        if (s.el[i].key_seq == best_seq) ch = ls_char(L, s.el[i], s.el[i].pos);
     // incrementPositionsAndExpire(choice)
     uint32_t w = 0;
     for (uint32_t i = 0; i < s.n; i++) {
         LsElem x = s.el[i];
-        if ((uint32_t)x.pos + 1 >= ls_len(e, x) || ls_char(e, x, x.pos) != ch) continue;
+        if ((uint32_t)x.pos + 1 >= ls_len(L, x) || ls_char(L, x, x.pos) != ch) continue;
         x.pos++;
         s.el[w++] = x;
     }
@@ -284,70 +253,67 @@ LDBG_HOSTDEV bool ls_next_choice(const EngineView& e, LinkStoreDev& s, unsigned*
 // ---- cursor (TraversalEngine.seek / next / previous, TraversalEngine.java:241-339, 518-597)
 template <int W>
 struct Cursor {
-    VRef<W> cur;
-    Adj<W> acur;        // neighbourhood of cur
-    VRef<W> nxt;        // the k-mer hasNext()/hasPrevious() refers to, looked up one step ahead
+    Node<W> cur;
+    Node<W> nxt;        // the vertex hasNext()/hasPrevious() refers to, looked up one step ahead
     bool has;
     bool first;         // specificLinksFiles == null: the next step re-seeks and initialises the link store
     uint32_t status;
 };
 
+// initializeLinkStore / updateLinkStore (:548-597): links of vertex v, if its record carries any
 template <int W>
-LDBG_HOSTDEV void cursor_add_links(const EngineView& e, LinkStoreDev& s, const VRef<W>& v, bool fwd) {
-    bool fc;
-    Kmer<W> c = kmer_canonical<W>(v.sk, e.g.k, &fc);
-    for (int L = 0; L < e.nlinks; L++) {
-        int64_t m = links_find<W>(e.links[L], e.g.k, c);
-        if (m >= 0) {
-            // recordOrientationMatchesKmer (LinkStore.java:18): the record's k-mer string is canon or rc(canon)
-            bool rec_is_canon = e.links[L].kcanon[m] != 0;
-            bool matches = rec_is_canon ? !fc : fc;
-            ls_add(e, s, L, m, matches, fwd);
-        }
-    }
+LDBG_HOSTDEV void cursor_add_links(const EngineView& e, LinkStoreDev& s, const Node<W>& v, bool fwd) {
+    if (!(v.lflags & e.link_flag_mask)) return;
+    Kmer<W> c = v.flip ? kmer_revcomp<W>(v.sk, e.g.k) : v.sk;
+    int64_t m = links_find<W>(e.links, e.g.k, c);
+    if (m >= 0) ls_add(e.links, s, m, v.flip != 0, fwd);
 }
 // seek(sk): cursor on v, unique neighbour in direction `fwd` looked up (TraversalEngine.java:321-335)
 template <int W>
-LDBG_HOSTDEV void cursor_seek(const EngineView& e, Cursor<W>& cu, LinkStoreDev& s, const VRef<W>& v, const Adj<W>& a, bool fwd) {
+LDBG_HOSTDEV void cursor_seek(const EngineView& e, Cursor<W>& cu, LinkStoreDev& s, VisitedTable& vt, const Node<W>& v, bool fwd) {
     cu.cur = v;
-    cu.acur = a;
     cu.first = true;
     cu.status = ST_OK;
     ls_clear(s);
-    uint32_t m = fwd ? a.next_mask : a.prev_mask;
+    uint32_t m = fwd ? v.next_mask : v.prev_mask;
     cu.has = popc4(m) == 1;
-    if (cu.has) cu.nxt = vref_find<W>(e, neighbour<W>(a, e.g.k, fwd, lowbit4(m)));
+    if (cu.has) {
+        node_find<W>(e, node_neighbour<W>(v, e.g.k, fwd, lowbit4(m)), cu.nxt);
+        node_locate<W>(vt, cu.nxt);
+    }
 }
 // next()/previous() (TraversalEngine.java:241-319); requires cu.has.  Returns the vertex stepped onto.
 template <int W>
-LDBG_HOSTDEV VRef<W> cursor_step(const EngineView& e, Cursor<W>& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd) {
+LDBG_HOSTDEV Node<W> cursor_step(const EngineView& e, Cursor<W>& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd) {
     if (cu.first) {
         cu.first = false;                              // seek(cur) recomputes the same state; then
         cursor_add_links<W>(e, s, cu.cur, fwd);        // initializeLinkStore :548-568
     }
     cursor_add_links<W>(e, s, cu.nxt, fwd);            // updateLinkStore :570-597
-    VRef<W> t = cu.nxt;
+    Node<W> t = cu.nxt;
     cu.cur = t;
-    adj_of<W>(e, t, cu.acur);
-    if (cu.acur.npe) cu.status = ST_NULLPTR;
-    uint32_t m = fwd ? cu.acur.next_mask : cu.acur.prev_mask;
+    if (t.npe) cu.status = ST_NULLPTR;
+    const uint32_t m = fwd ? t.next_mask : t.prev_mask;
     bool has = false;
-    int pc = popc4(m);
+    const int pc = popc4(m);
     if (pc == 1) {
-        VRef<W> x = vref_find<W>(e, neighbour<W>(cu.acur, e.g.k, fwd, lowbit4(m)));
-        if (!vt_seen(vt, x.idx, x.flip) || s.n > 0) {   // :262
+        Node<W> x;
+        node_find<W>(e, node_neighbour<W>(t, e.g.k, fwd, lowbit4(m)), x);
+        uint64_t ex = 0;
+        if (x.idx >= 0) { node_locate<W>(vt, x); ex = vt.tab[x.vslot]; }
+        if (!vt_seen_e(ex) || s.n > 0) {                // :262
             cu.nxt = x;
             has = true;
-            vt_update(vt, x.idx, x.flip, -1, true);     // seen.add(nextKmer)
+            if (x.idx >= 0) vt.tab[x.vslot] = ex | (1ull << 63);   // seen.add(nextKmer)
         }
     } else if (pc > 1) {
         unsigned ch;
-        if (ls_next_choice(e, s, &ch)) {                // getAdjacentKmer :518-546
+        if (ls_next_choice(e.links, s, &ch)) {          // getAdjacentKmer :518-546
             Kmer<W> cand = fwd ? kmer_next<W>(t.sk, e.g.k, ch) : kmer_prev<W>(t.sk, e.g.k, ch);
             bool member = false;
             for (unsigned b = 0; b < 4; b++)
-                if ((m >> b) & 1u) member |= kmer_eq<W>(neighbour<W>(cu.acur, e.g.k, fwd, b), cand);
-            if (member) { cu.nxt = vref_find<W>(e, cand); has = true; }
+                if ((m >> b) & 1u) member |= kmer_eq<W>(node_neighbour<W>(t, e.g.k, fwd, b), cand);
+            if (member) { node_find<W>(e, cand, cu.nxt); node_locate<W>(vt, cu.nxt); has = true; }
         }
         ls_increment_ages(s);                           // :271
     }

@@ -43,6 +43,7 @@ bool profile_get(const char* family, double* ms, int64_t* n) {
 LDBG_KERNEL void k_layout(const uint8_t* raw, int64_t first, int64_t n, int64_t N, int W, int C, int rec_size,
                           uint64_t* keys, uint32_t* cov, uint8_t* edges, uint8_t* probe, int stride, int edges_off,
                           int cov_off) {
+    // (the link-flags byte at edges_off + C is zeroed with the padding below)
     for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
         const uint8_t* r = raw + i * rec_size;
         int64_t gi = first + i;
@@ -180,7 +181,8 @@ void Graph::upload(const uint8_t* recs) {
     const int W = hdr.W, C = hdr.C;
     view.k = hdr.k; view.W = W; view.C = C; view.N = N;
     view.edges_off = 8 * W;
-    view.cov_off = 8 * W + ((C + 3) / 4) * 4;
+    view.flags_off = 8 * W + C;
+    view.cov_off = 8 * W + ((C + 1 + 3) / 4) * 4;
     view.stride = ((view.cov_off + 4 * C + 15) / 16) * 16;
     // radix index width: ~1-2 records per block for uniform k-mers, capped so the table stays cache-sized
     int p = 1;

@@ -4,8 +4,10 @@
 //   keys  [W][N] u64   structure-of-arrays, word-major (word 0 = most significant)   -- scans
 //   cov   [C][N] u32   structure-of-arrays, colour-major                            -- scans / filters
 //   edges [C][N] u8    structure-of-arrays, colour-major                            -- scans / filters
-//   probe [N][stride]  one aligned row per record: W×u64 key | C×u8 edges | pad4 | C×u32 cov | pad16
-//                      -- random access: one 16/32-byte sector yields key + edges (+ coverage)
+//   probe [N][stride]  one aligned row per record: W×u64 key | C×u8 edges | u8 link flags | pad4 | C×u32 cov | pad16
+//                      -- random access: one 16/32-byte sector yields key + edges (+ coverage); bit s of the
+//                      link-flags byte says "link set s (ldbg_links_open order) has a record for this k-mer",
+//                      so a walk only searches a link table where there is something to find
 //   pstart[4^p + 1] u32  radix index on the first p bases: records with that prefix are
 //                      [pstart[x], pstart[x+1]) -- replaces the top ~2p levels of the reference's
 //                      binary search (CortexGraph.java:282-313) with one cached load; the remaining
@@ -27,7 +29,7 @@ struct GraphView {
     const uint32_t* cov;
     const uint8_t* edges;
     const uint8_t* probe;
-    int stride, edges_off, cov_off;
+    int stride, edges_off, flags_off, cov_off;
     const uint32_t* pstart;
     int java_tiny;   // N <= 2: findRecord's loop never runs -> every lookup misses
 };
@@ -53,6 +55,7 @@ LDBG_HOSTDEV int64_t graph_find_canonical(const GraphView& g, const Kmer<W>& q) 
 }
 LDBG_HOSTDEV const uint8_t* graph_row(const GraphView& g, int64_t idx) { return g.probe + (size_t)idx * (size_t)g.stride; }
 LDBG_HOSTDEV uint8_t graph_edges(const GraphView& g, int64_t idx, int c) { return graph_row(g, idx)[g.edges_off + c]; }
+LDBG_HOSTDEV uint8_t graph_link_flags(const GraphView& g, int64_t idx) { return graph_row(g, idx)[g.flags_off]; }
 LDBG_HOSTDEV uint32_t graph_cov(const GraphView& g, int64_t idx, int c) {
     return ((const uint32_t*)(graph_row(g, idx) + g.cov_off))[c];
 }
@@ -79,6 +82,9 @@ public:
     void records_dev(int64_t first, int64_t n, uint64_t* d_words, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const;
     void find_dev(const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const;
     int color_for_sample_name(const std::string& name) const;
+    // link sets bound to this graph get a flag bit in the probe rows (at most 8)
+    mutable int next_link_slot = 0;
+    uint8_t* probe_mutable() const { return (uint8_t*)d_probe_; }
 
 private:
     void* d_keys_ = nullptr; void* d_cov_ = nullptr; void* d_edges_ = nullptr; void* d_probe_ = nullptr; void* d_pstart_ = nullptr;

@@ -69,11 +69,26 @@ LDBG_HD Kmer<W> kmer_canonical(const Kmer<W>& a, int k, bool* flipped_by_compare
     return f ? rc : a;
 }
 
+// word `idx` without a dynamically indexed array access (keeps Kmer<W> in registers on the GPU:
+// a runtime subscript would force every struct holding a k-mer into scratch / LDS)
+template <int W>
+LDBG_HD uint64_t kmer_word(const Kmer<W>& a, int idx) {
+    uint64_t v = a.w[0];
+#pragma unroll
+    for (int i = 1; i < W; i++) v = (idx == i) ? a.w[i] : v;
+    return v;
+}
+template <int W>
+LDBG_HD void kmer_or_word(Kmer<W>& a, int idx, uint64_t bits) {
+#pragma unroll
+    for (int i = 0; i < W; i++) a.w[i] |= (idx == i) ? bits : 0ULL;
+}
+
 // base i (0 = first / leftmost base) as 0..3
 template <int W>
 LDBG_HD unsigned kmer_base(const Kmer<W>& a, int k, int i) {
     int bit = 2 * (k - 1 - i);
-    return (unsigned)((a.w[W - 1 - (bit >> 6)] >> (bit & 63)) & 3ULL);
+    return (unsigned)((kmer_word<W>(a, W - 1 - (bit >> 6)) >> (bit & 63)) & 3ULL);
 }
 
 // successor: drop the first base, append b   (TraversalUtils.getAllNextKmers, sk[1:]+e)
@@ -95,7 +110,7 @@ LDBG_HD Kmer<W> kmer_prev(const Kmer<W>& a, int k, unsigned b) {
     for (int i = W - 1; i > 0; i--) r.w[i] = (a.w[i] >> 2) | (a.w[i - 1] << 62);
     r.w[0] = a.w[0] >> 2;
     int bit = 2 * (k - 1);
-    r.w[W - 1 - (bit >> 6)] |= (uint64_t)b << (bit & 63);
+    kmer_or_word<W>(r, W - 1 - (bit >> 6), (uint64_t)b << (bit & 63));
     return r;
 }
 
@@ -104,7 +119,7 @@ template <int W>
 LDBG_HD uint32_t kmer_java_hash(const Kmer<W>& a, int k) {
     uint32_t h = 1;
     for (int i = 0; i < k; i++) {
-        unsigned b = kmer_base<W>(a, k, i);
+        unsigned b = kmer_base<W>(a, k, i);   // kmer_word: select chain, no scratch
         // 'A'=65 'C'=67 'G'=71 'T'=84
         uint32_t ch = b == 0 ? 65u : (b == 1 ? 67u : (b == 2 ? 71u : 84u));
         h = 31u * h + ch;
@@ -118,8 +133,8 @@ LDBG_HD uint32_t kmer_prefix(const Kmer<W>& a, int k, int p) {
     int sh = 2 * (k - p);   // shift right by sh over the 64W-bit string
     int wi = W - 1 - (sh >> 6);
     int b = sh & 63;
-    uint64_t v = a.w[wi] >> b;
-    if (b != 0 && wi > 0) v |= a.w[wi - 1] << (64 - b);
+    uint64_t v = kmer_word<W>(a, wi) >> b;
+    if (b != 0 && wi > 0) v |= kmer_word<W>(a, wi - 1) << (64 - b);
     return (uint32_t)(v & ((1ULL << (2 * p)) - 1ULL));
 }
 

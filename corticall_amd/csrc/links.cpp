@@ -141,6 +141,18 @@ std::vector<std::string> split_fields(const std::string& s, bool commas) {
 
 }  // namespace
 
+// sets bit `slot` of the link-flags byte of every graph record that has a link record in this set
+template <int W>
+LDBG_KERNEL void k_set_link_flags(GraphView g, uint8_t* probe, const uint64_t* keys, int64_t M, int slot) {
+    for (int64_t i = global_tid(); i < M; i += global_nthreads()) {
+        Kmer<W> q;
+#pragma unroll
+        for (int w = 0; w < W; w++) q.w[w] = keys[i * W + w];
+        int64_t idx = graph_find_canonical<W>(g, q);
+        if (idx >= 0) probe[(size_t)idx * (size_t)g.stride + g.flags_off] |= (uint8_t)(1u << slot);
+    }
+}
+
 Links::Links(const std::string& path, const Graph& g) : device(g.device) {
     std::string text = gunzip_file(path);
     // header = lines from "{" to "}" (CortexLinksIterable.java:58-67)
@@ -234,43 +246,77 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
         while (have && line.empty()) have = next_line(line);
     }
 
-    // flatten in key order
-    std::vector<uint64_t> keys;
-    std::vector<uint32_t> off{0};
-    std::vector<uint8_t> kcanon, bases;
-    std::vector<JuncRec> junc;
     for (auto& kv : by_key) {
         record_keys.push_back(kv.first);
         records.push_back(kv.second);
-        keys.insert(keys.end(), kv.first.begin(), kv.first.end());
         std::vector<uint64_t> w(W);
         ascii_to_words(kv.second.kmer.c_str(), k, w.data(), W);
-        kcanon.push_back(w == kv.first ? 1 : 0);
-        for (auto& j : kv.second.juncs) {
-            JuncRec jr;
-            jr.str_off = (uint32_t)bases.size();
-            jr.len = (uint32_t)j.junctions.size();
-            jr.hash_asis = jstring_hash(j.junctions);
-            jr.hash_comp = jstring_hash(complement_ascii(j.junctions));
-            jr.is_fw = j.is_fw ? 1u : 0u;
-            for (char ch : j.junctions) {
-                uint8_t code;
-                switch (ch) {
-                    case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break;
-                    default: throw StatusError(LDBG_ERR_UNSUPPORTED, std::string("junction string with a non-ACGT character '") + ch + "'");
+        record_is_canonical.push_back(w == kv.first ? 1 : 0);
+    }
+    // claim a flag bit in the graph's probe rows and set it on every record that has links here
+    if (g.next_link_slot >= 8) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than 8 link sets bound to one graph");
+    slot = g.next_link_slot++;
+    const int64_t M = (int64_t)records.size();
+    if (M > 0) {
+        rt::set_device(device);
+        std::vector<uint64_t> keys;
+        keys.reserve((size_t)M * W);
+        for (auto& kk : record_keys) keys.insert(keys.end(), kk.begin(), kk.end());
+        void* d_keys = rt::dmalloc(keys.size() * 8);
+        rt::h2d(d_keys, keys.data(), keys.size() * 8, g.stream);
+        const int grid = (int)std::min<int64_t>((M + 255) / 256, 2048);
+        switch (W) {
+            case 1: LDBG_LAUNCH(k_set_link_flags<1>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot); break;
+            case 2: LDBG_LAUNCH(k_set_link_flags<2>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot); break;
+            case 3: LDBG_LAUNCH(k_set_link_flags<3>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot); break;
+            default: LDBG_LAUNCH(k_set_link_flags<4>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot); break;
+        }
+        rt::stream_sync(g.stream);
+        rt::dfree(d_keys);
+    }
+}
+
+MergedLinks::MergedLinks(const std::vector<const Links*>& sets, const Graph& g) {
+    const int W = g.hdr.W, k = g.hdr.k;
+    struct Ref { const Links* l; size_t i; };
+    std::map<std::vector<uint64_t>, std::vector<Ref>> by_key;
+    for (const Links* l : sets) {
+        flag_mask |= 1u << l->slot;
+        for (size_t i = 0; i < l->records.size(); i++) by_key[l->record_keys[i]].push_back({l, i});
+    }
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> off{0};
+    std::vector<uint8_t> bases;
+    std::vector<JuncRec> junc;
+    for (auto& kv : by_key) {
+        keys.insert(keys.end(), kv.first.begin(), kv.first.end());
+        for (auto& r : kv.second) {
+            const bool rec_canon = r.l->record_is_canonical[r.i] != 0;
+            for (auto& j : r.l->records[r.i].juncs) {
+                JuncRec jr;
+                jr.str_off = (uint32_t)bases.size();
+                jr.len = (uint32_t)j.junctions.size();
+                jr.hash_asis = jstring_hash(j.junctions);
+                jr.hash_comp = jstring_hash(complement_ascii(j.junctions));
+                jr.is_fw = (rec_canon == j.is_fw) ? 1u : 0u;
+                for (char ch : j.junctions) {
+                    uint8_t code;
+                    switch (ch) {
+                        case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break;
+                        default: throw StatusError(LDBG_ERR_UNSUPPORTED, std::string("junction string with a non-ACGT character '") + ch + "'");
+                    }
+                    bases.push_back(code);
                 }
-                bases.push_back(code);
+                junc.push_back(jr);
             }
-            junc.push_back(jr);
         }
         off.push_back((uint32_t)junc.size());
     }
-    const int64_t M = (int64_t)records.size();
+    const int64_t M = (int64_t)by_key.size();
     int p = 1;
     while (p < k && p < 12 && (1LL << (2 * (p + 1))) <= std::max<int64_t>(M, 1)) p++;
     std::vector<uint32_t> pstart(((size_t)1 << (2 * p)) + 1, (uint32_t)M);
     {
-        // pstart[x] = first record whose prefix >= x
         size_t x = 0;
         for (int64_t i = 0; i < M; i++) {
             uint32_t px;
@@ -283,14 +329,12 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
             while (x <= px) pstart[x++] = (uint32_t)i;
         }
     }
-
-    rt::set_device(device);
+    rt::set_device(g.device);
     rt::stream_t s = g.stream;
     auto up = [&](const void* h, size_t n) { void* d = rt::dmalloc(n); rt::h2d(d, h, n, s); return d; };
     d_keys_ = up(keys.data(), keys.size() * 8);
     d_pstart_ = up(pstart.data(), pstart.size() * 4);
     d_off_ = up(off.data(), off.size() * 4);
-    d_kcanon_ = up(kcanon.data(), kcanon.size());
     d_junc_ = up(junc.data(), junc.size() * sizeof(JuncRec));
     d_bases_ = up(bases.data(), bases.size());
     rt::stream_sync(s);
@@ -299,13 +343,12 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
     view.pstart = (const uint32_t*)d_pstart_;
     view.p = p;
     view.off = (const uint32_t*)d_off_;
-    view.kcanon = (const uint8_t*)d_kcanon_;
     view.junc = (const JuncRec*)d_junc_;
     view.bases = (const uint8_t*)d_bases_;
 }
 
-Links::~Links() {
-    rt::dfree(d_keys_); rt::dfree(d_pstart_); rt::dfree(d_off_); rt::dfree(d_kcanon_); rt::dfree(d_junc_); rt::dfree(d_bases_);
+MergedLinks::~MergedLinks() {
+    rt::dfree(d_keys_); rt::dfree(d_pstart_); rt::dfree(d_off_); rt::dfree(d_junc_); rt::dfree(d_bases_);
 }
 
 const HostLinksRecord* Links::get(const std::string& kmer_ascii) const {

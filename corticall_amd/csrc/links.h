@@ -18,17 +18,18 @@ struct JuncRec {
     uint32_t len;
     int32_t hash_asis;   // java.lang.String.hashCode of the junction string
     int32_t hash_comp;   // ... of its complement (LinkStore.add, LinkStore.java:25)
-    uint32_t is_fw;
+    uint32_t is_fw;      // "the link goes forward when the querying k-mer is the canonical orientation":
+                         // (record k-mer string is canonical) == CortexJunctionsRecord.isForward()
 };
 
+// one searchable link table on the device (the link sets of a traversal, merged by canonical k-mer)
 struct LinksView {
     int64_t M;
-    const uint8_t* keys;      // rows of W u64 (stride 8W)
+    const uint8_t* keys;      // rows of W u64 (stride 8W), ascending
     const uint32_t* pstart;
     int p;
     const uint32_t* off;      // [M+1]
-    const uint8_t* kcanon;    // [M] 1 = the record's k-mer string is the canonical orientation
-    const JuncRec* junc;
+    const JuncRec* junc;      // per key: set after set (order of addition), each in HashSet iteration order
     const uint8_t* bases;
 };
 
@@ -40,23 +41,30 @@ struct HostLinksRecord {
     std::vector<HostJunction> juncs;    // HashSet iteration order
 };
 
+// one .ctp.gz file: parsed on the host; on the device it only owns a flag bit in the graph's probe rows
 class Links {
 public:
     Links(const std::string& path, const Graph& g);
-    ~Links();
     int version = 0, num_colors = 0, k = 0;
     int64_t num_kmers_in_graph = 0, num_kmers_with_links = 0, num_links = 0, link_bytes = 0;
     std::vector<std::string> sample_names;
-    std::vector<HostLinksRecord> records;            // sorted by canonical k-mer (device order)
+    std::vector<HostLinksRecord> records;            // sorted by canonical k-mer
     std::vector<std::vector<uint64_t>> record_keys;  // canonical packed words, same order
-    LinksView view{};
+    std::vector<uint8_t> record_is_canonical;        // the record's k-mer string is the canonical orientation
     int device = 0;
-    // host lookup for ldbg_links_get (containsKey/get)
-    const HostLinksRecord* get(const std::string& kmer_ascii) const;
+    int slot = -1;                                   // bit of the probe rows' link-flags byte
+    const HostLinksRecord* get(const std::string& kmer_ascii) const;   // containsKey / get
+};
 
+// the link sets a traversal may use, merged into one device table
+class MergedLinks {
+public:
+    MergedLinks(const std::vector<const Links*>& sets, const Graph& g);
+    ~MergedLinks();
+    LinksView view{};
+    uint32_t flag_mask = 0;
 private:
-    void* d_keys_ = nullptr; void* d_pstart_ = nullptr; void* d_off_ = nullptr; void* d_kcanon_ = nullptr;
-    void* d_junc_ = nullptr; void* d_bases_ = nullptr;
+    void* d_keys_ = nullptr; void* d_pstart_ = nullptr; void* d_off_ = nullptr; void* d_junc_ = nullptr; void* d_bases_ = nullptr;
 };
 
 // radix-indexed search over sorted key rows (shared by graph and links)

@@ -9,6 +9,11 @@
 
 namespace ldbg {
 
+// Path storage: every strand appends 8-byte vertex entries to 1024-entry blocks drawn from one pool
+// (one atomic per 1024 traversed k-mers), so memory follows the actual walk lengths instead of
+// maxLength per strand.
+#define LDBG_PATH_BLOCK 1024
+
 struct WalkArgs {
     EngineView e;
     const uint64_t* seeds;     // [n][W]; word 0 == ~0 marks a seed that is not a k-mer (non-ACGT)
@@ -16,8 +21,11 @@ struct WalkArgs {
     int64_t n_slots;
     int run_rev, run_fwd;
     unsigned long long* next_strand;
-    uint64_t* path;            // [n_strands][pcap]
-    int64_t pcap;
+    uint64_t* pool;            // [n_blocks][LDBG_PATH_BLOCK]
+    unsigned long long* next_block;
+    uint64_t n_blocks;
+    uint32_t* block_table;     // [n_strands][max_blocks]
+    int max_blocks;
     uint32_t* strand_n;        // vertices in the strand's branch graph (0 = empty graph)
     uint32_t* status;
     uint32_t* iters;
@@ -30,9 +38,28 @@ struct WalkArgs {
 };
 
 template <int W>
-LDBG_DEV uint64_t pack_vertex(const VRef<W>& v, int k, bool fwd) {
+LDBG_DEV uint64_t pack_vertex(const Node<W>& v, int k, bool fwd) {
     unsigned base = kmer_base<W>(v.sk, k, fwd ? k - 1 : 0);
-    return path_pack(v.idx, v.flip, base, v.copy);
+    return path_pack(v.idx, v.flip != 0, base, v.copy);
+}
+
+struct PathWriter {
+    uint64_t* cur;       // current block
+    uint32_t n;          // entries written
+};
+LDBG_DEV bool path_append(const WalkArgs& a, int64_t s, PathWriter& pw, uint64_t entry) {
+    const uint32_t off = pw.n & (LDBG_PATH_BLOCK - 1);
+    if (off == 0) {
+        const uint32_t bi = pw.n / LDBG_PATH_BLOCK;
+        if ((int)bi >= a.max_blocks) return false;
+        const uint64_t b = (uint64_t)atomic_add_u64(a.next_block, 1ull);
+        if (b >= a.n_blocks) return false;
+        a.block_table[s * a.max_blocks + bi] = (uint32_t)b;
+        pw.cur = a.pool + b * LDBG_PATH_BLOCK;
+    }
+    pw.cur[off] = entry;
+    pw.n++;
+    return true;
 }
 
 // private dfs(cv, goForward, 0, 0, {}, sinks) for ContigStopper (TraversalEngine.java:356-482)
@@ -41,65 +68,65 @@ LDBG_DEV void run_strand(const WalkArgs& a, int64_t s, VisitedTable& vt, LinkSto
     const EngineView& e = a.e;
     const int k = e.g.k;
     const bool fwd = (s & 1) != 0;
-    uint64_t* path = a.path + s * a.pcap;
-    uint32_t status = ST_OK, n_path = 0, iters = 0;
+    uint32_t status = ST_OK, iters = 0;
     bool branch_null = false;
+    PathWriter pw;
+    pw.cur = nullptr; pw.n = 0;
 
-    VRef<W> cv;
-    Adj<W> A;
-    const uint64_t* sw = a.seeds + (s >> 1) * W;
+    Node<W> cv;
+    {
+        const uint64_t* sw = a.seeds + (s >> 1) * W;
+        Kmer<W> sk;
 #pragma unroll
-    for (int i = 0; i < W; i++) cv.sk.w[i] = sw[i];
-    if (sw[0] != ~0ull) {
-        cv = vref_find<W>(e, cv.sk);
-        adj_of<W>(e, cv, A);
-    } else {   // not a k-mer: findRecord misses (Q4)
-        cv.idx = -1; cv.flip = false; cv.copy = 0;
-        A.idx = -1; A.flip = false; A.o = cv.sk; A.next_mask = A.prev_mask = 0; A.npe = e.recruit_mask != 0;
+        for (int i = 0; i < W; i++) sk.w[i] = sw[i];
+        if (sw[0] != ~0ull) { node_find<W>(e, sk, cv); node_locate<W>(vt, cv); }
+        else node_null<W>(e, sk, cv);   // not a k-mer: findRecord misses (Q4)
     }
     Cursor<W> cu;
     cu.has = false; cu.status = ST_OK;
     const bool links_on = e.cursor_on != 0;
     ls_clear(ls);
-    if (A.npe) status = ST_NULLPTR;
-    else if (links_on) cursor_seek<W>(e, cu, ls, cv, A, fwd);   // :363-365
+    if (cv.npe) status = ST_NULLPTR;
+    else if (links_on) cursor_seek<W>(e, cu, ls, vt, cv, fwd);   // :363-365
 
     uint32_t gV = 0;
     while (status == ST_OK) {
         iters++;
-        const uint32_t m = fwd ? A.next_mask : A.prev_mask;
+        const uint32_t m = fwd ? cv.next_mask : cv.prev_mask;
         int adj = 0;
-        VRef<W> av = cv;
-        Adj<W> anext;
-        bool have_anext = false;
+        Node<W> av = cv;
         if (links_on && cu.has) {                       // :379-407
-            VRef<W> t = cursor_step<W>(e, cu, ls, vt, fwd);
+            av = cursor_step<W>(e, cu, ls, vt, fwd);
             if (cu.status != ST_OK) { status = cu.status; break; }
-            int cnt = vt_count(vt, t.idx, t.flip);      // first unused copyIndex
-            t.copy = fwd ? cnt : -cnt;
-            av = t; adj = 1;
-            anext = cu.acur; have_anext = true;
+            const int cnt = node_count<W>(vt, av);      // first unused copyIndex
+            av.copy = fwd ? cnt : -cnt;
+            adj = 1;
         } else {
             for (unsigned b = 0; b < 4; b++) {
                 if (!((m >> b) & 1u)) continue;
-                VRef<W> x = vref_find<W>(e, neighbour<W>(A, k, fwd, b));
-                if (vt_count(vt, x.idx, x.flip) > 0) continue;   // avs.removeAll(seen) :416-422
+                Node<W> x;
+                node_find<W>(e, node_neighbour<W>(cv, k, fwd, b), x);
+                node_locate<W>(vt, x);
+                if (node_count<W>(vt, x) > 0) continue;          // avs.removeAll(seen) :416-422
                 adj++;
                 av = x;
             }
         }
         const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
-        const bool previously = acopy < vt_count(vt, cv.idx, cv.flip);   // :424
-        if (!previously) {
+        uint64_t ecv = cv.idx >= 0 ? vt.tab[cv.vslot] : 0ull;
+        const bool previously = acopy < vt_count_e(ecv);                 // :424
+        if (!previously && cv.idx >= 0) {
             if (acopy + 1 > 32767) { status = ST_COPY_OVERFLOW; break; }
-            vt_update(vt, cv.idx, cv.flip, acopy + 1, false);           // visited.add(cv) :425
+            vt.tab[cv.vslot] = vt_with_count(ecv, acopy + 1);            // visited.add(cv) :425
         }
         const bool reached = gV > (uint32_t)e.max_len;                   // :428
         if (previously) { branch_null = true; break; }                   // :470-478, traversalSucceeded() still false
         if (adj != 1 || reached) break;                                  // ContigStopper succeeded -> return g
-        if (gV == 0) { path[n_path++] = pack_vertex<W>(cv, k, fwd); gV = 1; }   // connectVertex :494-516
-        if ((int64_t)n_path >= a.pcap) { status = ST_PATH_FULL; break; }
-        path[n_path++] = pack_vertex<W>(av, k, fwd);
+        if (gV == 0) {                                                   // connectVertex :494-516
+            if (!path_append(a, s, pw, pack_vertex<W>(cv, k, fwd))) { status = ST_POOL_FULL; break; }
+            gV = 1;
+        }
+        if (!path_append(a, s, pw, pack_vertex<W>(av, k, fwd))) { status = ST_POOL_FULL; break; }
         gV++;
         if (av.idx < 0) {
             uint64_t* tk = a.term + s * W;
@@ -107,10 +134,9 @@ LDBG_DEV void run_strand(const WalkArgs& a, int64_t s, VisitedTable& vt, LinkSto
             for (int i = 0; i < W; i++) tk[i] = av.sk.w[i];
         }
         cv = av;
-        if (have_anext) A = anext; else adj_of<W>(e, cv, A);
-        if (A.npe) status = ST_NULLPTR;
+        if (cv.npe) status = ST_NULLPTR;
     }
-    a.strand_n[s] = (branch_null || status != ST_OK) ? 0u : n_path;
+    a.strand_n[s] = (branch_null || status != ST_OK) ? 0u : pw.n;
     a.status[s] = status != ST_OK ? status : (branch_null ? (uint32_t)ST_BRANCH_NULL : (uint32_t)ST_OK);
     a.iters[s] = iters;
 }
@@ -151,7 +177,7 @@ struct AsmArgs {
     int64_t n;
     int op_and;
     const uint64_t* seeds;
-    const uint64_t* path; int64_t pcap;      // sparse arena
+    const uint64_t* pool; const uint32_t* block_table; int max_blocks;
     const uint32_t* strand_n; const uint32_t* status;
     int64_t* walk_len;                       // [n]
     uint8_t* seed_ok;                        // [n]
@@ -166,7 +192,8 @@ LDBG_KERNEL void k_walk_lengths(AsmArgs a) {
         int64_t len = 0;
         uint8_t ok = 0;
         if (!err && !is_null && nr + nf > 0) {
-            uint64_t seed_entry = nr > 0 ? a.path[(2 * i) * a.pcap] : a.path[(2 * i + 1) * a.pcap];
+            const int64_t ss = nr > 0 ? 2 * i : 2 * i + 1;
+            uint64_t seed_entry = a.pool[(uint64_t)a.block_table[ss * a.max_blocks] * LDBG_PATH_BLOCK];
             int64_t idx = path_idx(seed_entry);
             if (idx >= 0 && (int32_t)graph_cov(a.e.g, idx, a.e.first_trav) > 0) {   // Q5: coverage is a signed int
                 ok = 1;
@@ -178,11 +205,13 @@ LDBG_KERNEL void k_walk_lengths(AsmArgs a) {
     }
 }
 
-LDBG_KERNEL void k_compact_paths(const uint64_t* sparse, int64_t pcap, const int64_t* strand_off, int64_t n_strands, uint64_t* dense) {
+LDBG_KERNEL void k_compact_paths(const uint64_t* pool, const uint32_t* block_table, int max_blocks, const int64_t* strand_off,
+                                 int64_t n_strands, uint64_t* dense) {
     const int64_t wave = global_tid() >> 6, lane = global_tid() & 63, nwaves = (global_nthreads() + 63) >> 6;
     for (int64_t s = wave; s < n_strands; s += nwaves) {
         const int64_t o = strand_off[s], n = strand_off[s + 1] - o;
-        for (int64_t j = lane; j < n; j += 64) dense[o + j] = sparse[s * pcap + j];
+        for (int64_t j = lane; j < n; j += 64)
+            dense[o + j] = pool[(uint64_t)block_table[s * max_blocks + j / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK + (j & (LDBG_PATH_BLOCK - 1))];
     }
 }
 
@@ -262,6 +291,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     for (int i = 0; i < c.n_secondary; i++) if (c.secondary_colors[i] < 0 || c.secondary_colors[i] >= nc) fail("Secondary", c.secondary_colors[i]);
     if (c.stopping_rule < 0 || c.stopping_rule >= LDBG_STOP_COUNT) throw StatusError(LDBG_ERR_CORTEXJDK, "Must provide stopping rule for graph traversal");
 
+    rt::set_device(graph->device);
     view.g = graph->view;
     view.trav_mask = view.recruit_mask = view.join_mask = 0;
     for (int i = 0; i < c.n_traversal; i++) view.trav_mask |= 1u << c.traversal_colors[i];
@@ -273,19 +303,17 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.connect_all = c.connect_all_neighbors;
     view.strict_flip = c.strict_java_flip;
     // initializeLinkStore/updateLinkStore :548-597: only link sets whose colour-0 sample is a traversal sample
-    view.nlinks = 0;
     for (int i = 0; i < c.nlinks; i++) {
         const Links* l = (const Links*)c.links[i];
         if (!l) continue;
         bool mine = false;
         for (int t = 0; t < c.n_traversal; t++)
             if (!l->sample_names.empty() && l->sample_names[0] == graph->hdr.colors[c.traversal_colors[t]].sample_name) mine = true;
-        if (mine) {
-            if (view.nlinks >= LDBG_MAX_LINKS) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than " + std::to_string(LDBG_MAX_LINKS) + " link sets for one traversal");
-            view.links[view.nlinks++] = l->view;
-            my_links.push_back(l);
-        }
+        if (mine) my_links.push_back(l);
     }
+    merged_.reset(new MergedLinks(my_links, *graph));
+    view.links = merged_->view;
+    view.link_flag_mask = merged_->flag_mask;
     // ec.getLinks().isEmpty() (not "my links") decides whether dfs uses the cursor (:363, :379)
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
 }
@@ -293,9 +321,9 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
 Engine::~Engine() { clear_batch(); release_scratch(); }
 
 void Engine::release_scratch() {
-    rt::dfree(d_vtabs_); rt::dfree(d_ls_); rt::dfree(d_slot_gen_);
-    d_vtabs_ = d_ls_ = d_slot_gen_ = nullptr;
-    n_slots_ = 0;
+    rt::dfree(d_vtabs_); rt::dfree(d_ls_); rt::dfree(d_slot_gen_); rt::dfree(d_pool_); rt::dfree(d_block_table_);
+    d_vtabs_ = d_ls_ = d_slot_gen_ = d_pool_ = d_block_table_ = nullptr;
+    n_slots_ = 0; n_blocks_ = 0; bt_strands_ = 0;
 }
 
 void Engine::clear_batch() {
@@ -304,16 +332,30 @@ void Engine::clear_batch() {
     batch_n = batch_bytes = batch_traversed = 0;
 }
 
-void Engine::ensure_scratch(int64_t want_slots, uint32_t vcap, uint32_t ecap) {
-    if (d_vtabs_ && n_slots_ >= want_slots && vcap_ == vcap && ecap_ == ecap) return;
-    release_scratch();
+// per-slot visited tables + link stores, the path block pool and the block table; kept across batches
+void Engine::ensure_scratch(int64_t ns, uint32_t vcap, uint32_t ecap, int max_blocks) {
     rt::stream_t s = graph->stream;
-    d_vtabs_ = rt::dmalloc((size_t)want_slots * vcap * 8);
-    d_ls_ = rt::dmalloc((size_t)want_slots * ecap * sizeof(LsElem));
-    d_slot_gen_ = rt::dmalloc((size_t)want_slots * 4);
-    rt::dmemset(d_vtabs_, 0, (size_t)want_slots * vcap * 8, s);
-    rt::dmemset(d_slot_gen_, 0, (size_t)want_slots * 4, s);
-    n_slots_ = want_slots; vcap_ = vcap; ecap_ = ecap;
+    const size_t per_slot = (size_t)vcap * 8 + (size_t)ecap * sizeof(LsElem) + 4;
+    if (!(d_vtabs_ && vcap_ == vcap && ecap_ == ecap && max_blocks_ == max_blocks && bt_strands_ >= ns)) {
+        release_scratch();
+        size_t free_b = 0, total_b = 0;
+        rt::mem_info(&free_b, &total_b);
+        // memory split: up to 45% of what is free for the slots, up to 35% for the path pool
+        int64_t slots = (int64_t)((size_t)(free_b * 0.45) / per_slot);
+        slots = std::max<int64_t>(64, std::min<int64_t>(slots, 1 << 17));
+        slots = std::min<int64_t>(slots, ((ns + 63) / 64) * 64);
+        uint64_t want_blocks = (uint64_t)ns * (uint64_t)max_blocks;
+        uint64_t fit_blocks = (uint64_t)(free_b * 0.35) / (LDBG_PATH_BLOCK * 8);
+        n_blocks_ = std::max<uint64_t>(2, std::min(want_blocks, fit_blocks));
+        d_vtabs_ = rt::dmalloc((size_t)slots * vcap * 8);
+        d_ls_ = rt::dmalloc((size_t)slots * ecap * sizeof(LsElem));
+        d_slot_gen_ = rt::dmalloc((size_t)slots * 4);
+        d_pool_ = rt::dmalloc((size_t)n_blocks_ * LDBG_PATH_BLOCK * 8);
+        d_block_table_ = rt::dmalloc((size_t)ns * max_blocks * 4);
+        rt::dmemset(d_vtabs_, 0, (size_t)slots * vcap * 8, s);
+        rt::dmemset(d_slot_gen_, 0, (size_t)slots * 4, s);
+        n_slots_ = slots; vcap_ = vcap; ecap_ = ecap; max_blocks_ = max_blocks; bt_strands_ = ns;
+    }
 }
 
 void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
@@ -326,20 +368,24 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
     std::vector<uint64_t> words((size_t)n * W);
     for (int64_t i = 0; i < n; i++)
         if (!ascii_to_words(seeds + i * k, k, &words[i * W], W)) words[i * W] = ~0ull;
-
-    // chunking: the sparse path arena holds the worst case (maxLength + 2 vertices per strand)
-    size_t free_b = 0, total_b = 0;
-    rt::mem_info(&free_b, &total_b);
-    const int64_t pcap = (int64_t)cfg.max_branch_length + 2;
-    const size_t per_seed = (size_t)2 * pcap * 8;
-    int64_t chunk = (int64_t)std::max<size_t>(1, (size_t)(free_b * 0.40) / per_seed);
-    chunk = std::min<int64_t>(chunk, std::max<int64_t>(n, 1));
     batch_n = n;
     int64_t trav = 0;
-    for (int64_t first = 0; first < n; first += chunk) {
-        chunks.emplace_back();
-        run_chunk(words, first, std::min(chunk, n - first), chunks.back(), &trav);
+    // the whole batch in one launch; if the path pool runs dry the batch is split and re-run (exactness first)
+    std::vector<std::pair<int64_t, int64_t>> todo{{0, n}};
+    while (!todo.empty()) {
+        auto [first, cnt] = todo.back();
+        todo.pop_back();
+        if (cnt <= 0) continue;
+        WalkChunk c;
+        int64_t t = 0;
+        if (run_chunk(words, first, cnt, c, &t)) { trav += t; chunks.push_back(std::move(c)); }
+        else {
+            if (cnt == 1) throw StatusError(LDBG_ERR_HIP, "path pool too small for a single walk: not enough device memory");
+            todo.push_back({first + cnt / 2, cnt - cnt / 2});
+            todo.push_back({first, cnt / 2});
+        }
     }
+    std::sort(chunks.begin(), chunks.end(), [](const WalkChunk& a, const WalkChunk& b) { return a.first < b.first; });
     batch_traversed = trav;
     batch_bytes = 0;
     for (auto& c : chunks) batch_bytes += c.contig_off.back();
@@ -347,36 +393,28 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
     if (traversed) *traversed = trav;
 }
 
-void Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed) {
+// returns false when the path pool was exhausted (nothing is kept; the caller splits the chunk)
+bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed) {
     const int W = graph->hdr.W, k = graph->hdr.k;
     rt::stream_t s = graph->stream;
     const int64_t ns = 2 * n;
-    const int64_t pcap = (int64_t)cfg.max_branch_length + 2;
     out.first = first; out.n = n;
 
-    // scratch: per-slot visited table sized for the longest possible branch at load <= 1/2
+    // per-slot visited table sized for the longest possible branch at load <= 1/2
     const uint32_t vcap = std::max<uint32_t>(64u, next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 4)));
-    size_t free_b = 0, total_b = 0;
-    rt::mem_info(&free_b, &total_b);
-    uint32_t ecap = link_store_capacity;
-    const size_t sparse_bytes = (size_t)ns * pcap * 8;
-    size_t budget = free_b > sparse_bytes ? (size_t)((free_b - sparse_bytes) * 0.5) : 0;
-    if (n_slots_ > 0) budget += (size_t)n_slots_ * ((size_t)vcap_ * 8 + (size_t)ecap_ * sizeof(LsElem));
-    int64_t slots = (int64_t)(budget / ((size_t)vcap * 8 + (size_t)ecap * sizeof(LsElem) + 4));
-    slots = std::max<int64_t>(64, std::min<int64_t>(slots, 1 << 18));
-    slots = std::min<int64_t>(slots, ((ns + 63) / 64) * 64);
-    if (!(d_vtabs_ && n_slots_ >= slots && vcap_ == vcap && ecap_ == ecap)) ensure_scratch(slots, vcap, ecap);
+    const int max_blocks = (int)(((int64_t)cfg.max_branch_length + 2 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK);
+    ensure_scratch(ns, vcap, link_store_capacity, max_blocks);
 
     out.d_seed_words = rt::dmalloc((size_t)n * W * 8);
     rt::h2d(out.d_seed_words, &seed_words[first * W], (size_t)n * W * 8, s);
     out.d_term = rt::dmalloc((size_t)ns * W * 8);
-    void* d_sparse = rt::dmalloc(sparse_bytes);
     uint32_t* d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint32_t* d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint32_t* d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    unsigned long long* d_next = (unsigned long long*)rt::dmalloc(8);
-    rt::dmemset(d_next, 0, 8, s);
+    unsigned long long* d_ctr = (unsigned long long*)rt::dmalloc(16);
+    rt::dmemset(d_ctr, 0, 16, s);
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
+    auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); };
 
     WalkArgs a;
     a.e = view;
@@ -385,13 +423,16 @@ void Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
     a.run_rev = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_REVERSE;
     a.run_fwd = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_FORWARD;
-    a.next_strand = d_next;
-    a.path = (uint64_t*)d_sparse; a.pcap = pcap;
+    a.next_strand = d_ctr;
+    a.next_block = d_ctr + 1;
+    a.pool = (uint64_t*)d_pool_; a.n_blocks = n_blocks_;
+    a.block_table = (uint32_t*)d_block_table_; a.max_blocks = max_blocks;
     a.strand_n = d_strand_n; a.status = d_status; a.iters = d_iters;
     a.term = (uint64_t*)out.d_term;
     a.vtabs = (uint64_t*)d_vtabs_; a.vcap = vcap_;
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
     a.slot_gen = (uint32_t*)d_slot_gen_;
+
     rt::Event e0, e1;
     e0.record(s);
     const int block = 64;
@@ -409,7 +450,8 @@ void Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     uint8_t* d_seed_ok = (uint8_t*)rt::dmalloc((size_t)n);
     AsmArgs aa;
     aa.e = view; aa.n = n; aa.op_and = cfg.combination_operator == LDBG_OP_AND;
-    aa.seeds = a.seeds; aa.path = a.path; aa.pcap = pcap; aa.strand_n = d_strand_n; aa.status = d_status;
+    aa.seeds = a.seeds; aa.pool = a.pool; aa.block_table = a.block_table; aa.max_blocks = max_blocks;
+    aa.strand_n = d_strand_n; aa.status = d_status;
     aa.walk_len = d_walk_len; aa.seed_ok = d_seed_ok;
     LDBG_LAUNCH(k_walk_lengths, grid_for(n, 256, 2048), 256, s, aa);
 
@@ -424,6 +466,15 @@ void Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     rt::d2h(out.seed_ok.data(), d_seed_ok, (size_t)n, s);
     rt::stream_sync(s);
     profile_add("walk", rt::Event::elapsed_ms(e0, e1));
+
+    bool pool_full = false;
+    for (int64_t i = 0; i < ns; i++) pool_full |= out.status[i] == ST_POOL_FULL;
+    if (pool_full) {
+        free_tmp(); rt::dfree(d_walk_len); rt::dfree(d_seed_ok);
+        rt::dfree(out.d_seed_words); rt::dfree(out.d_term);
+        out.d_seed_words = out.d_term = nullptr;
+        return false;
+    }
     for (int64_t i = 0; i < ns; i++) *traversed += iters[i];
 
     // dense paths + contigs
@@ -439,7 +490,8 @@ void Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     out.d_contigs = rt::dmalloc((size_t)out.contig_off[n]);
     rt::Event c0, c1;
     c0.record(s);
-    LDBG_LAUNCH(k_compact_paths, grid_for(ns * 64, 256, 4096), 256, s, (const uint64_t*)d_sparse, pcap, (const int64_t*)d_strand_off, ns, (uint64_t*)out.d_path);
+    LDBG_LAUNCH(k_compact_paths, grid_for(ns * 64, 256, 4096), 256, s, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
+                (const int64_t*)d_strand_off, ns, (uint64_t*)out.d_path);
     const int cg = grid_for(n * 64, 256, 4096);
     switch (W) {
         case 1: LDBG_LAUNCH(k_contigs<1>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
@@ -450,19 +502,18 @@ void Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     c1.record(s);
     rt::stream_sync(s);
     profile_add("contig", rt::Event::elapsed_ms(c0, c1));
-    rt::dfree(d_sparse); rt::dfree(d_strand_n); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_next);
+    free_tmp();
     rt::dfree(d_walk_len); rt::dfree(d_seed_ok); rt::dfree(d_strand_off); rt::dfree(d_contig_off);
 
     // errors the reference raises as exceptions abort the call
     for (int64_t i = 0; i < ns; i++) {
         if (out.status[i] == ST_NULLPTR)
             throw StatusError(LDBG_ERR_NULLPOINTER, "getNextVertices: record missing while recruitment colours are set (seed " + std::to_string(first + i / 2) + ")");
-        if (out.status[i] == ST_LINKSTORE_FULL) {
-            throw StatusError(LDBG_ERR_CAPACITY, "LINKSTORE_FULL");
-        }
-        if (out.status[i] == ST_COPY_OVERFLOW || out.status[i] == ST_PATH_FULL)
-            throw StatusError(LDBG_ERR_UNSUPPORTED, "walk exceeded an internal limit (status " + std::to_string(out.status[i]) + ")");
+        if (out.status[i] == ST_LINKSTORE_FULL) throw StatusError(LDBG_ERR_CAPACITY, "LINKSTORE_FULL");
+        if (out.status[i] == ST_COPY_OVERFLOW)
+            throw StatusError(LDBG_ERR_UNSUPPORTED, "a vertex was visited more than 32767 times in one walk");
     }
+    return true;
 }
 
 void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len) {
