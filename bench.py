@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--repeat-families", type=int, default=4000)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--use-seeds", type=int, default=0, help="experiment: walk only the first N seeds")
+    ap.add_argument("--no-strict", action="store_true", help="experiment: CanonicalKmer.isFlipped by comparison (not Java-exact, Q6)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,6 +107,8 @@ def main():
 
     prefix, st = workload_files(args, 0)        # same graph on every rank
     seeds = np.fromfile(prefix + ".seeds", dtype=np.uint8).reshape(-1, args.k)
+    if args.use_seeds:
+        seeds = seeds[np.random.default_rng(7).permutation(len(seeds))[:args.use_seeds]]
     if world > 1:                               # weak scaling: each rank walks its own seeds
         rng = np.random.default_rng(1000 + rank)
         seeds = seeds[rng.permutation(len(seeds))]
@@ -113,7 +117,7 @@ def main():
     g = CortexGraph(prefix + ".ctx", device=local_rank)
     links = CortexLinks(prefix + ".ctp.gz", g)
     eng = (TraversalEngineFactory().traversalColors(g.getColorForSampleName("child")).traversalDirection(BOTH)
-           .combinationOperator(OR).stoppingRule(ContigStopper).maxBranchLength(args.max_len).graph(g).links(links).make())
+           .combinationOperator(OR).stoppingRule(ContigStopper).maxBranchLength(args.max_len).graph(g).links(links).strictJavaFlip(not args.no_strict).make())
     t_load = time.time() - t_load
 
     def sync():

@@ -12,7 +12,7 @@ struct CursorStateDev {
     Node<W> nxt, prv;
     uint32_t has_next, has_prev, first, go_forward, status;
     uint32_t ls_n, ls_java_cap, ls_nkeys, ls_next_seq;
-    uint32_t gen;
+    uint32_t vt_used;
     // outputs of the last step
     uint64_t out_words[W];
     int64_t out_rec;
@@ -21,17 +21,17 @@ struct CursorStateDev {
 template <int W>
 LDBG_DEV void cs_reseek(const EngineView& e, CursorStateDev<W>& st, uint64_t* vtab, uint32_t vcap) {
     // seek(sk) :321-335 — unique neighbours, fresh LinkStore, fresh `seen`
-    if (st.gen >= 32766u) { for (uint32_t i = 0; i < vcap; i++) vtab[i] = 0; st.gen = 0; }
-    st.gen++;
+    if (st.vt_used != 0) for (uint32_t i = 0; i < vcap; i++) vtab[i] = 0;    // seen = new HashSet<>()
     VisitedTable vt;
-    vt.tab = vtab; vt.mask = vcap - 1; vt.gen = st.gen;
+    vt.tab = vtab; vt.mask = vcap - 1; vt.used = 0;
     node_locate<W>(vt, st.cur);
     st.has_next = popc4(st.cur.next_mask) == 1;
-    if (st.has_next) { node_find<W>(e, node_neighbour<W>(st.cur, e.g.k, true, lowbit4(st.cur.next_mask)), st.nxt); node_locate<W>(vt, st.nxt); }
+    if (st.has_next) { node_child<W>(e, st.cur, true, lowbit4(st.cur.next_mask), st.nxt); node_locate<W>(vt, st.nxt); }
     st.has_prev = popc4(st.cur.prev_mask) == 1;
-    if (st.has_prev) { node_find<W>(e, node_neighbour<W>(st.cur, e.g.k, false, lowbit4(st.cur.prev_mask)), st.prv); node_locate<W>(vt, st.prv); }
+    if (st.has_prev) { node_child<W>(e, st.cur, false, lowbit4(st.cur.prev_mask), st.prv); node_locate<W>(vt, st.prv); }
     st.ls_n = st.ls_java_cap = st.ls_nkeys = st.ls_next_seq = 0;
     st.first = 1;
+    st.vt_used = vt.used;
     st.status = st.cur.npe ? (uint32_t)ST_NULLPTR : (uint32_t)ST_OK;
 }
 
@@ -58,7 +58,8 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
         if (st.status != ST_OK) return;
     }
     VisitedTable vt;
-    vt.tab = vtab; vt.mask = vcap - 1; vt.gen = st.gen;
+    vt.tab = vtab; vt.mask = vcap - 1; vt.used = st.vt_used;
+    if (vt.used * 2 > vcap) { st.status = ST_POOL_FULL; return; }   // more steps since seek() than the cursor's `seen` table holds
     LinkStoreDev ls;
     ls.el = els; ls.cap = ecap; ls.n = st.ls_n; ls.java_cap = st.ls_java_cap; ls.nkeys = st.ls_nkeys; ls.next_seq = st.ls_next_seq;
     ls.overflow = false;
@@ -75,6 +76,7 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
     else { st.nxt = old; st.has_next = 1; st.prv = cu.nxt; st.has_prev = cu.has ? 1 : 0; }
     st.ls_n = ls.n; st.ls_java_cap = ls.java_cap; st.ls_nkeys = ls.nkeys; st.ls_next_seq = ls.next_seq;
     st.status = cu.status;
+    st.vt_used = vt.used;
     for (int i = 0; i < W; i++) st.out_words[i] = t.sk.w[i];
     st.out_rec = t.idx;
 }
@@ -85,7 +87,7 @@ struct CursorHost::Impl {
     void* d_vtab = nullptr;
     void* d_ls = nullptr;
     void* d_words = nullptr;
-    uint32_t vcap = 1u << 16, ecap = 256;
+    uint32_t vcap = 1u << 17, ecap = 256;
     size_t state_bytes = 0;
     bool sought = false;
 };
@@ -119,6 +121,7 @@ static void read_state(void* d, CursorStateDev<W>& h, rt::stream_t s) {
 void CursorHost::check_status(uint32_t st) {
     if (st == ST_NULLPTR) throw StatusError(LDBG_ERR_NULLPOINTER, "cursor dereferenced a missing record / vanished target (NullPointerException in the reference)");
     if (st == ST_LINKSTORE_FULL) throw StatusError(LDBG_ERR_CAPACITY, "cursor link store capacity exceeded");
+    if (st == ST_POOL_FULL) throw StatusError(LDBG_ERR_CAPACITY, "cursor walked more than 65536 steps since the last seek()");
 }
 
 void CursorHost::seek(const char* kmer) {

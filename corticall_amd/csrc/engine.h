@@ -82,6 +82,19 @@ LDBG_HOSTDEV void node_null(const EngineView& e, const Kmer<W>& sk, Node<W>& n) 
     n.next_mask = n.prev_mask = 0;
     n.npe = e.recruit_mask != 0 ? 1 : 0;
 }
+// CanonicalKmer.isFlipped(): Arrays.hashCode(canonical) != Arrays.hashCode(supplied) (CanonicalKmer.java:16,23,33).
+// Differs from "the k-mer was reverse complemented" only on a 32-bit hash collision (Q6); the hashes are first
+// compared modulo 32 (a few popcounts), the 2k multiply-adds run for 1 flipped k-mer in 32.
+template <int W>
+LDBG_HOSTDEV bool java_flipped(const EngineView& e, const Kmer<W>& sk, bool flip_cmp) {
+    if (!flip_cmp || !e.strict_flip) return flip_cmp;
+    uint32_t hs, hr;
+    kmer_java_hash_mod32<W>(sk, e.g.k, &hs, &hr);
+    if (hs != hr) return true;
+    return kmer_java_hash<W>(kmer_revcomp<W>(sk, e.g.k), e.g.k) != kmer_java_hash<W>(sk, e.g.k);
+}
+template <int W> LDBG_HOSTDEV void node_fill_masks(const EngineView& e, Node<W>& n);
+
 // findRecord(sk) + neighbourhood: one radix-index load, then probe rows; the matching row yields edges and
 // link flags from the same sector as its key.
 template <int W>
@@ -90,11 +103,19 @@ LDBG_HOSTDEV void node_find(const EngineView& e, const Kmer<W>& sk, Node<W>& n) 
     bool fc;
     Kmer<W> c = kmer_canonical<W>(sk, g.k, &fc);
     n.sk = sk; n.copy = 0; n.vslot = 0; n.flip = fc ? 1 : 0; n.npe = 0; n.lflags = 0;
-    bool fj = fc;
-    if (e.strict_flip && fc) fj = kmer_java_hash<W>(c, g.k) != kmer_java_hash<W>(sk, g.k);
+    const bool fj = java_flipped<W>(e, sk, fc);
     n.fj = fj ? 1 : 0;
     const int64_t idx = graph_find_canonical<W>(g, c);
     n.idx = idx;
+    node_fill_masks<W>(e, n);
+}
+// edges of the node's record -> neighbour masks (+ link flags); one row read
+template <int W>
+LDBG_HOSTDEV void node_fill_masks(const EngineView& e, Node<W>& n) {
+    const GraphView& g = e.g;
+    const int64_t idx = n.idx;
+    const bool fj = n.fj != 0;
+    n.npe = 0; n.lflags = 0;
     uint32_t tf = 0, tr = 0, rf = 0, rr = 0;
     if (idx >= 0) {
         const uint8_t* row = graph_row(g, idx);
@@ -118,30 +139,58 @@ LDBG_HOSTDEV void node_find(const EngineView& e, const Kmer<W>& sk, Node<W>& n) 
     n.prev_mask = (uint8_t)(tr ? tr : rr);
 }
 
+// neighbour `base` of vertex p in travel direction `fwd`, through the neighbour index of p's probe row
+// (memoised findRecord, graph.h) — no search, no canonicalisation on the walk's critical path
+template <int W>
+LDBG_HOSTDEV void node_child(const EngineView& e, const Node<W>& p, bool fwd, unsigned base, Node<W>& n) {
+    const GraphView& g = e.g;
+    const Kmer<W> sk = node_neighbour<W>(p, g.k, fwd, base);
+    if (!g.nbr_on || p.idx < 0 || !(g.k & 1)) { node_find<W>(e, sk, n); return; }   // even k: palindromes need the compare
+    // p's orientation for neighbour generation is its Java flip: o = fj ? rc(canon) : canon.
+    //   fwd, !fj: next(c, b)            -> succ[b]         fwd, fj: next(rc(c), b) = rc(prev(c, 3-b)) -> pred[3-b], toggled
+    //   rev, !fj: prev(c, b)            -> pred[b]         rev, fj: prev(rc(c), b) = rc(next(c, 3-b)) -> succ[3-b], toggled
+    const bool fj = p.fj != 0;
+    const unsigned j = fwd ? (!fj ? base : 4u + (3u - base)) : (!fj ? 4u + base : (3u - base));
+    const uint32_t ent = graph_nbr(g, p.idx, (int)j);
+    n.sk = sk; n.copy = 0; n.vslot = 0;
+    n.idx = (int64_t)(ent & 0x7FFFFFFFu) - 1;
+    const bool flip = (((ent >> 31) & 1u) != 0) != fj;
+    n.flip = (n.idx >= 0 && flip) ? 1 : 0;
+    if (n.idx < 0) { bool fc; kmer_canonical<W>(sk, g.k, &fc); n.flip = fc ? 1 : 0; }   // null record: identity by k-mer
+    n.fj = java_flipped<W>(e, sk, n.flip != 0) ? 1 : 0;
+    node_fill_masks<W>(e, n);
+}
+
 // ---- per-walk visited table (HashSet<CortexVertex> visited, TraversalEngine.java:360-425, plus the
-// cursor's `seen` set :27,262-265): open addressing over 8-byte entries in HBM, generation-tagged so
-// a slot is reused by the next walk without clearing.  A vertex is located once (when it is first looked
-// up as a neighbour); later updates go straight to its slot.
-//  bits 0..32 key = (record index << 1) | flip ; bits 33..47 generation ; bits 48..62 copies visited ; bit 63 seen
+// cursor's `seen` set :27,262-265): open addressing over 8-byte entries in HBM.  A table is carved out of a
+// zeroed pool when a strand starts (4096 entries) and regrown x4 when half full, so memory follows the
+// walk lengths.  A vertex is located once (when it is first looked up as a neighbour); later updates go
+// straight to its slot.
+//  entry: bits 0..33 key = ((record index + 1) << 1) | flip (never 0) ; bits 48..62 copies visited ; bit 63 seen
 struct VisitedTable {
     uint64_t* tab;
     uint32_t mask;   // capacity - 1
-    uint32_t gen;    // 1..32767
+    uint32_t used;   // claimed slots
 };
+#define LDBG_VT_KEY_MASK 0x3FFFFFFFFull
 LDBG_HOSTDEV uint32_t vt_hash(uint64_t key) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(x >> 32);
 }
-// slot of (idx, flip); claims a free slot (count 0, not seen) if the vertex is not in the table yet
-LDBG_HOSTDEV uint32_t vt_locate(VisitedTable& t, int64_t idx, bool flip) {
-    const uint64_t key = ((uint64_t)idx << 1) | (flip ? 1ull : 0ull);
-    uint32_t h = vt_hash(key) & t.mask;
+LDBG_HOSTDEV uint64_t vt_key(int64_t idx, bool flip) { return ((uint64_t)(idx + 1) << 1) | (flip ? 1ull : 0ull); }
+// slot of the key starting the probe at h with the first entry already loaded; claims a free slot if absent
+LDBG_HOSTDEV uint32_t vt_locate_from(VisitedTable& t, uint64_t key, uint32_t h, uint64_t e) {
     while (true) {
-        uint64_t e = t.tab[h];
-        if (((e >> 33) & 0x7FFFull) != t.gen) { t.tab[h] = key | ((uint64_t)t.gen << 33); return h; }
-        if ((e & 0x1FFFFFFFFull) == key) return h;
+        if (e == 0) { t.tab[h] = key; t.used++; return h; }
+        if ((e & LDBG_VT_KEY_MASK) == key) return h;
         h = (h + 1) & t.mask;
+        e = t.tab[h];
     }
+}
+LDBG_HOSTDEV uint32_t vt_locate(VisitedTable& t, int64_t idx, bool flip) {
+    const uint64_t key = vt_key(idx, flip);
+    const uint32_t h = vt_hash(key) & t.mask;
+    return vt_locate_from(t, key, h, t.tab[h]);
 }
 LDBG_HOSTDEV int vt_count_e(uint64_t e) { return (int)((e >> 48) & 0x7FFFull); }
 LDBG_HOSTDEV bool vt_seen_e(uint64_t e) { return (e >> 63) != 0; }
@@ -150,6 +199,12 @@ template <int W>
 LDBG_HOSTDEV void node_locate(VisitedTable& t, Node<W>& n) { if (n.idx >= 0) n.vslot = vt_locate(t, n.idx, n.flip != 0); }
 template <int W>
 LDBG_HOSTDEV int node_count(const VisitedTable& t, const Node<W>& n) { return n.idx >= 0 ? vt_count_e(t.tab[n.vslot]) : 0; }
+// neighbour + its visited-table slot: the table probe is issued before the row is read so the two loads overlap
+template <int W>
+LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const Node<W>& p, bool fwd, unsigned base, Node<W>& n) {
+    node_child<W>(e, p, fwd, base, n);
+    node_locate<W>(t, n);
+}
 
 // ---- per-walk LinkStore (J/utils/traversal/LinkStore.java), elements kept in insertion order
 struct LsElem {
@@ -278,8 +333,7 @@ LDBG_HOSTDEV void cursor_seek(const EngineView& e, Cursor<W>& cu, LinkStoreDev& 
     uint32_t m = fwd ? v.next_mask : v.prev_mask;
     cu.has = popc4(m) == 1;
     if (cu.has) {
-        node_find<W>(e, node_neighbour<W>(v, e.g.k, fwd, lowbit4(m)), cu.nxt);
-        node_locate<W>(vt, cu.nxt);
+        node_child_located<W>(e, vt, v, fwd, lowbit4(m), cu.nxt);
     }
 }
 // next()/previous() (TraversalEngine.java:241-319); requires cu.has.  Returns the vertex stepped onto.
@@ -298,9 +352,8 @@ LDBG_HOSTDEV Node<W> cursor_step(const EngineView& e, Cursor<W>& cu, LinkStoreDe
     const int pc = popc4(m);
     if (pc == 1) {
         Node<W> x;
-        node_find<W>(e, node_neighbour<W>(t, e.g.k, fwd, lowbit4(m)), x);
-        uint64_t ex = 0;
-        if (x.idx >= 0) { node_locate<W>(vt, x); ex = vt.tab[x.vslot]; }
+        node_child_located<W>(e, vt, t, fwd, lowbit4(m), x);
+        uint64_t ex = x.idx >= 0 ? vt.tab[x.vslot] : 0ull;
         if (!vt_seen_e(ex) || s.n > 0) {                // :262
             cu.nxt = x;
             has = true;
@@ -310,10 +363,10 @@ LDBG_HOSTDEV Node<W> cursor_step(const EngineView& e, Cursor<W>& cu, LinkStoreDe
         unsigned ch;
         if (ls_next_choice(e.links, s, &ch)) {          // getAdjacentKmer :518-546
             Kmer<W> cand = fwd ? kmer_next<W>(t.sk, e.g.k, ch) : kmer_prev<W>(t.sk, e.g.k, ch);
-            bool member = false;
+            int mb = -1;
             for (unsigned b = 0; b < 4; b++)
-                if ((m >> b) & 1u) member |= kmer_eq<W>(node_neighbour<W>(t, e.g.k, fwd, b), cand);
-            if (member) { node_find<W>(e, cand, cu.nxt); node_locate<W>(vt, cu.nxt); has = true; }
+                if (((m >> b) & 1u) && kmer_eq<W>(node_neighbour<W>(t, e.g.k, fwd, b), cand)) mb = (int)b;
+            if (mb >= 0) { node_child_located<W>(e, vt, t, fwd, (unsigned)mb, cu.nxt); has = true; }
         }
         ls_increment_ages(s);                           // :271
     }

@@ -43,14 +43,14 @@ public:
 
 private:
     // per-slot scratch kept across batches: visited tables, link stores, table generations
-    void* d_vtabs_ = nullptr; void* d_ls_ = nullptr; void* d_slot_gen_ = nullptr;
+    void* d_vpool_ = nullptr; void* d_ls_ = nullptr;
     void* d_pool_ = nullptr; void* d_block_table_ = nullptr;
     int64_t n_slots_ = 0, bt_strands_ = 0;
-    uint64_t n_blocks_ = 0;
-    uint32_t vcap_ = 0, ecap_ = 0;
+    uint64_t n_blocks_ = 0, vpool_entries_ = 0, vpool_dirty_ = 0;
+    uint32_t ecap_ = 0;
     int max_blocks_ = 0;
     std::unique_ptr<MergedLinks> merged_;
-    void ensure_scratch(int64_t n_strands, uint32_t vcap, uint32_t ecap, int max_blocks);
+    void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks);
     void release_scratch();
     bool run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);
 };

@@ -99,6 +99,37 @@ LDBG_KERNEL void k_prefix_index(GraphView g, uint32_t* pstart) {
     }
 }
 
+// neighbour index: for every record and every edge bit any colour carries, the record of that neighbour
+// (memoised findRecord of canon[1:]+b and b+canon[:-1]); entry = (index + 1) | (neighbour flipped << 31)
+template <int W>
+LDBG_KERNEL void k_build_nbr(GraphView g, uint8_t* probe) {
+    for (int64_t i = global_tid(); i < g.N; i += global_nthreads()) {
+        uint8_t* row = probe + (size_t)i * (size_t)g.stride;
+        Kmer<W> c = graph_key<W>(g, i);
+        uint32_t lo = 0, hi = 0;
+        for (int col = 0; col < g.C; col++) { uint32_t e = row[g.edges_off + col]; lo |= e & 0xf; hi |= e >> 4; }
+        uint32_t* nbr = (uint32_t*)(row + g.nbr_off);
+        for (unsigned b = 0; b < 4; b++) {
+            uint32_t ent = 0;
+            if ((lo >> b) & 1u) {                       // out-edge base b  (CortexRecord.java:252-275)
+                bool f;
+                Kmer<W> x = kmer_canonical<W>(kmer_next<W>(c, g.k, b), g.k, &f);
+                int64_t idx = graph_find_canonical<W>(g, x);
+                if (idx >= 0) ent = (uint32_t)(idx + 1) | (f ? 0x80000000u : 0u);
+            }
+            nbr[b] = ent;
+            ent = 0;
+            if ((hi >> (3 - b)) & 1u) {                 // in-edge base b <-> bit 3-b  (:214-238)
+                bool f;
+                Kmer<W> x = kmer_canonical<W>(kmer_prev<W>(c, g.k, b), g.k, &f);
+                int64_t idx = graph_find_canonical<W>(g, x);
+                if (idx >= 0) ent = (uint32_t)(idx + 1) | (f ? 0x80000000u : 0u);
+            }
+            nbr[4 + b] = ent;
+        }
+    }
+}
+
 // Iterator<CortexRecord> / getRecord in bulk: SoA -> caller arrays (n×W, n×C, n×C)
 LDBG_KERNEL void k_records(GraphView g, int64_t first, int64_t n, uint64_t* words, uint32_t* cov, uint8_t* edges) {
     for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
@@ -183,7 +214,9 @@ void Graph::upload(const uint8_t* recs) {
     view.edges_off = 8 * W;
     view.flags_off = 8 * W + C;
     view.cov_off = 8 * W + ((C + 1 + 3) / 4) * 4;
-    view.stride = ((view.cov_off + 4 * C + 15) / 16) * 16;
+    view.nbr_off = view.cov_off + 4 * C;
+    view.stride = ((view.nbr_off + 32 + 15) / 16) * 16;
+    view.nbr_on = N < (1LL << 31) ? 1 : 0;
     // radix index width: ~1-2 records per block for uniform k-mers, capped so the table stays cache-sized
     int p = 1;
     while (p < hdr.k && p < 13 && (1LL << (2 * (p + 1))) <= std::max<int64_t>(N, 1)) p++;
@@ -251,6 +284,14 @@ void Graph::upload(const uint8_t* recs) {
         case 2: LDBG_LAUNCH(k_prefix_index<2>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
         case 3: LDBG_LAUNCH(k_prefix_index<3>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
         default: LDBG_LAUNCH(k_prefix_index<4>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
+    }
+    if (view.nbr_on) {
+        switch (W) {
+            case 1: LDBG_LAUNCH(k_build_nbr<1>, grid_for(N, 256, 256 * 16), 256, stream, view, (uint8_t*)d_probe_); break;
+            case 2: LDBG_LAUNCH(k_build_nbr<2>, grid_for(N, 256, 256 * 16), 256, stream, view, (uint8_t*)d_probe_); break;
+            case 3: LDBG_LAUNCH(k_build_nbr<3>, grid_for(N, 256, 256 * 16), 256, stream, view, (uint8_t*)d_probe_); break;
+            default: LDBG_LAUNCH(k_build_nbr<4>, grid_for(N, 256, 256 * 16), 256, stream, view, (uint8_t*)d_probe_); break;
+        }
     }
     rt::stream_sync(stream);
 }

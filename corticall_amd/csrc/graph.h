@@ -8,6 +8,11 @@
 //                      -- random access: one 16/32-byte sector yields key + edges (+ coverage); bit s of the
 //                      link-flags byte says "link set s (ldbg_links_open order) has a record for this k-mer",
 //                      so a walk only searches a link table where there is something to find
+//                      ... | 8×u32 neighbour index: record (+1, bit 31 = its flip) of the 4 successors and the
+//                      4 predecessors of the canonical k-mer, filled at load time for every edge any colour
+//                      has.  A walk step then needs ONE row read (key, edges, link flags, coverage and the
+//                      pointers to all neighbours share a 64-byte line for k<=64, C<=3); arbitrary findRecord
+//                      queries still go through the radix index + binary search below.
 //   pstart[4^p + 1] u32  radix index on the first p bases: records with that prefix are
 //                      [pstart[x], pstart[x+1]) -- replaces the top ~2p levels of the reference's
 //                      binary search (CortexGraph.java:282-313) with one cached load; the remaining
@@ -29,7 +34,8 @@ struct GraphView {
     const uint32_t* cov;
     const uint8_t* edges;
     const uint8_t* probe;
-    int stride, edges_off, flags_off, cov_off;
+    int stride, edges_off, flags_off, cov_off, nbr_off;
+    int nbr_on;      // neighbour index built (N < 2^31)
     const uint32_t* pstart;
     int java_tiny;   // N <= 2: findRecord's loop never runs -> every lookup misses
 };
@@ -56,6 +62,9 @@ LDBG_HOSTDEV int64_t graph_find_canonical(const GraphView& g, const Kmer<W>& q) 
 LDBG_HOSTDEV const uint8_t* graph_row(const GraphView& g, int64_t idx) { return g.probe + (size_t)idx * (size_t)g.stride; }
 LDBG_HOSTDEV uint8_t graph_edges(const GraphView& g, int64_t idx, int c) { return graph_row(g, idx)[g.edges_off + c]; }
 LDBG_HOSTDEV uint8_t graph_link_flags(const GraphView& g, int64_t idx) { return graph_row(g, idx)[g.flags_off]; }
+LDBG_HOSTDEV uint32_t graph_nbr(const GraphView& g, int64_t idx, int j) {
+    return ((const uint32_t*)(graph_row(g, idx) + g.nbr_off))[j];
+}
 LDBG_HOSTDEV uint32_t graph_cov(const GraphView& g, int64_t idx, int c) {
     return ((const uint32_t*)(graph_row(g, idx) + g.cov_off))[c];
 }

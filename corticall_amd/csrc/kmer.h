@@ -127,6 +127,41 @@ LDBG_HD uint32_t kmer_java_hash(const Kmer<W>& a, int k) {
     return h;
 }
 
+// The two Java hashes of a k-mer and of its reverse complement, modulo 32, without walking the bases:
+// Arrays.hashCode(bytes) = 31^k + sum c_i 31^(k-1-i), and 31 == -1 (mod 32), so the hash mod 32 is an
+// alternating sum of the character codes by distance from the end.  Used as a 31/32 quick reject before
+// the full kmer_java_hash comparison of quirk Q6.
+template <int W>
+LDBG_HD void kmer_java_hash_mod32(const Kmer<W>& a, int k, uint32_t* h_self, uint32_t* h_rc) {
+    // n[v][par]: occurrences of base v at even / odd distance from the END of the k-mer
+    int n[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const int fields = (i == 0) ? (k - 32 * (W - 1)) : 32;          // valid 2-bit fields in this word
+        const uint64_t valid = fields >= 32 ? 0x5555555555555555ULL : ((1ULL << (2 * fields)) - 1ULL) & 0x5555555555555555ULL;
+        const uint64_t x = a.w[i];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const uint64_t pat = (uint64_t)v * 0x5555555555555555ULL;
+            const uint64_t t = x ^ pat;
+            const uint64_t z = ~(t | (t >> 1)) & valid;                  // 1 at the low bit of every field equal to v
+            n[v][0] += __builtin_popcountll(z & 0x1111111111111111ULL); // even distance: fields 0,2,4,...
+            n[v][1] += __builtin_popcountll(z & 0x4444444444444444ULL);
+        }
+    }
+    const int code[4] = {65, 67, 71, 84};
+    const int sign_k = (k & 1) ? -1 : 1;
+    int hs = sign_k, hr = sign_k;
+    const int q = (k - 1) & 1;      // a base at distance d from the end sits at distance k-1-d in the reverse complement
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        hs += code[v] * (n[v][0] - n[v][1]);
+        hr += code[3 - v] * (n[v][q] - n[v][1 - q]);
+    }
+    *h_self = (uint32_t)hs & 31u;
+    *h_rc = (uint32_t)hr & 31u;
+}
+
 // top 2p bits (first p bases) as an integer, p <= 16, p <= k
 template <int W>
 LDBG_HD uint32_t kmer_prefix(const Kmer<W>& a, int k, int p) {

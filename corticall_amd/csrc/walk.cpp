@@ -21,21 +21,23 @@ struct WalkArgs {
     int64_t n_slots;
     int run_rev, run_fwd;
     unsigned long long* next_strand;
-    uint64_t* pool;            // [n_blocks][LDBG_PATH_BLOCK]
+    uint64_t* pool;            // path blocks [n_blocks][LDBG_PATH_BLOCK]
     unsigned long long* next_block;
     uint64_t n_blocks;
     uint32_t* block_table;     // [n_strands][max_blocks]
     int max_blocks;
+    uint64_t* vpool;           // zeroed visited-table pool (entries)
+    unsigned long long* vnext;
+    uint64_t vpool_entries;
+    uint32_t vcap_max;         // largest table a strand may need
     uint32_t* strand_n;        // vertices in the strand's branch graph (0 = empty graph)
     uint32_t* status;
     uint32_t* iters;
     uint64_t* term;            // [n_strands][W]
-    uint64_t* vtabs;           // [n_slots][vcap]
-    uint32_t vcap;
     LsElem* ls;                // [n_slots][ecap]
     uint32_t ecap;
-    uint32_t* slot_gen;
 };
+#define LDBG_VT_INITIAL 4096u
 
 template <int W>
 LDBG_DEV uint64_t pack_vertex(const Node<W>& v, int k, bool fwd) {
@@ -62,113 +64,160 @@ LDBG_DEV bool path_append(const WalkArgs& a, int64_t s, PathWriter& pw, uint64_t
     return true;
 }
 
-// private dfs(cv, goForward, 0, 0, {}, sinks) for ContigStopper (TraversalEngine.java:356-482)
+// carve a zeroed table of `cap` entries out of the pool
+LDBG_DEV bool vt_alloc(const WalkArgs& a, VisitedTable& vt, uint32_t cap) {
+    const uint64_t o = (uint64_t)atomic_add_u64(a.vnext, (unsigned long long)cap);
+    if (o + cap > a.vpool_entries) return false;
+    vt.tab = a.vpool + o;
+    vt.mask = cap - 1;
+    vt.used = 0;
+    return true;
+}
+
+// one strand = private dfs(cv, goForward, 0, 0, {}, sinks) for ContigStopper (TraversalEngine.java:356-482),
+// advanced one loop iteration per call so that the lanes of a wave stay busy with different strands
 template <int W>
-LDBG_DEV void run_strand(const WalkArgs& a, int64_t s, VisitedTable& vt, LinkStoreDev& ls) {
+struct StrandState {
+    int64_t s;
+    Node<W> cv;
+    Cursor<W> cu;
+    PathWriter pw;
+    VisitedTable vt;
+    uint32_t gV, iters, status;
+    bool fwd, branch_null;
+};
+
+template <int W>
+LDBG_DEV void strand_finish(const WalkArgs& a, StrandState<W>& st) {
+    a.strand_n[st.s] = (st.branch_null || st.status != ST_OK) ? 0u : st.pw.n;
+    a.status[st.s] = st.status != ST_OK ? st.status : (st.branch_null ? (uint32_t)ST_BRANCH_NULL : (uint32_t)ST_OK);
+    a.iters[st.s] = st.iters;
+}
+
+// returns false when the strand ended at once
+template <int W>
+LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState<W>& st, LinkStoreDev& ls, int64_t s) {
+    const EngineView& e = a.e;
+    st.s = s;
+    st.fwd = (s & 1) != 0;
+    st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false;
+    st.pw.cur = nullptr; st.pw.n = 0;
+    st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true;
+    ls_clear(ls);
+    if (!vt_alloc(a, st.vt, LDBG_VT_INITIAL < a.vcap_max ? LDBG_VT_INITIAL : a.vcap_max)) { st.status = ST_POOL_FULL; return false; }
+    const uint64_t* sw = a.seeds + (s >> 1) * W;
+    Kmer<W> sk;
+#pragma unroll
+    for (int i = 0; i < W; i++) sk.w[i] = sw[i];
+    if (sw[0] != ~0ull) { node_find<W>(e, sk, st.cv); node_locate<W>(st.vt, st.cv); }
+    else node_null<W>(e, sk, st.cv);   // not a k-mer: findRecord misses (Q4)
+    if (st.cv.npe) { st.status = ST_NULLPTR; return false; }
+    if (e.cursor_on) cursor_seek<W>(e, st.cu, ls, st.vt, st.cv, st.fwd);   // :363-365
+    return true;
+}
+
+// regrow the visited table x4 (entries rehashed) and re-locate the vertices whose slots are carried
+template <int W>
+LDBG_DEV bool strand_grow_table(const WalkArgs& a, StrandState<W>& st) {
+    VisitedTable old = st.vt;
+    uint64_t cap = ((uint64_t)old.mask + 1) * 4;
+    if (cap > a.vcap_max) cap = a.vcap_max;
+    if (cap <= (uint64_t)old.mask + 1) return true;      // already at the largest size a strand can need
+    if (!vt_alloc(a, st.vt, (uint32_t)cap)) return false;
+    for (uint32_t i = 0; i <= old.mask; i++) {
+        const uint64_t e = old.tab[i];
+        if (e == 0) continue;
+        const uint64_t key = e & LDBG_VT_KEY_MASK;
+        uint32_t h = vt_hash(key) & st.vt.mask;
+        while (st.vt.tab[h] != 0) h = (h + 1) & st.vt.mask;
+        st.vt.tab[h] = e;
+        st.vt.used++;
+    }
+    node_locate<W>(st.vt, st.cv);
+    if (a.e.cursor_on) { node_locate<W>(st.vt, st.cu.cur); if (st.cu.has) node_locate<W>(st.vt, st.cu.nxt); }
+    return true;
+}
+
+// one iteration of the do-loop at TraversalEngine.java:373-481; returns true when the branch has ended
+template <int W>
+LDBG_DEV bool strand_step(const WalkArgs& a, StrandState<W>& st, LinkStoreDev& ls) {
     const EngineView& e = a.e;
     const int k = e.g.k;
-    const bool fwd = (s & 1) != 0;
-    uint32_t status = ST_OK, iters = 0;
-    bool branch_null = false;
-    PathWriter pw;
-    pw.cur = nullptr; pw.n = 0;
-
-    Node<W> cv;
-    {
-        const uint64_t* sw = a.seeds + (s >> 1) * W;
-        Kmer<W> sk;
-#pragma unroll
-        for (int i = 0; i < W; i++) sk.w[i] = sw[i];
-        if (sw[0] != ~0ull) { node_find<W>(e, sk, cv); node_locate<W>(vt, cv); }
-        else node_null<W>(e, sk, cv);   // not a k-mer: findRecord misses (Q4)
+    const bool fwd = st.fwd;
+    if ((st.vt.used + 8) * 2 > st.vt.mask + 1 && st.vt.mask + 1 < a.vcap_max) {
+        if (!strand_grow_table<W>(a, st)) { st.status = ST_POOL_FULL; return true; }
     }
-    Cursor<W> cu;
-    cu.has = false; cu.status = ST_OK;
-    const bool links_on = e.cursor_on != 0;
-    ls_clear(ls);
-    if (cv.npe) status = ST_NULLPTR;
-    else if (links_on) cursor_seek<W>(e, cu, ls, vt, cv, fwd);   // :363-365
-
-    uint32_t gV = 0;
-    while (status == ST_OK) {
-        iters++;
-        const uint32_t m = fwd ? cv.next_mask : cv.prev_mask;
-        int adj = 0;
-        Node<W> av = cv;
-        if (links_on && cu.has) {                       // :379-407
-            av = cursor_step<W>(e, cu, ls, vt, fwd);
-            if (cu.status != ST_OK) { status = cu.status; break; }
-            const int cnt = node_count<W>(vt, av);      // first unused copyIndex
-            av.copy = fwd ? cnt : -cnt;
-            adj = 1;
-        } else {
-            for (unsigned b = 0; b < 4; b++) {
-                if (!((m >> b) & 1u)) continue;
-                Node<W> x;
-                node_find<W>(e, node_neighbour<W>(cv, k, fwd, b), x);
-                node_locate<W>(vt, x);
-                if (node_count<W>(vt, x) > 0) continue;          // avs.removeAll(seen) :416-422
-                adj++;
-                av = x;
-            }
+    st.iters++;
+    Node<W>& cv = st.cv;
+    const uint32_t m = fwd ? cv.next_mask : cv.prev_mask;
+    int adj = 0;
+    Node<W> av = cv;
+    if (e.cursor_on && st.cu.has) {                     // :379-407
+        av = cursor_step<W>(e, st.cu, ls, st.vt, fwd);
+        if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
+        const int cnt = node_count<W>(st.vt, av);       // first unused copyIndex
+        av.copy = fwd ? cnt : -cnt;
+        adj = 1;
+    } else {
+        for (unsigned b = 0; b < 4; b++) {
+            if (!((m >> b) & 1u)) continue;
+            Node<W> x;
+            node_child_located<W>(e, st.vt, cv, fwd, b, x);
+            if (node_count<W>(st.vt, x) > 0) continue;              // avs.removeAll(seen) :416-422
+            adj++;
+            av = x;
         }
-        const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
-        uint64_t ecv = cv.idx >= 0 ? vt.tab[cv.vslot] : 0ull;
-        const bool previously = acopy < vt_count_e(ecv);                 // :424
-        if (!previously && cv.idx >= 0) {
-            if (acopy + 1 > 32767) { status = ST_COPY_OVERFLOW; break; }
-            vt.tab[cv.vslot] = vt_with_count(ecv, acopy + 1);            // visited.add(cv) :425
-        }
-        const bool reached = gV > (uint32_t)e.max_len;                   // :428
-        if (previously) { branch_null = true; break; }                   // :470-478, traversalSucceeded() still false
-        if (adj != 1 || reached) break;                                  // ContigStopper succeeded -> return g
-        if (gV == 0) {                                                   // connectVertex :494-516
-            if (!path_append(a, s, pw, pack_vertex<W>(cv, k, fwd))) { status = ST_POOL_FULL; break; }
-            gV = 1;
-        }
-        if (!path_append(a, s, pw, pack_vertex<W>(av, k, fwd))) { status = ST_POOL_FULL; break; }
-        gV++;
-        if (av.idx < 0) {
-            uint64_t* tk = a.term + s * W;
-#pragma unroll
-            for (int i = 0; i < W; i++) tk[i] = av.sk.w[i];
-        }
-        cv = av;
-        if (cv.npe) status = ST_NULLPTR;
     }
-    a.strand_n[s] = (branch_null || status != ST_OK) ? 0u : pw.n;
-    a.status[s] = status != ST_OK ? status : (branch_null ? (uint32_t)ST_BRANCH_NULL : (uint32_t)ST_OK);
-    a.iters[s] = iters;
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    const uint64_t ecv = cv.idx >= 0 ? st.vt.tab[cv.vslot] : 0ull;
+    const bool previously = acopy < vt_count_e(ecv);                    // :424
+    if (!previously && cv.idx >= 0) {
+        if (acopy + 1 > 32767) { st.status = ST_COPY_OVERFLOW; return true; }
+        st.vt.tab[cv.vslot] = vt_with_count(ecv, acopy + 1);            // visited.add(cv) :425
+    }
+    const bool reached = st.gV > (uint32_t)e.max_len;                   // :428
+    if (previously) { st.branch_null = true; return true; }             // :470-478, traversalSucceeded() still false
+    if (adj != 1 || reached) return true;                               // ContigStopper succeeded -> return g
+    if (st.gV == 0) {                                                   // connectVertex :494-516
+        if (!path_append(a, st.s, st.pw, pack_vertex<W>(cv, k, fwd))) { st.status = ST_POOL_FULL; return true; }
+        st.gV = 1;
+    }
+    if (!path_append(a, st.s, st.pw, pack_vertex<W>(av, k, fwd))) { st.status = ST_POOL_FULL; return true; }
+    st.gV++;
+    if (av.idx < 0) {
+        uint64_t* tk = a.term + st.s * W;
+#pragma unroll
+        for (int i = 0; i < W; i++) tk[i] = av.sk.w[i];
+    }
+    cv = av;
+    if (cv.npe) { st.status = ST_NULLPTR; return true; }
+    return false;
 }
 
 template <int W>
 LDBG_KERNEL void k_walk(WalkArgs a) {
     const int64_t slot = global_tid();
     if (slot >= a.n_slots) return;
-    VisitedTable vt;
-    vt.tab = a.vtabs + (size_t)slot * a.vcap;
-    vt.mask = a.vcap - 1;
-    vt.gen = a.slot_gen[slot];
     LinkStoreDev ls;
     ls.el = a.ls + (size_t)slot * a.ecap;
     ls.cap = a.ecap;
     ls_clear(ls);
+    StrandState<W> st;
+    bool active = false;
     while (true) {
-        const int64_t s = (int64_t)atomic_add_u64(a.next_strand, 1ull);
-        if (s >= a.n_strands) break;
-        const bool fwd = (s & 1) != 0;
-        if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
-            a.strand_n[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0;
-            continue;
+        if (!active) {
+            const int64_t s = (int64_t)atomic_add_u64(a.next_strand, 1ull);
+            if (s >= a.n_strands) break;
+            const bool fwd = (s & 1) != 0;
+            if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
+                a.strand_n[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0;
+                continue;
+            }
+            active = strand_begin<W>(a, st, ls, s);
+            if (!active) { strand_finish<W>(a, st); continue; }
         }
-        vt.gen++;
-        if (vt.gen > 32767u) {
-            for (uint32_t i = 0; i <= vt.mask; i++) vt.tab[i] = 0;
-            vt.gen = 1;
-        }
-        run_strand<W>(a, s, vt, ls);
+        if (strand_step<W>(a, st, ls)) { strand_finish<W>(a, st); active = false; }
     }
-    a.slot_gen[slot] = vt.gen;
 }
 
 // ---- result assembly -------------------------------------------------------------------------
@@ -321,9 +370,9 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
 Engine::~Engine() { clear_batch(); release_scratch(); }
 
 void Engine::release_scratch() {
-    rt::dfree(d_vtabs_); rt::dfree(d_ls_); rt::dfree(d_slot_gen_); rt::dfree(d_pool_); rt::dfree(d_block_table_);
-    d_vtabs_ = d_ls_ = d_slot_gen_ = d_pool_ = d_block_table_ = nullptr;
-    n_slots_ = 0; n_blocks_ = 0; bt_strands_ = 0;
+    rt::dfree(d_vpool_); rt::dfree(d_ls_); rt::dfree(d_pool_); rt::dfree(d_block_table_);
+    d_vpool_ = d_ls_ = d_pool_ = d_block_table_ = nullptr;
+    n_slots_ = 0; n_blocks_ = 0; bt_strands_ = 0; vpool_entries_ = 0; vpool_dirty_ = 0;
 }
 
 void Engine::clear_batch() {
@@ -332,30 +381,27 @@ void Engine::clear_batch() {
     batch_n = batch_bytes = batch_traversed = 0;
 }
 
-// per-slot visited tables + link stores, the path block pool and the block table; kept across batches
-void Engine::ensure_scratch(int64_t ns, uint32_t vcap, uint32_t ecap, int max_blocks) {
+// per-slot link stores, the visited-table pool, the path block pool and the block table; kept across batches
+void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks) {
     rt::stream_t s = graph->stream;
-    const size_t per_slot = (size_t)vcap * 8 + (size_t)ecap * sizeof(LsElem) + 4;
-    if (!(d_vtabs_ && vcap_ == vcap && ecap_ == ecap && max_blocks_ == max_blocks && bt_strands_ >= ns)) {
-        release_scratch();
-        size_t free_b = 0, total_b = 0;
-        rt::mem_info(&free_b, &total_b);
-        // memory split: up to 45% of what is free for the slots, up to 35% for the path pool
-        int64_t slots = (int64_t)((size_t)(free_b * 0.45) / per_slot);
-        slots = std::max<int64_t>(64, std::min<int64_t>(slots, 1 << 17));
-        slots = std::min<int64_t>(slots, ((ns + 63) / 64) * 64);
-        uint64_t want_blocks = (uint64_t)ns * (uint64_t)max_blocks;
-        uint64_t fit_blocks = (uint64_t)(free_b * 0.35) / (LDBG_PATH_BLOCK * 8);
-        n_blocks_ = std::max<uint64_t>(2, std::min(want_blocks, fit_blocks));
-        d_vtabs_ = rt::dmalloc((size_t)slots * vcap * 8);
-        d_ls_ = rt::dmalloc((size_t)slots * ecap * sizeof(LsElem));
-        d_slot_gen_ = rt::dmalloc((size_t)slots * 4);
-        d_pool_ = rt::dmalloc((size_t)n_blocks_ * LDBG_PATH_BLOCK * 8);
-        d_block_table_ = rt::dmalloc((size_t)ns * max_blocks * 4);
-        rt::dmemset(d_vtabs_, 0, (size_t)slots * vcap * 8, s);
-        rt::dmemset(d_slot_gen_, 0, (size_t)slots * 4, s);
-        n_slots_ = slots; vcap_ = vcap; ecap_ = ecap; max_blocks_ = max_blocks; bt_strands_ = ns;
-    }
+    if (d_vpool_ && ecap_ == ecap && max_blocks_ == max_blocks && bt_strands_ >= ns) return;
+    release_scratch();
+    size_t free_b = 0, total_b = 0;
+    rt::mem_info(&free_b, &total_b);
+    const int64_t slots = ((ns + 63) / 64) * 64;           // every strand of the batch gets a lane
+    // memory split: 40% of what is free for the visited-table pool, 35% for the path pool (both capped by need)
+    const uint64_t vcap_max = next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 12));
+    uint64_t want_v = (uint64_t)ns * vcap_max * 4 / 3 + LDBG_VT_INITIAL;
+    vpool_entries_ = std::max<uint64_t>(LDBG_VT_INITIAL * 2, std::min<uint64_t>(want_v, (uint64_t)(free_b * 0.40) / 8));
+    uint64_t want_blocks = (uint64_t)ns * (uint64_t)max_blocks;
+    n_blocks_ = std::max<uint64_t>(2, std::min<uint64_t>(want_blocks, (uint64_t)(free_b * 0.35) / (LDBG_PATH_BLOCK * 8)));
+    d_vpool_ = rt::dmalloc((size_t)vpool_entries_ * 8);
+    d_ls_ = rt::dmalloc((size_t)slots * ecap * sizeof(LsElem));
+    d_pool_ = rt::dmalloc((size_t)n_blocks_ * LDBG_PATH_BLOCK * 8);
+    d_block_table_ = rt::dmalloc((size_t)ns * max_blocks * 4);
+    rt::dmemset(d_vpool_, 0, (size_t)vpool_entries_ * 8, s);
+    vpool_dirty_ = 0;
+    n_slots_ = slots; ecap_ = ecap; max_blocks_ = max_blocks; bt_strands_ = ns;
 }
 
 void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
@@ -400,10 +446,11 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     const int64_t ns = 2 * n;
     out.first = first; out.n = n;
 
-    // per-slot visited table sized for the longest possible branch at load <= 1/2
-    const uint32_t vcap = std::max<uint32_t>(64u, next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 4)));
+    // a strand's visited table never needs more than this (longest possible branch at load <= 1/2)
+    const uint32_t vcap_max = std::max<uint32_t>(64u, next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 12)));
     const int max_blocks = (int)(((int64_t)cfg.max_branch_length + 2 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK);
-    ensure_scratch(ns, vcap, link_store_capacity, max_blocks);
+    ensure_scratch(ns, link_store_capacity, max_blocks);
+    if (vpool_dirty_ > 0) rt::dmemset(d_vpool_, 0, (size_t)std::min<uint64_t>(vpool_dirty_, vpool_entries_) * 8, s);   // only what the last launch used
 
     out.d_seed_words = rt::dmalloc((size_t)n * W * 8);
     rt::h2d(out.d_seed_words, &seed_words[first * W], (size_t)n * W * 8, s);
@@ -411,8 +458,8 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     uint32_t* d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint32_t* d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint32_t* d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    unsigned long long* d_ctr = (unsigned long long*)rt::dmalloc(16);
-    rt::dmemset(d_ctr, 0, 16, s);
+    unsigned long long* d_ctr = (unsigned long long*)rt::dmalloc(32);
+    rt::dmemset(d_ctr, 0, 32, s);
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
     auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); };
 
@@ -429,9 +476,8 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.block_table = (uint32_t*)d_block_table_; a.max_blocks = max_blocks;
     a.strand_n = d_strand_n; a.status = d_status; a.iters = d_iters;
     a.term = (uint64_t*)out.d_term;
-    a.vtabs = (uint64_t*)d_vtabs_; a.vcap = vcap_;
+    a.vpool = (uint64_t*)d_vpool_; a.vnext = d_ctr + 2; a.vpool_entries = vpool_entries_; a.vcap_max = vcap_max;
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
-    a.slot_gen = (uint32_t*)d_slot_gen_;
 
     rt::Event e0, e1;
     e0.record(s);
@@ -464,7 +510,10 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     rt::d2h(iters.data(), d_iters, (size_t)ns * 4, s);
     rt::d2h(out.walk_len.data(), d_walk_len, (size_t)n * 8, s);
     rt::d2h(out.seed_ok.data(), d_seed_ok, (size_t)n, s);
+    unsigned long long ctr[4] = {0, 0, 0, 0};
+    rt::d2h(ctr, d_ctr, 32, s);
     rt::stream_sync(s);
+    vpool_dirty_ = ctr[2];
     profile_add("walk", rt::Event::elapsed_ms(e0, e1));
 
     bool pool_full = false;

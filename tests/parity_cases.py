@@ -331,3 +331,17 @@ def case_dense_cycles(orc, lib, tmp, seed):
     compare_walks(cs, seeds, trav=[0], links=["a"], max_len=150)
     compare_walks(cs, seeds, trav=[1], links=["b"], recruit=[0], max_len=150)
     compare_walks(cs, seeds, trav=[0, 1], links=["a", "b"], max_len=12)
+
+
+def case_long_walks(orc, lib, tmp):
+    """walks far longer than the initial per-strand visited table (4096 entries) and than one path block (1024):
+    exercises table regrowth, block chaining, and the maxLength cut"""
+    rng = random.Random(99)
+    g1 = rand_seq(rng, 9000)
+    cs = Case(orc, tmp, lib, [("a", [g1])], 21, link_samples=["a"], reads={"a": [g1[:300]]}, name="long")
+    seeds = [g1[i:i + 21] for i in (0, 1500, 4400, 8979)] + [orc.revcomp(g1[3000:3021])]
+    exp = compare_walks(cs, seeds, trav=[0])
+    assert max(len(c) for c in exp) == 9000
+    compare_walks(cs, seeds, trav=[0], links=["a"])
+    compare_walks(cs, seeds, trav=[0], max_len=5000)
+    compare_walks(cs, seeds, trav=[0], links=["a"], max_len=3000)
