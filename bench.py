@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--use-seeds", type=int, default=0, help="experiment: walk only the first N seeds")
+    ap.add_argument("--no-links", action="store_true", help="experiment: walk without the link annotations")
     ap.add_argument("--no-strict", action="store_true", help="experiment: CanonicalKmer.isFlipped by comparison (not Java-exact, Q6)")
     args = ap.parse_args()
 
@@ -117,7 +118,10 @@ def main():
     g = CortexGraph(prefix + ".ctx", device=local_rank)
     links = CortexLinks(prefix + ".ctp.gz", g)
     eng = (TraversalEngineFactory().traversalColors(g.getColorForSampleName("child")).traversalDirection(BOTH)
-           .combinationOperator(OR).stoppingRule(ContigStopper).maxBranchLength(args.max_len).graph(g).links(links).strictJavaFlip(not args.no_strict).make())
+           .combinationOperator(OR).stoppingRule(ContigStopper).maxBranchLength(args.max_len).graph(g).strictJavaFlip(not args.no_strict))
+    if not args.no_links:
+        eng.links(links)
+    eng = eng.make()
     t_load = time.time() - t_load
 
     def sync():

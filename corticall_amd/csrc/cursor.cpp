@@ -8,11 +8,12 @@ namespace ldbg {
 
 template <int W>
 struct CursorStateDev {
-    Node<W> cur;
-    Node<W> nxt, prv;
+    Node cur;
+    Node nxt, prv;
     uint32_t has_next, has_prev, first, go_forward, status;
-    uint32_t ls_n, ls_java_cap, ls_nkeys, ls_next_seq;
-    uint32_t vt_used;
+    uint32_t ls_n, ls_java_cap, ls_nkeys, ls_next_seq, ls_age, ls_n_new;
+    uint32_t vt_used, nxt_words_valid;
+    uint64_t cur_words[W];     // k-mer of the cursor vertex (vertices without a record have no row to read it from)
     // outputs of the last step
     uint64_t out_words[W];
     int64_t out_rec;
@@ -24,12 +25,12 @@ LDBG_DEV void cs_reseek(const EngineView& e, CursorStateDev<W>& st, uint64_t* vt
     if (st.vt_used != 0) for (uint32_t i = 0; i < vcap; i++) vtab[i] = 0;    // seen = new HashSet<>()
     VisitedTable vt;
     vt.tab = vtab; vt.mask = vcap - 1; vt.used = 0;
-    node_locate<W>(vt, st.cur);
+    node_locate(vt, st.cur);
     st.has_next = popc4(st.cur.next_mask) == 1;
-    if (st.has_next) { node_child<W>(e, st.cur, true, lowbit4(st.cur.next_mask), st.nxt); node_locate<W>(vt, st.nxt); }
+    if (st.has_next) { node_child_located(e, vt, st.cur, true, lowbit4(st.cur.next_mask), st.nxt); st.nxt_words_valid = 0; }
     st.has_prev = popc4(st.cur.prev_mask) == 1;
-    if (st.has_prev) { node_child<W>(e, st.cur, false, lowbit4(st.cur.prev_mask), st.prv); node_locate<W>(vt, st.prv); }
-    st.ls_n = st.ls_java_cap = st.ls_nkeys = st.ls_next_seq = 0;
+    if (st.has_prev) { node_child_located(e, vt, st.cur, false, lowbit4(st.cur.prev_mask), st.prv); }
+    st.ls_n = st.ls_java_cap = st.ls_nkeys = st.ls_next_seq = st.ls_age = st.ls_n_new = 0;
     st.first = 1;
     st.vt_used = vt.used;
     st.status = st.cur.npe ? (uint32_t)ST_NULLPTR : (uint32_t)ST_OK;
@@ -42,7 +43,8 @@ LDBG_KERNEL void k_cursor_seek(EngineView e, CursorStateDev<W>* stp, const uint6
     Kmer<W> sk;
     for (int i = 0; i < W; i++) sk.w[i] = words[i];
     if (words[0] != ~0ull) node_find<W>(e, sk, st.cur);
-    else node_null<W>(e, sk, st.cur);
+    else node_null(e, st.cur);
+    for (int i = 0; i < W; i++) st.cur_words[i] = sk.w[i];
     cs_reseek<W>(e, st, vtab, vcap);
 }
 
@@ -62,22 +64,29 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
     if (vt.used * 2 > vcap) { st.status = ST_POOL_FULL; return; }   // more steps since seek() than the cursor's `seen` table holds
     LinkStoreDev ls;
     ls.el = els; ls.cap = ecap; ls.n = st.ls_n; ls.java_cap = st.ls_java_cap; ls.nkeys = st.ls_nkeys; ls.next_seq = st.ls_next_seq;
+    ls.age = st.ls_age; ls.n_new = st.ls_n_new;
     ls.overflow = false;
-    Cursor<W> cu;
+    Cursor cu;
     cu.cur = st.cur; cu.first = st.first != 0; cu.status = ST_OK;
     cu.has = fwd ? st.has_next != 0 : st.has_prev != 0;
     if (!cu.has) { st.status = ST_NULLPTR; return; }   // target vanished after the re-seek: NPE in the reference
     cu.nxt = fwd ? st.nxt : st.prv;
-    Node<W> old = st.cur;
-    Node<W> t = cursor_step<W>(e, cu, ls, vt, fwd);
+    Node old = st.cur;
+    // k-mer of the vertex stepped onto: from its row, or (no record) from the cursor k-mer and the edge base
+    Kmer<W> tk;
+    if (cu.nxt.idx >= 0) tk = node_kmer<W>(e, cu.nxt);
+    else if (old.idx >= 0) tk = child_kmer<W>(e, old, fwd, cu.nxt.base);
+    else { for (int i = 0; i < W; i++) tk.w[i] = st.cur_words[i]; }
+    Node t = cursor_step<W>(e, cu, ls, vt, fwd);
     st.first = 0;
     st.cur = cu.cur;
     if (fwd) { st.prv = old; st.has_prev = 1; st.nxt = cu.nxt; st.has_next = cu.has ? 1 : 0; }
     else { st.nxt = old; st.has_next = 1; st.prv = cu.nxt; st.has_prev = cu.has ? 1 : 0; }
     st.ls_n = ls.n; st.ls_java_cap = ls.java_cap; st.ls_nkeys = ls.nkeys; st.ls_next_seq = ls.next_seq;
+    st.ls_age = ls.age; st.ls_n_new = ls.n_new;
     st.status = cu.status;
     st.vt_used = vt.used;
-    for (int i = 0; i < W; i++) st.out_words[i] = t.sk.w[i];
+    for (int i = 0; i < W; i++) { st.out_words[i] = tk.w[i]; st.cur_words[i] = tk.w[i]; }
     st.out_rec = t.idx;
 }
 

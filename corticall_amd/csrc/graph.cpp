@@ -108,10 +108,21 @@ LDBG_KERNEL void k_build_nbr(GraphView g, uint8_t* probe) {
         Kmer<W> c = graph_key<W>(g, i);
         uint32_t lo = 0, hi = 0;
         for (int col = 0; col < g.C; col++) { uint32_t e = row[g.edges_off + col]; lo |= e & 0xf; hi |= e >> 4; }
+        {   // orientation quirks of this record, decided once here instead of on every traversal step
+            Kmer<W> rc = kmer_revcomp<W>(c, g.k);
+            uint8_t fl = row[g.flags_off] & LDBG_ROW_LINK_BITS;
+            if (kmer_eq<W>(rc, c)) fl |= LDBG_ROW_PALINDROME;
+            else {
+                uint32_t hs, hr;
+                kmer_java_hash_mod32<W>(c, g.k, &hs, &hr);
+                if (hs == hr && kmer_java_hash<W>(c, g.k) == kmer_java_hash<W>(rc, g.k)) fl |= LDBG_ROW_HASH_COLLISION;
+            }
+            row[g.flags_off] = fl;
+        }
         uint32_t* nbr = (uint32_t*)(row + g.nbr_off);
         for (unsigned b = 0; b < 4; b++) {
             uint32_t ent = 0;
-            if ((lo >> b) & 1u) {                       // out-edge base b  (CortexRecord.java:252-275)
+            if (g.nbr_on && ((lo >> b) & 1u)) {         // out-edge base b  (CortexRecord.java:252-275)
                 bool f;
                 Kmer<W> x = kmer_canonical<W>(kmer_next<W>(c, g.k, b), g.k, &f);
                 int64_t idx = graph_find_canonical<W>(g, x);
@@ -119,7 +130,7 @@ LDBG_KERNEL void k_build_nbr(GraphView g, uint8_t* probe) {
             }
             nbr[b] = ent;
             ent = 0;
-            if ((hi >> (3 - b)) & 1u) {                 // in-edge base b <-> bit 3-b  (:214-238)
+            if (g.nbr_on && ((hi >> (3 - b)) & 1u)) {   // in-edge base b <-> bit 3-b  (:214-238)
                 bool f;
                 Kmer<W> x = kmer_canonical<W>(kmer_prev<W>(c, g.k, b), g.k, &f);
                 int64_t idx = graph_find_canonical<W>(g, x);
@@ -285,7 +296,7 @@ void Graph::upload(const uint8_t* recs) {
         case 3: LDBG_LAUNCH(k_prefix_index<3>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
         default: LDBG_LAUNCH(k_prefix_index<4>, grid_for(N + 1), 256, stream, view, (uint32_t*)d_pstart_); break;
     }
-    if (view.nbr_on) {
+    {
         switch (W) {
             case 1: LDBG_LAUNCH(k_build_nbr<1>, grid_for(N, 256, 256 * 16), 256, stream, view, (uint8_t*)d_probe_); break;
             case 2: LDBG_LAUNCH(k_build_nbr<2>, grid_for(N, 256, 256 * 16), 256, stream, view, (uint8_t*)d_probe_); break;

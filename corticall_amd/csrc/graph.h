@@ -27,6 +27,11 @@
 
 namespace ldbg {
 
+// bits of the probe rows' flag byte
+#define LDBG_ROW_LINK_BITS 0x3Fu        // bit s: link set s has a record for this k-mer (6 sets per graph)
+#define LDBG_ROW_HASH_COLLISION 0x40u   // Arrays.hashCode(k-mer) == Arrays.hashCode(revcomp), k-mer != revcomp (quirk Q6)
+#define LDBG_ROW_PALINDROME 0x80u       // k-mer == its reverse complement (even k only)
+
 struct GraphView {
     int k, W, C, p;
     int64_t N;

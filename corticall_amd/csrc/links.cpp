@@ -254,7 +254,7 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
         record_is_canonical.push_back(w == kv.first ? 1 : 0);
     }
     // claim a flag bit in the graph's probe rows and set it on every record that has links here
-    if (g.next_link_slot >= 8) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than 8 link sets bound to one graph");
+    if (g.next_link_slot >= 6) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than 6 link sets bound to one graph");
     slot = g.next_link_slot++;
     const int64_t M = (int64_t)records.size();
     if (M > 0) {

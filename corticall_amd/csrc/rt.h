@@ -81,6 +81,17 @@ LDBG_DEV unsigned long long atomic_add_u64(unsigned long long* p, unsigned long 
 LDBG_DEV unsigned atomic_add_u32(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 LDBG_DEV unsigned atomic_min_u32(unsigned* p, unsigned v) { return atomicMin(p, v); }
 LDBG_DEV unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
+LDBG_DEV unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { return atomicCAS(p, cmp, v); }
+// wavefront primitives (64 lanes on gfx950); kernels that use them are launched with 64-thread blocks
+LDBG_DEV int wave_size() { return 64; }
+LDBG_DEV int wave_lane() { return (int)(threadIdx.x & 63u); }
+LDBG_DEV unsigned long long wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
+LDBG_DEV uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+LDBG_DEV uint64_t wave_bcast_u64(uint64_t v, int src) {
+    uint32_t lo = wave_bcast_u32((uint32_t)v, src), hi = wave_bcast_u32((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+LDBG_DEV void wave_fence() { __threadfence_block(); }
 }  // namespace ldbg
 
 #else  // ------------------------------------------------------------------ LDBG_HOSTSIM (tests only)
@@ -121,6 +132,14 @@ inline unsigned long long atomic_add_u64(unsigned long long* p, unsigned long lo
 inline unsigned atomic_add_u32(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
 inline unsigned atomic_min_u32(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
+inline unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { unsigned long long o = *p; if (o == cmp) *p = v; return o; }
+// a simulated "wave" is a single lane
+inline int wave_size() { return 1; }
+inline int wave_lane() { return 0; }
+inline unsigned long long wave_ballot(bool p) { return p ? 1ull : 0ull; }
+inline uint32_t wave_bcast_u32(uint32_t v, int) { return v; }
+inline uint64_t wave_bcast_u64(uint64_t v, int) { return v; }
+inline void wave_fence() {}
 }  // namespace ldbg
 
 // sequential "launch": every simulated thread runs to completion in turn.  Kernels must therefore

@@ -33,17 +33,14 @@ struct WalkArgs {
     uint32_t* strand_n;        // vertices in the strand's branch graph (0 = empty graph)
     uint32_t* status;
     uint32_t* iters;
+    uint8_t* quirk;            // [n_strands] the strand contains a Q6 vertex
     uint64_t* term;            // [n_strands][W]
     LsElem* ls;                // [n_slots][ecap]
     uint32_t ecap;
 };
 #define LDBG_VT_INITIAL 4096u
 
-template <int W>
-LDBG_DEV uint64_t pack_vertex(const Node<W>& v, int k, bool fwd) {
-    unsigned base = kmer_base<W>(v.sk, k, fwd ? k - 1 : 0);
-    return path_pack(v.idx, v.flip != 0, base, v.copy);
-}
+LDBG_DEV uint64_t pack_vertex(const Node& v) { return path_pack(v.idx, v.flip != 0, v.base, v.copy, v.flip && !v.fj); }
 
 struct PathWriter {
     uint64_t* cur;       // current block
@@ -76,31 +73,30 @@ LDBG_DEV bool vt_alloc(const WalkArgs& a, VisitedTable& vt, uint32_t cap) {
 
 // one strand = private dfs(cv, goForward, 0, 0, {}, sinks) for ContigStopper (TraversalEngine.java:356-482),
 // advanced one loop iteration per call so that the lanes of a wave stay busy with different strands
-template <int W>
 struct StrandState {
     int64_t s;
-    Node<W> cv;
-    Cursor<W> cu;
+    Node cv;
+    Cursor cu;
     PathWriter pw;
     VisitedTable vt;
     uint32_t gV, iters, status;
-    bool fwd, branch_null;
+    bool fwd, branch_null, quirk;
 };
 
-template <int W>
-LDBG_DEV void strand_finish(const WalkArgs& a, StrandState<W>& st) {
+LDBG_DEV void strand_finish(const WalkArgs& a, StrandState& st) {
     a.strand_n[st.s] = (st.branch_null || st.status != ST_OK) ? 0u : st.pw.n;
     a.status[st.s] = st.status != ST_OK ? st.status : (st.branch_null ? (uint32_t)ST_BRANCH_NULL : (uint32_t)ST_OK);
     a.iters[st.s] = st.iters;
+    a.quirk[st.s] = st.quirk ? 1 : 0;
 }
 
 // returns false when the strand ended at once
 template <int W>
-LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState<W>& st, LinkStoreDev& ls, int64_t s) {
+LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, int64_t s) {
     const EngineView& e = a.e;
     st.s = s;
     st.fwd = (s & 1) != 0;
-    st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false;
+    st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false; st.quirk = false;
     st.pw.cur = nullptr; st.pw.n = 0;
     st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true;
     ls_clear(ls);
@@ -109,61 +105,83 @@ LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState<W>& st, LinkStoreDev& 
     Kmer<W> sk;
 #pragma unroll
     for (int i = 0; i < W; i++) sk.w[i] = sw[i];
-    if (sw[0] != ~0ull) { node_find<W>(e, sk, st.cv); node_locate<W>(st.vt, st.cv); }
-    else node_null<W>(e, sk, st.cv);   // not a k-mer: findRecord misses (Q4)
+    if (sw[0] != ~0ull) { node_find<W>(e, sk, st.cv); node_locate(st.vt, st.cv); }
+    else node_null(e, st.cv);   // not a k-mer: findRecord misses (Q4)
     if (st.cv.npe) { st.status = ST_NULLPTR; return false; }
-    if (e.cursor_on) cursor_seek<W>(e, st.cu, ls, st.vt, st.cv, st.fwd);   // :363-365
+    if (e.cursor_on) cursor_seek(e, st.cu, ls, st.vt, st.cv, st.fwd);   // :363-365
     return true;
 }
 
-// regrow the visited table x4 (entries rehashed) and re-locate the vertices whose slots are carried
-template <int W>
-LDBG_DEV bool strand_grow_table(const WalkArgs& a, StrandState<W>& st) {
-    VisitedTable old = st.vt;
-    uint64_t cap = ((uint64_t)old.mask + 1) * 4;
-    if (cap > a.vcap_max) cap = a.vcap_max;
-    if (cap <= (uint64_t)old.mask + 1) return true;      // already at the largest size a strand can need
-    if (!vt_alloc(a, st.vt, (uint32_t)cap)) return false;
-    for (uint32_t i = 0; i <= old.mask; i++) {
-        const uint64_t e = old.tab[i];
-        if (e == 0) continue;
-        const uint64_t key = e & LDBG_VT_KEY_MASK;
-        uint32_t h = vt_hash(key) & st.vt.mask;
-        while (st.vt.tab[h] != 0) h = (h + 1) & st.vt.mask;
-        st.vt.tab[h] = e;
-        st.vt.used++;
+// Regrowing a strand's visited table is a wave-cooperative operation: a lane that rehashed its own table
+// alone would stall the other 63 lanes of its wavefront for as long as the table is big.  Every lane whose
+// table is half full raises its hand (ballot); for each of them in turn the whole wavefront moves that
+// lane's entries into a table 4x the size (CAS inserts), then the owner re-locates the vertices whose
+// slots it carries.
+LDBG_DEV void wave_grow_tables(const WalkArgs& a, StrandState& st, bool active) {
+    const uint32_t cap = st.vt.mask + 1;
+    const bool need = active && st.status == ST_OK && (st.vt.used + 8) * 2 > cap && cap < a.vcap_max;
+    unsigned long long ballot = wave_ballot(need);
+    const int lane = wave_lane();
+    while (ballot) {
+        const int L = __builtin_ctzll(ballot);
+        ballot &= ballot - 1;
+        uint64_t new_tab = 0;
+        uint32_t new_cap = 0;
+        if (lane == L) {
+            uint64_t c = (uint64_t)cap * 4;
+            if (c > a.vcap_max) c = a.vcap_max;
+            VisitedTable nt;
+            if (vt_alloc(a, nt, (uint32_t)c)) { new_tab = (uint64_t)(uintptr_t)nt.tab; new_cap = (uint32_t)c; }
+            else st.status = ST_POOL_FULL;
+        }
+        const uint64_t* old_tab = (const uint64_t*)(uintptr_t)wave_bcast_u64((uint64_t)(uintptr_t)st.vt.tab, L);
+        const uint32_t old_mask = wave_bcast_u32(st.vt.mask, L);
+        unsigned long long* nt_tab = (unsigned long long*)(uintptr_t)wave_bcast_u64(new_tab, L);
+        const uint32_t nt_mask = wave_bcast_u32(new_cap, L) - 1;
+        if (nt_tab) {
+            for (uint32_t i = (uint32_t)lane; i <= old_mask; i += (uint32_t)wave_size()) {
+                const uint64_t e = old_tab[i];
+                if (e == 0) continue;
+                uint32_t h = vt_hash(e & LDBG_VT_KEY_MASK) & nt_mask;
+                while (atomic_cas_u64(&nt_tab[h], 0ull, (unsigned long long)e) != 0ull) h = (h + 1) & nt_mask;
+            }
+            wave_fence();
+            if (lane == L) {
+                st.vt.tab = (uint64_t*)nt_tab;
+                st.vt.mask = nt_mask;       // `used` is unchanged: every entry moved
+                const uint32_t used = st.vt.used;
+                node_locate(st.vt, st.cv);
+                if (a.e.cursor_on) { node_locate(st.vt, st.cu.cur); if (st.cu.has) node_locate(st.vt, st.cu.nxt); }
+                st.vt.used = used;
+            }
+        }
     }
-    node_locate<W>(st.vt, st.cv);
-    if (a.e.cursor_on) { node_locate<W>(st.vt, st.cu.cur); if (st.cu.has) node_locate<W>(st.vt, st.cu.nxt); }
-    return true;
 }
 
 // one iteration of the do-loop at TraversalEngine.java:373-481; returns true when the branch has ended
 template <int W>
-LDBG_DEV bool strand_step(const WalkArgs& a, StrandState<W>& st, LinkStoreDev& ls) {
+LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) {
     const EngineView& e = a.e;
     const int k = e.g.k;
     const bool fwd = st.fwd;
-    if ((st.vt.used + 8) * 2 > st.vt.mask + 1 && st.vt.mask + 1 < a.vcap_max) {
-        if (!strand_grow_table<W>(a, st)) { st.status = ST_POOL_FULL; return true; }
-    }
+    if (st.status != ST_OK) return true;     // pool exhausted while regrowing the table
     st.iters++;
-    Node<W>& cv = st.cv;
+    Node& cv = st.cv;
     const uint32_t m = fwd ? cv.next_mask : cv.prev_mask;
     int adj = 0;
-    Node<W> av = cv;
+    Node av = cv;
     if (e.cursor_on && st.cu.has) {                     // :379-407
         av = cursor_step<W>(e, st.cu, ls, st.vt, fwd);
         if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
-        const int cnt = node_count<W>(st.vt, av);       // first unused copyIndex
+        const int cnt = node_count(st.vt, av);          // first unused copyIndex
         av.copy = fwd ? cnt : -cnt;
         adj = 1;
     } else {
         for (unsigned b = 0; b < 4; b++) {
             if (!((m >> b) & 1u)) continue;
-            Node<W> x;
-            node_child_located<W>(e, st.vt, cv, fwd, b, x);
-            if (node_count<W>(st.vt, x) > 0) continue;              // avs.removeAll(seen) :416-422
+            Node x;
+            node_child_located(e, st.vt, cv, fwd, b, x);
+            if (node_count(st.vt, x) > 0) continue;                 // avs.removeAll(seen) :416-422
             adj++;
             av = x;
         }
@@ -179,15 +197,17 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState<W>& st, LinkStoreDev& l
     if (previously) { st.branch_null = true; return true; }             // :470-478, traversalSucceeded() still false
     if (adj != 1 || reached) return true;                               // ContigStopper succeeded -> return g
     if (st.gV == 0) {                                                   // connectVertex :494-516
-        if (!path_append(a, st.s, st.pw, pack_vertex<W>(cv, k, fwd))) { st.status = ST_POOL_FULL; return true; }
+        if (!path_append(a, st.s, st.pw, pack_vertex(cv))) { st.status = ST_POOL_FULL; return true; }
         st.gV = 1;
     }
-    if (!path_append(a, st.s, st.pw, pack_vertex<W>(av, k, fwd))) { st.status = ST_POOL_FULL; return true; }
+    if (!path_append(a, st.s, st.pw, pack_vertex(av))) { st.status = ST_POOL_FULL; return true; }
     st.gV++;
-    if (av.idx < 0) {
-        uint64_t* tk = a.term + st.s * W;
+    st.quirk |= (cv.flip && !cv.fj) || (av.flip && !av.fj);
+    if (av.idx < 0) {   // a vertex without a record ends the branch; keep its k-mer for the result
+        const Kmer<W> tk = child_kmer<W>(e, cv, fwd, av.base);
+        uint64_t* out = a.term + st.s * W;
 #pragma unroll
-        for (int i = 0; i < W; i++) tk[i] = av.sk.w[i];
+        for (int i = 0; i < W; i++) out[i] = tk.w[i];
     }
     cv = av;
     if (cv.npe) { st.status = ST_NULLPTR; return true; }
@@ -202,21 +222,27 @@ LDBG_KERNEL void k_walk(WalkArgs a) {
     ls.el = a.ls + (size_t)slot * a.ecap;
     ls.cap = a.ecap;
     ls_clear(ls);
-    StrandState<W> st;
-    bool active = false;
-    while (true) {
-        if (!active) {
+    StrandState st;
+    st.vt.tab = nullptr; st.vt.mask = 0; st.vt.used = 0; st.status = ST_OK;
+    bool active = false, exhausted = false;
+    // all lanes of a wavefront stay in the loop until every one of them has run out of strands: the table
+    // regrowth below is a wave-wide operation
+    while (wave_ballot(active || !exhausted) != 0ull) {
+        if (!active && !exhausted) {
             const int64_t s = (int64_t)atomic_add_u64(a.next_strand, 1ull);
-            if (s >= a.n_strands) break;
-            const bool fwd = (s & 1) != 0;
-            if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
-                a.strand_n[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0;
-                continue;
+            if (s >= a.n_strands) exhausted = true;
+            else {
+                const bool fwd = (s & 1) != 0;
+                if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
+                    a.strand_n[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0; a.quirk[s] = 0;
+                } else {
+                    active = strand_begin<W>(a, st, ls, s);
+                    if (!active) strand_finish(a, st);
+                }
             }
-            active = strand_begin<W>(a, st, ls, s);
-            if (!active) { strand_finish<W>(a, st); continue; }
         }
-        if (strand_step<W>(a, st, ls)) { strand_finish<W>(a, st); active = false; }
+        wave_grow_tables(a, st, active);
+        if (active && strand_step<W>(a, st, ls)) { strand_finish(a, st); active = false; }
     }
 }
 
@@ -265,25 +291,60 @@ LDBG_KERNEL void k_compact_paths(const uint64_t* pool, const uint32_t* block_tab
 }
 
 // TraversalUtils.toContig (TraversalUtils.java:367-381) over walk = reverse strand (far end first), seed, forward strand
+struct ContigArgs {
+    GraphView g;
+    int64_t n;
+    const uint64_t* seeds;
+    const uint64_t* dense;
+    const int64_t* strand_off;
+    const int64_t* walk_len;
+    const int64_t* contig_off;
+    const uint8_t* quirk;
+    const uint64_t* term;
+    char* out;
+};
 template <int W>
-LDBG_KERNEL void k_contigs(int k, int64_t n, const uint64_t* seeds, const uint64_t* dense, const int64_t* strand_off,
-                           const int64_t* walk_len, const int64_t* contig_off, char* out) {
+LDBG_DEV Kmer<W> walk_vertex_kmer(const ContigArgs& a, int64_t i, int64_t v, int64_t ro, int64_t nr, int64_t fo) {
+    const int64_t nrev = nr > 0 ? nr - 1 : 0;
+    uint64_t e;
+    const uint64_t* term;
+    if (v < nrev) { e = a.dense[ro + (nr - 1 - v)]; term = a.term + (2 * i) * W; }
+    else if (v == nrev) { e = nr > 0 ? a.dense[ro] : a.dense[fo]; term = a.seeds + i * W; }
+    else { e = a.dense[fo + (v - nrev)]; term = a.term + (2 * i + 1) * W; }
+    Kmer<W> km;
+    const int64_t ri = path_idx(e);
+    if (ri >= 0) { km = graph_key<W>(a.g, ri); if (path_flip(e)) km = kmer_revcomp<W>(km, a.g.k); }
+    else { for (int w = 0; w < W; w++) km.w[w] = term[w]; }
+    return km;
+}
+template <int W>
+LDBG_KERNEL void k_contigs(ContigArgs a) {
+    const int k = a.g.k;
     const int64_t wave = global_tid() >> 6, lane = global_tid() & 63, nwaves = (global_nthreads() + 63) >> 6;
-    for (int64_t i = wave; i < n; i += nwaves) {
-        if (walk_len[i] == 0) continue;
-        const int64_t L = contig_off[i + 1] - contig_off[i];
-        const int64_t ro = strand_off[2 * i], nr = strand_off[2 * i + 1] - ro;
-        const int64_t fo = strand_off[2 * i + 1];
+    for (int64_t i = wave; i < a.n; i += nwaves) {
+        if (a.walk_len[i] == 0) continue;
+        const int64_t L = a.contig_off[i + 1] - a.contig_off[i];
+        const int64_t ro = a.strand_off[2 * i], nr = a.strand_off[2 * i + 1] - ro;
+        const int64_t fo = a.strand_off[2 * i + 1];
         const int64_t nrev = nr > 0 ? nr - 1 : 0;
+        char* o = a.out + a.contig_off[i];
+        if (a.quirk[2 * i] | a.quirk[2 * i + 1]) {
+            // a Q6 vertex breaks the k-1 overlaps: first k-mer, then the last base of every further vertex's k-mer
+            for (int64_t p = lane; p < L; p += 64) {
+                const int64_t v = p < k ? 0 : p - k + 1;
+                const Kmer<W> km = walk_vertex_kmer<W>(a, i, v, ro, nr, fo);
+                o[p] = "ACGT"[kmer_base<W>(km, k, p < k ? (int)p : k - 1)];
+            }
+            continue;
+        }
         Kmer<W> sk;
 #pragma unroll
-        for (int w = 0; w < W; w++) sk.w[w] = seeds[i * W + w];
-        char* o = out + contig_off[i];
+        for (int w = 0; w < W; w++) sk.w[w] = a.seeds[i * W + w];
         for (int64_t p = lane; p < L; p += 64) {
             unsigned b;
-            if (p < nrev) b = path_base(dense[ro + (nr - 1 - p)]);
+            if (p < nrev) b = path_base(a.dense[ro + (nr - 1 - p)]);
             else if (p < nrev + k) b = kmer_base<W>(sk, k, (int)(p - nrev));
-            else b = path_base(dense[fo + (p - nrev - k + 1)]);
+            else b = path_base(a.dense[fo + (p - nrev - k + 1)]);
             o[p] = "ACGT"[b];
         }
     }
@@ -458,10 +519,11 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     uint32_t* d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint32_t* d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint32_t* d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    uint8_t* d_quirk = (uint8_t*)rt::dmalloc((size_t)ns);
     unsigned long long* d_ctr = (unsigned long long*)rt::dmalloc(32);
     rt::dmemset(d_ctr, 0, 32, s);
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
-    auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); };
+    auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk); };
 
     WalkArgs a;
     a.e = view;
@@ -474,7 +536,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.next_block = d_ctr + 1;
     a.pool = (uint64_t*)d_pool_; a.n_blocks = n_blocks_;
     a.block_table = (uint32_t*)d_block_table_; a.max_blocks = max_blocks;
-    a.strand_n = d_strand_n; a.status = d_status; a.iters = d_iters;
+    a.strand_n = d_strand_n; a.status = d_status; a.iters = d_iters; a.quirk = d_quirk;
     a.term = (uint64_t*)out.d_term;
     a.vpool = (uint64_t*)d_vpool_; a.vnext = d_ctr + 2; a.vpool_entries = vpool_entries_; a.vcap_max = vcap_max;
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
@@ -542,11 +604,15 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     LDBG_LAUNCH(k_compact_paths, grid_for(ns * 64, 256, 4096), 256, s, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
                 (const int64_t*)d_strand_off, ns, (uint64_t*)out.d_path);
     const int cg = grid_for(n * 64, 256, 4096);
+    ContigArgs ca;
+    ca.g = graph->view; ca.n = n; ca.seeds = a.seeds; ca.dense = (const uint64_t*)out.d_path; ca.strand_off = d_strand_off;
+    ca.walk_len = d_walk_len; ca.contig_off = d_contig_off; ca.quirk = d_quirk; ca.term = (const uint64_t*)out.d_term;
+    ca.out = (char*)out.d_contigs;
     switch (W) {
-        case 1: LDBG_LAUNCH(k_contigs<1>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
-        case 2: LDBG_LAUNCH(k_contigs<2>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
-        case 3: LDBG_LAUNCH(k_contigs<3>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
-        default: LDBG_LAUNCH(k_contigs<4>, cg, 256, s, k, n, a.seeds, (const uint64_t*)out.d_path, (const int64_t*)d_strand_off, (const int64_t*)d_walk_len, (const int64_t*)d_contig_off, (char*)out.d_contigs); break;
+        case 1: LDBG_LAUNCH(k_contigs<1>, cg, 256, s, ca); break;
+        case 2: LDBG_LAUNCH(k_contigs<2>, cg, 256, s, ca); break;
+        case 3: LDBG_LAUNCH(k_contigs<3>, cg, 256, s, ca); break;
+        default: LDBG_LAUNCH(k_contigs<4>, cg, 256, s, ca); break;
     }
     c1.record(s);
     rt::stream_sync(s);
