@@ -277,6 +277,13 @@ ldbg_status ldbg_engine_has_previous(ldbg_engine* e, int* yes) { return guard([&
 ldbg_status ldbg_engine_next(ldbg_engine* e, char* kmer_out, int64_t* rec_out) { return guard([&] { cursor_of(e).step(true, kmer_out, rec_out); }); }
 ldbg_status ldbg_engine_previous(ldbg_engine* e, char* kmer_out, int64_t* rec_out) { return guard([&] { cursor_of(e).step(false, kmer_out, rec_out); }); }
 
+#ifdef LDBG_HOSTSIM
+void ldbg_debug_ls(uint64_t* out) {
+    auto& d = ldbg::ls_debug();
+    out[0] = d.adds; out[1] = d.newkeys; out[2] = d.choices; out[3] = d.scan; out[4] = d.maxn; out[5] = d.steps; out[6] = d.sum_n;
+    d = ldbg::LsDebug();
+}
+#endif
 // ---- measurement
 ldbg_status ldbg_profile_reset(void) { profile_reset_all(); return LDBG_OK; }
 ldbg_status ldbg_profile_get(const char* family, double* total_ms, int64_t* launches) {

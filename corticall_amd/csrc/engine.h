@@ -20,6 +20,7 @@ struct EngineView {
     int stopper, max_len, connect_all, strict_flip;
     int cursor_on;        // !ec.getLinks().isEmpty(): dfs drives the cursor (TraversalEngine.java:363, 379) even
                           // when none of the configured link sets belongs to a traversal sample
+    uint32_t dbg;         // timing experiments only (LDBG_DEBUG_SKIP): results are wrong when non-zero
     uint32_t link_flag_mask;   // probe-row link-flag bits of the link sets merged into `links`
     LinksView links;      // the traversal's link sets merged into one table (links.h)
 };
@@ -186,10 +187,15 @@ LDBG_HOSTDEV int vt_count_e(uint64_t e) { return (int)((e >> 48) & 0x7FFFull); }
 LDBG_HOSTDEV bool vt_seen_e(uint64_t e) { return (e >> 63) != 0; }
 LDBG_HOSTDEV uint64_t vt_with_count(uint64_t e, int c) { return (e & ~(0x7FFFull << 48)) | ((uint64_t)(c & 0x7FFF) << 48); }
 LDBG_HOSTDEV void node_locate(VisitedTable& t, Node& n) { if (n.idx >= 0) n.vslot = vt_locate(t, n.idx, n.flip != 0); }
+// timing experiment (EngineView.dbg & 16): a 64-entry direct-mapped pseudo table, collisions ignored — wrong results
+LDBG_HOSTDEV void node_locate_dbg(const uint32_t dbg, VisitedTable& t, Node& n) {
+    if (dbg & 16u) { if (n.idx >= 0) n.vslot = vt_hash(vt_key(n.idx, n.flip != 0)) & 63u; }
+    else node_locate(t, n);
+}
 LDBG_HOSTDEV int node_count(const VisitedTable& t, const Node& n) { return n.idx >= 0 ? vt_count_e(t.tab[n.vslot]) : 0; }
 LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const Node& p, bool fwd, unsigned base, Node& n) {
     node_child(e, p, fwd, base, n);
-    node_locate(t, n);
+    node_locate_dbg(e.dbg, t, n);
 }
 
 // ---- per-walk LinkStore (J/utils/traversal/LinkStore.java), elements kept in insertion order.
@@ -197,15 +203,19 @@ LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const
 // value of the store's age counter at insertion and age = counter - birth; incrementAges and numNewPaths
 // (:45-56) are O(1).  Each element caches its junction record's fields so the junction logic reads one
 // element + one base byte per link.
+#ifdef LDBG_HOSTSIM
+struct LsDebug { uint64_t adds = 0, newkeys = 0, choices = 0, scan = 0, maxn = 0, steps = 0, sum_n = 0; };
+inline LsDebug& ls_debug() { static LsDebug d; return d; }
+#endif
 struct LsElem {
-    uint32_t str_off;  // junction string in LinksView.bases
+    uint32_t str_off;  // junction string in LinksView.bases (one offset per junction record: identifies it)
     uint32_t birth;    // store.age at insertion
     int32_t hash;      // java.lang.String.hashCode of the (possibly complemented) junction string
-    uint32_t jrec;     // index into LinksView.junc
+    uint32_t key_seq;  // insertion sequence number of this element's key in the Java HashMap
     uint16_t len;
     uint16_t pos;
-    uint16_t key_seq;  // insertion sequence number of this element's key in the Java HashMap
     uint16_t comp;     // junction string is used complemented (LinkStore.java:25)
+    uint16_t pad;
 };
 struct LinkStoreDev {
     LsElem* el;
@@ -224,81 +234,117 @@ LDBG_HOSTDEV unsigned ls_char(const LinksView& L, const LsElem& x, uint32_t i) {
     return x.comp ? 3u - b : b;
 }
 LDBG_HOSTDEV bool ls_same_string(const LinksView& L, const LsElem& a, const LsElem& b) {
-    if (a.jrec == b.jrec && a.comp == b.comp) return true;
+    if (a.str_off == b.str_off && a.comp == b.comp) return true;
     if (a.len != b.len || a.hash != b.hash) return false;
     for (uint32_t i = 0; i < a.len; i++) if (ls_char(L, a, i) != ls_char(L, b, i)) return false;
     return true;
 }
+// is any live element (other than index `skip`) filed under HashMap key `key_seq`?
+LDBG_HOSTDEV bool ls_key_alive(const LinkStoreDev& s, uint32_t key_seq, uint32_t n) {
+    for (uint32_t i = n; i-- > 0;) if (s.el[i].key_seq == key_seq) return true;
+    return false;
+}
 // LinkStore.add :17-35 for merged link record m.  `query_flipped`: the cursor k-mer is the reverse complement
 // of the canonical key; JuncRec.is_fw is stored as "link goes forward when the query is the canonical k-mer".
+// s.nkeys = HashMap.size() is maintained incrementally (new key: +1 here; last element of a key expiring: -1 in
+// ls_next_choice); the table doubles when a put() pushes it past 3/4 of the table size (HashMap.resize).
 LDBG_HOSTDEV void ls_add(const LinksView& L, LinkStoreDev& s, int64_t m, bool query_flipped, bool fwd) {
     for (uint32_t j = L.off[m]; j < L.off[m + 1]; j++) {
         const JuncRec jr = L.junc[j];
         bool lgf = (jr.is_fw != 0) != query_flipped;    // recordOrientationMatchesKmer == cjr.isForward() :24
         if (lgf != fwd) continue;
         LsElem x;
-        x.str_off = jr.str_off; x.birth = s.age; x.hash = lgf ? jr.hash_asis : jr.hash_comp; x.jrec = j;
+        x.str_off = jr.str_off; x.birth = s.age; x.hash = lgf ? jr.hash_asis : jr.hash_comp; x.pad = 0;
         x.len = (uint16_t)jr.len; x.pos = 0; x.comp = lgf ? 0 : 1; x.key_seq = 0;
+        // an element with the same junction string?  newest first: a walk circling a repeat re-adds the links it
+        // added one revolution ago, so the match sits near the end of the (insertion-ordered) array
         bool have = false;
-        for (uint32_t i = 0; i < s.n; i++)
+        for (uint32_t i = s.n; i-- > 0;)
             if (ls_same_string(L, s.el[i], x)) { x.key_seq = s.el[i].key_seq; have = true; break; }
         if (!have) {
-            // a new key: HashMap.size() = distinct keys still alive (counted here, where it matters, instead of
-            // after every expiry) + 1; the table doubles when that exceeds 3/4 of its size (HashMap.resize)
-            uint32_t live = 0;
-            for (uint32_t i = 0; i < s.n; i++) {
-                bool first = true;
-                for (uint32_t q = 0; q < i; q++) if (s.el[q].key_seq == s.el[i].key_seq) { first = false; break; }
-                live += first;
-            }
-            x.key_seq = (uint16_t)s.next_seq++;
-            s.nkeys = live + 1;
+            x.key_seq = s.next_seq++;
+            s.nkeys++;
             if (s.java_cap == 0) s.java_cap = 16;
             if (s.nkeys > s.java_cap * 3 / 4) s.java_cap *= 2;
         }
-        if (s.n >= s.cap || s.next_seq >= 65535u || jr.len >= 65535u) { s.overflow = true; return; }
+        if (s.n >= s.cap || jr.len >= 65535u || s.n >= 0x7FFFu) { s.overflow = true; return; }
         s.el[s.n++] = x;
         s.n_new++;
+#ifdef LDBG_HOSTSIM
+        ls_debug().adds++; if (!have) ls_debug().newkeys++; if (s.n > ls_debug().maxn) ls_debug().maxn = s.n;
+#endif
     }
 }
 LDBG_HOSTDEV void ls_increment_ages(LinkStoreDev& s) { s.age++; s.n_new = 0; }
 LDBG_HOSTDEV int ls_num_new(const LinkStoreDev& s) { return (int)s.n_new; }
-// LinkStore.getNextJunctionChoice :122-144 (+ getOldestLink :92-119, incrementPositionsAndExpire :58-90)
+// LinkStore.getNextJunctionChoice :122-144 (+ getOldestLink :92-119, incrementPositionsAndExpire :58-90).
+// Elements are in insertion order and births never decrease along the array, so the oldest links are a prefix.
 LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* choice) {
     if (s.n == 0) return false;
-    uint32_t minbirth = 0xFFFFFFFFu;          // oldest = largest age = smallest birth
-    for (uint32_t i = 0; i < s.n; i++) if (s.el[i].birth < minbirth) minbirth = s.el[i].birth;
+#ifdef LDBG_HOSTSIM
+    ls_debug().choices++; ls_debug().scan += s.n;
+#endif
+    const uint32_t minbirth = s.el[0].birth;   // oldest = largest age = smallest birth
     // first oldest element in java.util.HashMap iteration order: (bucket, key insertion order, list order)
-    bool have = false, agree = true;
+    bool agree = true;
     unsigned ch0 = 0;
     uint32_t best_b = 0, best_seq = 0;
     for (uint32_t i = 0; i < s.n; i++) {
         const LsElem x = s.el[i];
-        if (x.birth != minbirth) continue;
+        if (x.birth != minbirth) break;
         unsigned c = ls_char(L, x, x.pos);
         uint32_t h = (uint32_t)x.hash;
         uint32_t b = (h ^ (h >> 16)) & (s.java_cap - 1);
-        if (!have) { have = true; ch0 = c; best_b = b; best_seq = x.key_seq; }
+        if (i == 0) { ch0 = c; best_b = b; best_seq = x.key_seq; }
         else {
             if (c != ch0) agree = false;
             if (b < best_b || (b == best_b && x.key_seq < best_seq)) { best_b = b; best_seq = x.key_seq; }
         }
     }
-    if (!have || !agree) return false;
+    if (!agree) return false;
     unsigned ch = ch0;
-    for (uint32_t i = 0; i < s.n; i++)   // last element of that key's list wins (:129-133)
-        if (s.el[i].key_seq == best_seq) ch = ls_char(L, s.el[i], s.el[i].pos);
-    // incrementPositionsAndExpire(choice)
+    for (uint32_t i = s.n; i-- > 0;)     // last element of that key's list wins (:129-133)
+        if (s.el[i].key_seq == best_seq) { ch = ls_char(L, s.el[i], s.el[i].pos); break; }
+    // incrementPositionsAndExpire(choice): four elements at a time so that their loads overlap
     uint32_t w = 0, n_new = 0;
-    for (uint32_t i = 0; i < s.n; i++) {
-        LsElem x = s.el[i];
-        if ((uint32_t)x.pos + 1 >= x.len || ls_char(L, x, x.pos) != ch) continue;
-        x.pos++;
-        n_new += x.birth == s.age;
-        s.el[w++] = x;
+    uint32_t dead[8];
+    uint32_t n_dead = 0;
+    bool many_dead = false;
+    for (uint32_t i0 = 0; i0 < s.n; i0 += 4) {
+        LsElem x[4];
+        unsigned c[4];
+        const uint32_t cnt = s.n - i0 < 4 ? s.n - i0 : 4;
+        for (uint32_t q = 0; q < 4; q++) if (q < cnt) x[q] = s.el[i0 + q];
+        for (uint32_t q = 0; q < 4; q++) if (q < cnt) c[q] = ls_char(L, x[q], x[q].pos);
+        for (uint32_t q = 0; q < 4; q++) {
+            if (q >= cnt) break;
+            if ((uint32_t)x[q].pos + 1 >= x[q].len || c[q] != ch) {
+                if (n_dead < 8) dead[n_dead++] = x[q].key_seq; else many_dead = true;
+                continue;
+            }
+            x[q].pos++;
+            n_new += x[q].birth == s.age;
+            s.el[w++] = x[q];
+        }
     }
     s.n = w;
     s.n_new = n_new;
+    // keys whose last element expired leave the HashMap (:84-88)
+    if (many_dead) {
+        uint32_t nk = 0;
+        for (uint32_t i = 0; i < s.n; i++) {
+            bool first = true;
+            for (uint32_t j = 0; j < i; j++) if (s.el[j].key_seq == s.el[i].key_seq) { first = false; break; }
+            nk += first;
+        }
+        s.nkeys = nk;
+    } else {
+        for (uint32_t d = 0; d < n_dead; d++) {
+            bool dup = false;
+            for (uint32_t q = 0; q < d; q++) dup |= dead[q] == dead[d];
+            if (!dup && !ls_key_alive(s, dead[d], s.n)) s.nkeys--;
+        }
+    }
     *choice = ch;
     return true;
 }
@@ -315,7 +361,7 @@ struct Cursor {
 // initializeLinkStore / updateLinkStore (:548-597): links of vertex v, if its record carries any
 template <int W>
 LDBG_HOSTDEV void cursor_add_links(const EngineView& e, LinkStoreDev& s, const Node& v, bool fwd) {
-    if (!(v.lflags & e.link_flag_mask)) return;
+    if (!(v.lflags & e.link_flag_mask) || (e.dbg & 4u)) return;
     Kmer<W> c = graph_key<W>(e.g, v.idx);
     int64_t m = links_find<W>(e.links, e.g.k, c);
     if (m >= 0) ls_add(e.links, s, m, v.flip != 0, fwd);
@@ -362,7 +408,7 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
         if (!vt_seen_e(ex) || s.n > 0) {                // :262
             cu.nxt = x;
             has = true;
-            if (x.idx >= 0) vt.tab[x.vslot] = ex | (1ull << 63);   // seen.add(nextKmer)
+            if (x.idx >= 0 && !(e.dbg & 2u)) vt.tab[x.vslot] = ex | (1ull << 63);   // seen.add(nextKmer)
         }
     } else if (pc > 1) {
         unsigned ch;
@@ -373,6 +419,9 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
         ls_increment_ages(s);                           // :271
     }
     cu.has = has;
+#ifdef LDBG_HOSTSIM
+    ls_debug().steps++; ls_debug().sum_n += s.n;
+#endif
     if (ls_num_new(s) > 0) ls_increment_ages(s);        // :274-276 (Q12)
     if (s.overflow) cu.status = ST_LINKSTORE_FULL;
     return t;

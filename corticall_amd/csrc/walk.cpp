@@ -30,6 +30,7 @@ struct WalkArgs {
     unsigned long long* vnext;
     uint64_t vpool_entries;
     uint32_t vcap_max;         // largest table a strand may need
+    uint32_t vcap_init;        // size a strand's table starts with
     uint32_t* strand_n;        // vertices in the strand's branch graph (0 = empty graph)
     uint32_t* status;
     uint32_t* iters;
@@ -37,6 +38,8 @@ struct WalkArgs {
     uint64_t* term;            // [n_strands][W]
     LsElem* ls;                // [n_slots][ecap]
     uint32_t ecap;
+    unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
+    unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
 };
 #define LDBG_VT_INITIAL 4096u
 
@@ -56,7 +59,7 @@ LDBG_DEV bool path_append(const WalkArgs& a, int64_t s, PathWriter& pw, uint64_t
         a.block_table[s * a.max_blocks + bi] = (uint32_t)b;
         pw.cur = a.pool + b * LDBG_PATH_BLOCK;
     }
-    pw.cur[off] = entry;
+    if (!(a.e.dbg & 1u)) pw.cur[off] = entry;
     pw.n++;
     return true;
 }
@@ -88,6 +91,9 @@ LDBG_DEV void strand_finish(const WalkArgs& a, StrandState& st) {
     a.status[st.s] = st.status != ST_OK ? st.status : (st.branch_null ? (uint32_t)ST_BRANCH_NULL : (uint32_t)ST_OK);
     a.iters[st.s] = st.iters;
     a.quirk[st.s] = st.quirk ? 1 : 0;
+#ifndef LDBG_HOSTSIM
+    if (a.st_times) a.st_times[2 * st.s + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // returns false when the strand ended at once
@@ -95,12 +101,15 @@ template <int W>
 LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, int64_t s) {
     const EngineView& e = a.e;
     st.s = s;
+#ifndef LDBG_HOSTSIM
+    if (a.st_times) a.st_times[2 * s] = __builtin_amdgcn_s_memrealtime();
+#endif
     st.fwd = (s & 1) != 0;
     st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false; st.quirk = false;
     st.pw.cur = nullptr; st.pw.n = 0;
     st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true;
     ls_clear(ls);
-    if (!vt_alloc(a, st.vt, LDBG_VT_INITIAL < a.vcap_max ? LDBG_VT_INITIAL : a.vcap_max)) { st.status = ST_POOL_FULL; return false; }
+    if (!vt_alloc(a, st.vt, a.vcap_init < a.vcap_max ? a.vcap_init : a.vcap_max)) { st.status = ST_POOL_FULL; return false; }
     const uint64_t* sw = a.seeds + (s >> 1) * W;
     Kmer<W> sk;
 #pragma unroll
@@ -191,7 +200,7 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) 
     const bool previously = acopy < vt_count_e(ecv);                    // :424
     if (!previously && cv.idx >= 0) {
         if (acopy + 1 > 32767) { st.status = ST_COPY_OVERFLOW; return true; }
-        st.vt.tab[cv.vslot] = vt_with_count(ecv, acopy + 1);            // visited.add(cv) :425
+        if (!(e.dbg & 8u)) st.vt.tab[cv.vslot] = vt_with_count(ecv, acopy + 1);            // visited.add(cv) :425
     }
     const bool reached = st.gV > (uint32_t)e.max_len;                   // :428
     if (previously) { st.branch_null = true; return true; }             // :470-478, traversalSucceeded() still false
@@ -218,6 +227,9 @@ template <int W>
 LDBG_KERNEL void k_walk(WalkArgs a) {
     const int64_t slot = global_tid();
     if (slot >= a.n_slots) return;
+#ifndef LDBG_HOSTSIM
+    if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     LinkStoreDev ls;
     ls.el = a.ls + (size_t)slot * a.ecap;
     ls.cap = a.ecap;
@@ -244,6 +256,9 @@ LDBG_KERNEL void k_walk(WalkArgs a) {
         wave_grow_tables(a, st, active);
         if (active && strand_step<W>(a, st, ls)) { strand_finish(a, st); active = false; }
     }
+#ifndef LDBG_HOSTSIM
+    if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---- result assembly -------------------------------------------------------------------------
@@ -426,6 +441,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.link_flag_mask = merged_->flag_mask;
     // ec.getLinks().isEmpty() (not "my links") decides whether dfs uses the cursor (:363, :379)
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
+    view.dbg = 0;
 }
 
 Engine::~Engine() { clear_batch(); release_scratch(); }
@@ -527,9 +543,12 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
 
     WalkArgs a;
     a.e = view;
+    a.e.dbg = 0;
+    if (const char* ev = getenv("LDBG_DEBUG_SKIP")) a.e.dbg = (uint32_t)atoi(ev);   // timing experiments only
     a.seeds = (const uint64_t*)out.d_seed_words;
     a.n_strands = ns;
     a.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
+    if (const char* ev = getenv("LDBG_MAX_SLOTS")) a.n_slots = std::max<int64_t>(64, std::min<int64_t>(a.n_slots, (atoll(ev) / 64) * 64));   // tuning knob
     a.run_rev = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_REVERSE;
     a.run_fwd = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_FORWARD;
     a.next_strand = d_ctr;
@@ -539,12 +558,23 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.strand_n = d_strand_n; a.status = d_status; a.iters = d_iters; a.quirk = d_quirk;
     a.term = (uint64_t*)out.d_term;
     a.vpool = (uint64_t*)d_vpool_; a.vnext = d_ctr + 2; a.vpool_entries = vpool_entries_; a.vcap_max = vcap_max;
+    a.vcap_init = LDBG_VT_INITIAL;
+    if (const char* ev = getenv("LDBG_VT_INITIAL")) a.vcap_init = std::max<uint32_t>(64u, next_pow2((uint64_t)atoll(ev)));   // tuning knob
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
 
+    a.wg_times = nullptr; a.st_times = nullptr;
+    const bool want_times = getenv("LDBG_WG_TIMES") != nullptr;
     rt::Event e0, e1;
     e0.record(s);
-    const int block = 64;
+    int block = 64;
+    if (const char* ev = getenv("LDBG_BLOCK")) block = std::max(64, (atoi(ev) / 64) * 64);   // tuning knob
+    a.n_slots = (a.n_slots / block) * block;
+    if (a.n_slots < block) a.n_slots = block;
     const int grid = (int)((a.n_slots + block - 1) / block);
+    if (want_times) {
+        a.wg_times = (unsigned long long*)rt::dmalloc((size_t)grid * 16); rt::dmemset(a.wg_times, 0, (size_t)grid * 16, s);
+        a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
+    }
     switch (W) {
         case 1: LDBG_LAUNCH(k_walk<1>, grid, block, s, a); break;
         case 2: LDBG_LAUNCH(k_walk<2>, grid, block, s, a); break;
@@ -575,6 +605,35 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     unsigned long long ctr[4] = {0, 0, 0, 0};
     rt::d2h(ctr, d_ctr, 32, s);
     rt::stream_sync(s);
+    if (want_times) {
+        std::vector<unsigned long long> t((size_t)grid * 2);
+        rt::d2h(t.data(), a.wg_times, (size_t)grid * 16, s);
+        rt::stream_sync(s);
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < grid; i++) t0 = std::min(t0, t[2 * i]);
+        std::vector<double> st(grid), en(grid);
+        for (int i = 0; i < grid; i++) { st[i] = (t[2 * i] - t0) / 1e5; en[i] = (t[2 * i + 1] - t0) / 1e5; }   // ms
+        std::vector<double> ss = st, ee = en;
+        std::sort(ss.begin(), ss.end()); std::sort(ee.begin(), ee.end());
+        fprintf(stderr, "[ldbg] k_walk workgroups=%d start ms p0/p50/p90/p100 = %.2f %.2f %.2f %.2f ; end ms p0/p50/p90/p100 = %.2f %.2f %.2f %.2f\n",
+                grid, ss[0], ss[grid / 2], ss[grid * 9 / 10], ss[grid - 1], ee[0], ee[grid / 2], ee[grid * 9 / 10], ee[grid - 1]);
+        rt::dfree(a.wg_times);
+        std::vector<unsigned long long> tt((size_t)ns * 2);
+        rt::d2h(tt.data(), a.st_times, (size_t)ns * 16, s);
+        rt::stream_sync(s);
+        std::vector<int64_t> order(ns);
+        for (int64_t i = 0; i < ns; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return tt[2 * x + 1] - tt[2 * x] > tt[2 * y + 1] - tt[2 * y]; });
+        for (int r = 0; r < 12 && r < ns; r++) {
+            int64_t i = order[r];
+            double ms = (tt[2 * i + 1] - tt[2 * i]) / 1e5;
+            fprintf(stderr, "[ldbg] slow strand %lld (seed %lld %s): %.1f ms, %u iterations, %.2f us/iter, lane %lld of its wave, status %u\n", (long long)i, (long long)(first + i / 2),
+                    (i & 1) ? "fwd" : "rev", ms, iters[i], iters[i] ? ms * 1e3 / iters[i] : 0.0, (long long)(i & 63), out.status[i]);
+        }
+        double tot_ms = 0; for (int64_t i = 0; i < ns; i++) tot_ms += (tt[2 * i + 1] - tt[2 * i]) / 1e5;
+        fprintf(stderr, "[ldbg] sum of strand durations %.1f s over %lld strands\n", tot_ms / 1e3, (long long)ns);
+        rt::dfree(a.st_times);
+    }
     vpool_dirty_ = ctr[2];
     profile_add("walk", rt::Event::elapsed_ms(e0, e1));
 
