@@ -63,10 +63,12 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
     vt.tab = vtab; vt.mask = vcap - 1; vt.used = st.vt_used;
     if (vt.used * 2 > vcap) { st.status = ST_POOL_FULL; return; }   // more steps since seek() than the cursor's `seen` table holds
     LinkStoreDev ls;
+    ls.fast = nullptr; ls.fast_cap = 0; ls.fast_stride = 0;
     ls.el = els; ls.cap = ecap; ls.n = st.ls_n; ls.java_cap = st.ls_java_cap; ls.nkeys = st.ls_nkeys; ls.next_seq = st.ls_next_seq;
     ls.age = st.ls_age; ls.n_new = st.ls_n_new;
     ls.overflow = false;
     Cursor cu;
+    cu.prof = nullptr;
     cu.cur = st.cur; cu.first = st.first != 0; cu.status = ST_OK;
     cu.has = fwd ? st.has_next != 0 : st.has_prev != 0;
     if (!cu.has) { st.status = ST_NULLPTR; return; }   // target vanished after the re-seek: NPE in the reference

@@ -173,10 +173,17 @@ LDBG_HOSTDEV uint32_t vt_hash(uint64_t key) {
 }
 LDBG_HOSTDEV uint64_t vt_key(int64_t idx, bool flip) { return ((uint64_t)(idx + 1) << 1) | (flip ? 1ull : 0ull); }
 // slot of (idx, flip); claims a free slot (count 0, not seen) if the vertex is not in the table yet
+#ifdef LDBG_HOSTSIM
+struct LsDebug { uint64_t adds = 0, newkeys = 0, choices = 0, scan = 0, maxn = 0, steps = 0, sum_n = 0; };
+inline LsDebug& ls_debug() { static LsDebug d; return d; }
+#endif
 LDBG_HOSTDEV uint32_t vt_locate(VisitedTable& t, int64_t idx, bool flip) {
     const uint64_t key = vt_key(idx, flip);
     uint32_t h = vt_hash(key) & t.mask;
     while (true) {
+#ifdef LDBG_HOSTSIM
+        ls_debug().scan++;
+#endif
         const uint64_t e = t.tab[h];
         if (e == 0) { t.tab[h] = key; t.used++; return h; }
         if ((e & LDBG_VT_KEY_MASK) == key) return h;
@@ -203,10 +210,6 @@ LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const
 // value of the store's age counter at insertion and age = counter - birth; incrementAges and numNewPaths
 // (:45-56) are O(1).  Each element caches its junction record's fields so the junction logic reads one
 // element + one base byte per link.
-#ifdef LDBG_HOSTSIM
-struct LsDebug { uint64_t adds = 0, newkeys = 0, choices = 0, scan = 0, maxn = 0, steps = 0, sum_n = 0; };
-inline LsDebug& ls_debug() { static LsDebug d; return d; }
-#endif
 struct LsElem {
     uint32_t str_off;  // junction string in LinksView.bases (one offset per junction record: identifies it)
     uint32_t birth;    // store.age at insertion
@@ -218,8 +221,10 @@ struct LsElem {
     uint16_t pad;
 };
 struct LinkStoreDev {
-    LsElem* el;
-    uint32_t cap;       // capacity of el
+    LsElem* fast;       // the first `fast_cap` elements live here (LDS in the walk kernel), element i at fast[i * fast_stride]
+    LsElem* el;         // the rest spill to HBM: element i at el[i - fast_cap]
+    uint32_t fast_cap, fast_stride;
+    uint32_t cap;       // total capacity
     uint32_t n;
     uint32_t java_cap;  // table size of the emulated java.util.HashMap (0 = not allocated)
     uint32_t nkeys;
@@ -228,6 +233,8 @@ struct LinkStoreDev {
     uint32_t n_new;     // elements with age 0
     bool overflow;
 };
+LDBG_HOSTDEV LsElem ls_get(const LinkStoreDev& s, uint32_t i) { return i < s.fast_cap ? s.fast[i * s.fast_stride] : s.el[i - s.fast_cap]; }
+LDBG_HOSTDEV void ls_set(LinkStoreDev& s, uint32_t i, const LsElem& x) { if (i < s.fast_cap) s.fast[i * s.fast_stride] = x; else s.el[i - s.fast_cap] = x; }
 LDBG_HOSTDEV void ls_clear(LinkStoreDev& s) { s.n = 0; s.java_cap = 0; s.nkeys = 0; s.next_seq = 0; s.age = 0; s.n_new = 0; s.overflow = false; }
 LDBG_HOSTDEV unsigned ls_char(const LinksView& L, const LsElem& x, uint32_t i) {
     unsigned b = L.bases[x.str_off + i];
@@ -241,7 +248,7 @@ LDBG_HOSTDEV bool ls_same_string(const LinksView& L, const LsElem& a, const LsEl
 }
 // is any live element (other than index `skip`) filed under HashMap key `key_seq`?
 LDBG_HOSTDEV bool ls_key_alive(const LinkStoreDev& s, uint32_t key_seq, uint32_t n) {
-    for (uint32_t i = n; i-- > 0;) if (s.el[i].key_seq == key_seq) return true;
+    for (uint32_t i = n; i-- > 0;) if (ls_get(s, i).key_seq == key_seq) return true;
     return false;
 }
 // LinkStore.add :17-35 for merged link record m.  `query_flipped`: the cursor k-mer is the reverse complement
@@ -260,7 +267,7 @@ LDBG_HOSTDEV void ls_add(const LinksView& L, LinkStoreDev& s, int64_t m, bool qu
         // added one revolution ago, so the match sits near the end of the (insertion-ordered) array
         bool have = false;
         for (uint32_t i = s.n; i-- > 0;)
-            if (ls_same_string(L, s.el[i], x)) { x.key_seq = s.el[i].key_seq; have = true; break; }
+            { const LsElem y = ls_get(s, i); if (ls_same_string(L, y, x)) { x.key_seq = y.key_seq; have = true; break; } }
         if (!have) {
             x.key_seq = s.next_seq++;
             s.nkeys++;
@@ -268,7 +275,7 @@ LDBG_HOSTDEV void ls_add(const LinksView& L, LinkStoreDev& s, int64_t m, bool qu
             if (s.nkeys > s.java_cap * 3 / 4) s.java_cap *= 2;
         }
         if (s.n >= s.cap || jr.len >= 65535u || s.n >= 0x7FFFu) { s.overflow = true; return; }
-        s.el[s.n++] = x;
+        ls_set(s, s.n++, x);
         s.n_new++;
 #ifdef LDBG_HOSTSIM
         ls_debug().adds++; if (!have) ls_debug().newkeys++; if (s.n > ls_debug().maxn) ls_debug().maxn = s.n;
@@ -282,15 +289,15 @@ LDBG_HOSTDEV int ls_num_new(const LinkStoreDev& s) { return (int)s.n_new; }
 LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* choice) {
     if (s.n == 0) return false;
 #ifdef LDBG_HOSTSIM
-    ls_debug().choices++; ls_debug().scan += s.n;
+    ls_debug().choices++;
 #endif
-    const uint32_t minbirth = s.el[0].birth;   // oldest = largest age = smallest birth
+    const uint32_t minbirth = ls_get(s, 0).birth;   // oldest = largest age = smallest birth
     // first oldest element in java.util.HashMap iteration order: (bucket, key insertion order, list order)
     bool agree = true;
     unsigned ch0 = 0;
     uint32_t best_b = 0, best_seq = 0;
     for (uint32_t i = 0; i < s.n; i++) {
-        const LsElem x = s.el[i];
+        const LsElem x = ls_get(s, i);
         if (x.birth != minbirth) break;
         unsigned c = ls_char(L, x, x.pos);
         uint32_t h = (uint32_t)x.hash;
@@ -304,7 +311,7 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
     if (!agree) return false;
     unsigned ch = ch0;
     for (uint32_t i = s.n; i-- > 0;)     // last element of that key's list wins (:129-133)
-        if (s.el[i].key_seq == best_seq) { ch = ls_char(L, s.el[i], s.el[i].pos); break; }
+        { const LsElem y = ls_get(s, i); if (y.key_seq == best_seq) { ch = ls_char(L, y, y.pos); break; } }
     // incrementPositionsAndExpire(choice): four elements at a time so that their loads overlap
     uint32_t w = 0, n_new = 0;
     uint32_t dead[8];
@@ -314,7 +321,7 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
         LsElem x[4];
         unsigned c[4];
         const uint32_t cnt = s.n - i0 < 4 ? s.n - i0 : 4;
-        for (uint32_t q = 0; q < 4; q++) if (q < cnt) x[q] = s.el[i0 + q];
+        for (uint32_t q = 0; q < 4; q++) if (q < cnt) x[q] = ls_get(s, i0 + q);
         for (uint32_t q = 0; q < 4; q++) if (q < cnt) c[q] = ls_char(L, x[q], x[q].pos);
         for (uint32_t q = 0; q < 4; q++) {
             if (q >= cnt) break;
@@ -324,7 +331,7 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
             }
             x[q].pos++;
             n_new += x[q].birth == s.age;
-            s.el[w++] = x[q];
+            ls_set(s, w++, x[q]);
         }
     }
     s.n = w;
@@ -334,7 +341,7 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
         uint32_t nk = 0;
         for (uint32_t i = 0; i < s.n; i++) {
             bool first = true;
-            for (uint32_t j = 0; j < i; j++) if (s.el[j].key_seq == s.el[i].key_seq) { first = false; break; }
+            for (uint32_t j = 0; j < i; j++) if (ls_get(s, j).key_seq == ls_get(s, i).key_seq) { first = false; break; }
             nk += first;
         }
         s.nkeys = nk;
@@ -350,7 +357,14 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
 }
 
 // ---- cursor (TraversalEngine.seek / next / previous, TraversalEngine.java:241-339, 518-597)
+struct StepProf { unsigned long long t_links, t_child, t_choice, n_links, n_choice; };
+#if !defined(LDBG_HOSTSIM)
+#define LDBG_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define LDBG_NOW() 0ull
+#endif
 struct Cursor {
+    StepProf* prof;     // diagnostics only (nullptr in normal runs)
     Node cur;
     Node nxt;           // the vertex hasNext()/hasPrevious() refers to, looked up one step ahead
     bool has;
@@ -390,11 +404,13 @@ LDBG_HOSTDEV int cursor_choice_base(const EngineView& e, const Node& t, uint32_t
 // next()/previous() (TraversalEngine.java:241-319); requires cu.has.  Returns the vertex stepped onto.
 template <int W>
 LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd) {
+    unsigned long long p0 = cu.prof ? LDBG_NOW() : 0ull;
     if (cu.first) {
         cu.first = false;                              // seek(cur) recomputes the same state; then
         cursor_add_links<W>(e, s, cu.cur, fwd);        // initializeLinkStore :548-568
     }
     cursor_add_links<W>(e, s, cu.nxt, fwd);            // updateLinkStore :570-597
+    if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_links += p1 - p0; cu.prof->n_links += (cu.nxt.lflags & e.link_flag_mask) ? 1 : 0; p0 = p1; }
     Node t = cu.nxt;
     cu.cur = t;
     if (t.npe) cu.status = ST_NULLPTR;
@@ -405,6 +421,7 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
         Node x;
         node_child_located(e, vt, t, fwd, lowbit4(m), x);
         const uint64_t ex = x.idx >= 0 ? vt.tab[x.vslot] : 0ull;
+        if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_child += p1 - p0; p0 = p1; }
         if (!vt_seen_e(ex) || s.n > 0) {                // :262
             cu.nxt = x;
             has = true;
@@ -417,6 +434,7 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
             if (mb >= 0) { node_child_located(e, vt, t, fwd, (unsigned)mb, cu.nxt); has = true; }
         }
         ls_increment_ages(s);                           // :271
+        if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_choice += p1 - p0; cu.prof->n_choice++; p0 = p1; }
     }
     cu.has = has;
 #ifdef LDBG_HOSTSIM

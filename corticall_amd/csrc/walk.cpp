@@ -19,6 +19,8 @@ struct WalkArgs {
     const uint64_t* seeds;     // [n][W]; word 0 == ~0 marks a seed that is not a k-mer (non-ACGT)
     int64_t n_strands;         // 2n: strand 2i = reverse, 2i+1 = forward
     int64_t n_slots;
+    int64_t fetch_stride;      // strands are handed out in the order (i * fetch_stride) mod n_strands (coprime): neighbouring
+                               // seeds walk the same contig, and a wavefront full of identical long walks is the worst tail
     int run_rev, run_fwd;
     unsigned long long* next_strand;
     uint64_t* pool;            // path blocks [n_blocks][LDBG_PATH_BLOCK]
@@ -40,8 +42,12 @@ struct WalkArgs {
     uint32_t ecap;
     unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
+    StepProf* st_prof;              // diagnostics: [n_strands] time split of the cursor step
 };
 #define LDBG_VT_INITIAL 4096u
+#ifndef LDBG_LS_FAST
+#define LDBG_LS_FAST 32u          // link-store elements per lane kept in LDS (48 KB per 64-lane workgroup)
+#endif
 
 LDBG_DEV uint64_t pack_vertex(const Node& v) { return path_pack(v.idx, v.flip != 0, v.base, v.copy, v.flip && !v.fj); }
 
@@ -108,6 +114,7 @@ LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls,
     st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false; st.quirk = false;
     st.pw.cur = nullptr; st.pw.n = 0;
     st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true;
+    st.cu.prof = a.st_prof ? a.st_prof + s : nullptr;
     ls_clear(ls);
     if (!vt_alloc(a, st.vt, a.vcap_init < a.vcap_max ? a.vcap_init : a.vcap_max)) { st.status = ST_POOL_FULL; return false; }
     const uint64_t* sw = a.seeds + (s >> 1) * W;
@@ -230,9 +237,20 @@ LDBG_KERNEL void k_walk(WalkArgs a) {
 #ifndef LDBG_HOSTSIM
     if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
+    // link store: the first LDBG_LS_FAST elements of every lane live in LDS ([element][lane]), the rest in HBM
+#ifndef LDBG_HOSTSIM
+    __shared__ LsElem lds_store[LDBG_LS_FAST * 64];
+    LsElem* fast = lds_store + (threadIdx.x & 63u);
+    const uint32_t fast_stride = 64;
+#else
+    static LsElem lds_store[LDBG_LS_FAST];
+    LsElem* fast = lds_store;
+    const uint32_t fast_stride = 1;
+#endif
     LinkStoreDev ls;
+    ls.fast = fast; ls.fast_cap = LDBG_LS_FAST; ls.fast_stride = fast_stride;
     ls.el = a.ls + (size_t)slot * a.ecap;
-    ls.cap = a.ecap;
+    ls.cap = a.ecap + LDBG_LS_FAST;
     ls_clear(ls);
     StrandState st;
     st.vt.tab = nullptr; st.vt.mask = 0; st.vt.used = 0; st.status = ST_OK;
@@ -241,9 +259,10 @@ LDBG_KERNEL void k_walk(WalkArgs a) {
     // regrowth below is a wave-wide operation
     while (wave_ballot(active || !exhausted) != 0ull) {
         if (!active && !exhausted) {
-            const int64_t s = (int64_t)atomic_add_u64(a.next_strand, 1ull);
-            if (s >= a.n_strands) exhausted = true;
+            const int64_t fi = (int64_t)atomic_add_u64(a.next_strand, 1ull);
+            if (fi >= a.n_strands) exhausted = true;
             else {
+                const int64_t s = (int64_t)(((unsigned __int128)fi * (unsigned __int128)a.fetch_stride) % (unsigned __int128)a.n_strands);
                 const bool fwd = (s & 1) != 0;
                 if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
                     a.strand_n[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0; a.quirk[s] = 0;
@@ -549,6 +568,13 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.n_strands = ns;
     a.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
     if (const char* ev = getenv("LDBG_MAX_SLOTS")) a.n_slots = std::max<int64_t>(64, std::min<int64_t>(a.n_slots, (atoll(ev) / 64) * 64));   // tuning knob
+    {   // a stride coprime to the number of strands, a few thousand apart
+        auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
+        int64_t st = 7919;
+        if (const char* ev = getenv("LDBG_FETCH_STRIDE")) st = std::max<int64_t>(1, atoll(ev));
+        while (gcd(st, ns) != 1) st++;
+        a.fetch_stride = st % ns ? st % ns : 1;
+    }
     a.run_rev = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_REVERSE;
     a.run_fwd = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_FORWARD;
     a.next_strand = d_ctr;
@@ -562,18 +588,20 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     if (const char* ev = getenv("LDBG_VT_INITIAL")) a.vcap_init = std::max<uint32_t>(64u, next_pow2((uint64_t)atoll(ev)));   // tuning knob
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
 
-    a.wg_times = nullptr; a.st_times = nullptr;
+    a.wg_times = nullptr; a.st_times = nullptr; a.st_prof = nullptr;
     const bool want_times = getenv("LDBG_WG_TIMES") != nullptr;
     rt::Event e0, e1;
     e0.record(s);
-    int block = 64;
-    if (const char* ev = getenv("LDBG_BLOCK")) block = std::max(64, (atoi(ev) / 64) * 64);   // tuning knob
+    const int block = 64;            // one wavefront per workgroup (the LDS link store is laid out [element][lane])
+    // every workgroup must be resident (lanes refill from the strand queue): 48 KB of LDS each -> 3 per CU
+    a.n_slots = std::min<int64_t>(a.n_slots, (int64_t)3 * 256 * 64);
     a.n_slots = (a.n_slots / block) * block;
     if (a.n_slots < block) a.n_slots = block;
     const int grid = (int)((a.n_slots + block - 1) / block);
     if (want_times) {
         a.wg_times = (unsigned long long*)rt::dmalloc((size_t)grid * 16); rt::dmemset(a.wg_times, 0, (size_t)grid * 16, s);
         a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
+        a.st_prof = (StepProf*)rt::dmalloc((size_t)ns * sizeof(StepProf)); rt::dmemset(a.st_prof, 0, (size_t)ns * sizeof(StepProf), s);
     }
     switch (W) {
         case 1: LDBG_LAUNCH(k_walk<1>, grid, block, s, a); break;
@@ -624,6 +652,15 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         std::vector<int64_t> order(ns);
         for (int64_t i = 0; i < ns; i++) order[i] = i;
         std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return tt[2 * x + 1] - tt[2 * x] > tt[2 * y + 1] - tt[2 * y]; });
+        std::vector<StepProf> pr(ns);
+        rt::d2h(pr.data(), a.st_prof, (size_t)ns * sizeof(StepProf), s);
+        rt::stream_sync(s);
+        rt::dfree(a.st_prof);
+        for (int r = 0; r < 3 && r < ns; r++) {
+            int64_t i = order[r];
+            fprintf(stderr, "[ldbg] prof strand %lld: links %.1f ms (%llu flagged), child+locate %.1f ms, junction choice %.1f ms (%llu)\n", (long long)i,
+                    pr[i].t_links / 1e5, pr[i].n_links, pr[i].t_child / 1e5, pr[i].t_choice / 1e5, pr[i].n_choice);
+        }
         for (int r = 0; r < 12 && r < ns; r++) {
             int64_t i = order[r];
             double ms = (tt[2 * i + 1] - tt[2 * i]) / 1e5;
