@@ -21,7 +21,7 @@ struct ldbg_engine {
     std::unique_ptr<CursorHost> cursor;
     explicit ldbg_engine(const ldbg_engine_config& c) : e(c) {}
 };
-struct ldbg_dfs_result { int unused; };
+struct ldbg_dfs_result { std::unique_ptr<DfsBatch> b; };
 
 namespace {
 thread_local std::string g_err;
@@ -257,14 +257,68 @@ ldbg_status ldbg_engine_walk_vertices(ldbg_engine* e, int64_t walk, int64_t capa
     return guard([&] { e->e.walk_vertices(walk, capacity, len, words, rec, copy, index); });
 }
 
-ldbg_status ldbg_engine_dfs_batch(ldbg_engine*, const char*, int64_t, const char*, const int64_t*, ldbg_dfs_result** out) {
-    return guard([&] { *out = nullptr; throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: the general DFS kernel is not built yet (DESIGN.md §Scope)"); });
+ldbg_status ldbg_engine_dfs_batch(ldbg_engine* e, const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets, ldbg_dfs_result** out) {
+    return guard([&] {
+        *out = nullptr;
+        // a full per-walk link store or frame stack is retried with a larger one (exactness is never traded away)
+        for (int attempt = 0;; attempt++) {
+            try {
+                std::unique_ptr<DfsBatch> b(e->e.dfs_batch(sources, n, sinks, sink_offsets));
+                *out = new ldbg_dfs_result{std::move(b)};
+                return;
+            } catch (const StatusError& se) {
+                const std::string what = se.what();
+                if (se.status == LDBG_ERR_CAPACITY && what == "LINKSTORE_FULL" && attempt < 8) { e->e.link_store_capacity *= 4; continue; }
+                if (se.status == LDBG_ERR_CAPACITY && what == "LOG_FULL" && e->e.dfs_log_blocks < (1 << 20)) { e->e.dfs_log_blocks *= 8; continue; }
+                if (se.status == LDBG_ERR_CAPACITY && what == "DEPTH_OVERFLOW" && e->e.dfs_max_depth < 4096) { e->e.dfs_max_depth *= 4; continue; }
+                if (se.status == LDBG_ERR_CAPACITY && what == "DEPTH_OVERFLOW")
+                    throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs recursion deeper than 4096 branches (the reference overflows its thread stack here)");
+                throw;
+            }
+        }
+    });
 }
-ldbg_status ldbg_dfs_result_sizes(const ldbg_dfs_result*, int64_t, int*, int64_t*, int64_t*) { g_err = "no dfs result"; return LDBG_ERR_UNSUPPORTED; }
-ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result*, int64_t, uint64_t*, int64_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*) { g_err = "no dfs result"; return LDBG_ERR_UNSUPPORTED; }
-ldbg_status ldbg_dfs_result_walk(const ldbg_dfs_result*, int64_t, const char*, int, char*, int64_t, int64_t*) { g_err = "no dfs result"; return LDBG_ERR_UNSUPPORTED; }
+static const DfsGraphHost& dfs_at(const ldbg_dfs_result* r, int64_t i) {
+    if (!r || !r->b) throw StatusError(LDBG_ERR_ARG, "no dfs result");
+    if (i < 0 || i >= (int64_t)r->b->results.size()) throw StatusError(LDBG_ERR_ARG, "dfs result index out of range");
+    return r->b->results[(size_t)i];
+}
+ldbg_status ldbg_dfs_result_sizes(const ldbg_dfs_result* r, int64_t i, int* is_null, int64_t* n_vertices, int64_t* n_edges) {
+    return guard([&] {
+        const DfsGraphHost& g = dfs_at(r, i);
+        if (is_null) *is_null = g.is_null ? 1 : 0;
+        if (n_vertices) *n_vertices = (int64_t)g.verts.size();
+        if (n_edges) *n_edges = (int64_t)g.edges.size();
+    });
+}
+ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result* r, int64_t i, uint64_t* kmer_words, int64_t* rec, int32_t* copy_index, int32_t* index,
+                                int32_t* edge_src, int32_t* edge_dst, int32_t* edge_color) {
+    return guard([&] {
+        const DfsGraphHost& g = dfs_at(r, i);
+        if (kmer_words && !g.words.empty()) memcpy(kmer_words, g.words.data(), g.words.size() * 8);
+        for (size_t v = 0; v < g.verts.size(); v++) {
+            if (rec) rec[v] = g.verts[v].rec;
+            if (copy_index) copy_index[v] = g.verts[v].copy;
+            if (index) index[v] = g.verts[v].index;
+        }
+        for (size_t x = 0; x < g.edges.size(); x++) {
+            if (edge_src) edge_src[x] = g.edges[x].src;
+            if (edge_dst) edge_dst[x] = g.edges[x].dst;
+            if (edge_color) edge_color[x] = g.edges[x].color;
+        }
+    });
+}
+ldbg_status ldbg_dfs_result_walk(const ldbg_dfs_result* r, int64_t i, const char* seed, int color, char* contig, int64_t capacity, int64_t* len) {
+    return guard([&] {
+        dfs_at(r, i);
+        const std::string c = r->b->walk_contig(i, seed, color);
+        if (len) *len = (int64_t)c.size();
+        if ((int64_t)c.size() + 1 > capacity) throw StatusError(LDBG_ERR_CAPACITY, "contig buffer too small: need " + std::to_string(c.size() + 1));
+        memcpy(contig, c.c_str(), c.size() + 1);
+    });
+}
 ldbg_status ldbg_dfs_result_free(ldbg_dfs_result* r) { delete r; return LDBG_OK; }
-ldbg_status ldbg_engine_dfs_kmers_traversed(const ldbg_engine*, int64_t* n) { *n = 0; return LDBG_OK; }
+ldbg_status ldbg_engine_dfs_kmers_traversed(const ldbg_engine* e, int64_t* n) { return guard([&] { *n = e->e.dfs_traversed(); }); }
 
 // ---- cursor
 static CursorHost& cursor_of(ldbg_engine* e) {

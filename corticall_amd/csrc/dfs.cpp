@@ -1,0 +1,918 @@
+// General depth-first search with a stopping rule: TraversalEngine.dfs(source, sinks...)
+// (J/utils/traversal/TraversalEngine.java:64-106) and its private recursive branch method (:356-482).
+//
+// Device side.  One strand = (seed, direction) per lane, exactly like the contig walks (walk.cpp), but a
+// branch that reaches a junction recurses into its children.  The recursion is an explicit stack of 64-byte
+// frames in HBM, touched only at junctions; the lane advances by micro-steps (one loop iteration of :373-481,
+// one child launch, or one entry of a visited-set undo) so that the 64 lanes of a wavefront keep working on
+// their own strands in lock step.
+//
+//  * visited (HashSet<CortexVertex>, copied into every child, :360): the strand's ONE visited table is shared by
+//    the whole recursion; what a branch added is taken out again when the branch returns (siblings must not see
+//    each other's vertices), by replaying the branch's own vertices from the log.
+//  * seen (cleared by the seek() that opens every branch when links are configured, :363-365): an epoch number in
+//    the table entries.
+//  * stopping rule instance per branch (:366): 12 bytes of state (stoppers.h), the parent's copy is kept in its frame.
+//  * output: an event log per strand — OPEN, the branch's vertices in order, the logs of the children that
+//    returned a graph, CLOSE; a branch that returns null truncates the log back to its OPEN.  The log fully
+//    determines the DirectedWeightedPseudograph the reference builds; the JGraphT container semantics
+//    (vertex/edge insertion order, Graphs.addGraph merges, index relabelling, OR/AND combination, :75-99) are
+//    replayed on the host from that log (assemble_* below).
+#include <algorithm>
+#include <functional>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "stoppers.h"
+#include "strand.h"
+
+namespace ldbg {
+
+#define DFS_MARK (1ull << 63)
+#define DFS_OPEN (DFS_MARK | 1ull)
+#define DFS_CLOSE (DFS_MARK | 2ull)
+#define DFS_KMER (DFS_MARK | 3ull)   // the W entries that follow are the packed k-mer of the vertex before (it has no record)
+
+enum : uint8_t { PH_ITER = 0, PH_CHILD = 1, PH_UNDO = 2 };
+
+struct DfsFrame {
+    Node cv;                              // the branch's last vertex (where it forked)
+    uint32_t log_start, size, gV, nlin;
+    StopState ss;
+    uint8_t child[4];                     // child bases in the reference's iteration order
+    uint8_t nchild, next, any, adj;
+    uint32_t pad[2];
+};
+static_assert(sizeof(DfsFrame) == 64, "frame is one cache line");
+
+struct DfsArgs {
+    WalkArgs w;
+    StopEnv env;
+    const int64_t* sink_off;       // [n + 1] (nullptr: no sinks)
+    DfsFrame* frames;              // [n_slots][max_depth]
+    int max_depth;
+    int n_trav;
+    uint8_t trav_order[LDBG_MAX_COLORS];   // traversal colours in LinkedHashSet order
+};
+
+template <int W>
+struct DfsLane {
+    StrandState st;
+    Kmer<W> nullk;                 // k-mer of st.cv when it has no record
+    StopState ss;
+    int64_t sink_lo, sink_hi;
+    uint32_t depth, size, nlin, log_start;
+    uint32_t undo_pos, undo_left;
+    uint8_t phase;
+    bool result, last_prev;
+};
+
+// ---- Java iteration order of the neighbour vertices (TraversalEngine.getNextVertices/getPrevVertices :147-239):
+// HashSet<CortexVertex> over HashMap<CortexByteKmer, ...> over per-colour HashSet<CortexByteKmer> over
+// HashSet<Byte>.  All tables have 16 buckets (at most 4 entries), so the order is a lexicographic key:
+//   (bucket of CortexVertex.hashCode, bucket of the k-mer's Arrays.hashCode, first colour that has the edge,
+//    rank of the base in HashSet<Byte> order A,C,T,G)
+LDBG_HOSTDEV uint32_t jbucket16(uint32_t h) { return (h ^ (h >> 16)) & 15u; }
+LDBG_HOSTDEV uint32_t bswap64_fold(uint64_t w) {    // Long.hashCode of the byte-swapped word (CortexRecord keeps big-endian longs)
+    uint64_t u = __builtin_bswap64(w);
+    return (uint32_t)(u ^ (u >> 32));
+}
+template <int W>
+LDBG_HOSTDEV uint32_t record_java_hash(const GraphView& g, int64_t idx) {   // CortexRecord.hashCode :398-408
+    uint32_t hl = 1, hi = 1, hb = 1;
+    const Kmer<W> key = graph_key<W>(g, idx);
+    for (int i = 0; i < W; i++) hl = 31u * hl + bswap64_fold(kmer_word<W>(key, i));
+    for (int c = 0; c < g.C; c++) hi = 31u * hi + graph_cov(g, idx, c);
+    for (int c = 0; c < g.C; c++) hb = 31u * hb + (uint32_t)(int32_t)(int8_t)graph_edges(g, idx, c);
+    return hl - hi + hb;
+}
+template <int W>
+LDBG_DEV int order_children(const DfsArgs& a, VisitedTable& vt, const Node& cv, bool fwd, uint32_t avs_mask, uint8_t* out) {
+    const EngineView& e = a.w.e;
+    uint32_t keys[4];
+    int n = 0;
+    // per-colour neighbour masks of cv (as node_fill, colour by colour)
+    const uint8_t* ed = graph_row(e.g, cv.idx) + e.g.edges_off;
+    const bool fj = cv.fj != 0;
+    for (unsigned b = 0; b < 4; b++) {
+        if (!((avs_mask >> b) & 1u)) continue;
+        uint32_t rank = 0xFFu;
+        // colours in the order the reference concatenates them: traversal colours (insertion order) if they
+        // give any neighbour, else recruitment colours (ascending)
+        const uint32_t tmask = fwd ? cv.next_mask : cv.prev_mask;
+        (void)tmask;
+        bool from_trav = false;
+        for (int t = 0; t < a.n_trav && !from_trav; t++) {
+            const uint32_t eb = ed[a.trav_order[t]];
+            const uint32_t lo = eb & 0xf, hi = eb >> 4;
+            const uint32_t f = !fj ? lo : hi, rn = !fj ? hi : lo;
+            const uint32_t r = ((rn & 1u) << 3) | ((rn & 2u) << 1) | ((rn & 4u) >> 1) | ((rn & 8u) >> 3);
+            if ((fwd ? f : r) != 0) from_trav = true;
+        }
+        if (from_trav) {
+            for (int t = 0; t < a.n_trav; t++) {
+                const uint32_t eb = ed[a.trav_order[t]];
+                const uint32_t lo = eb & 0xf, hi = eb >> 4;
+                const uint32_t f = !fj ? lo : hi, rn = !fj ? hi : lo;
+                const uint32_t r = ((rn & 1u) << 3) | ((rn & 2u) << 1) | ((rn & 4u) >> 1) | ((rn & 8u) >> 3);
+                if ((((fwd ? f : r) >> b) & 1u) && rank == 0xFFu) rank = (uint32_t)t;
+            }
+        } else {
+            uint32_t t = 0;
+            for (int c = 0; c < e.g.C; c++) {
+                if (!((e.recruit_mask >> c) & 1u)) continue;
+                const uint32_t eb = ed[c];
+                const uint32_t lo = eb & 0xf, hi = eb >> 4;
+                const uint32_t f = !fj ? lo : hi, rn = !fj ? hi : lo;
+                const uint32_t r = ((rn & 1u) << 3) | ((rn & 2u) << 1) | ((rn & 4u) >> 1) | ((rn & 8u) >> 3);
+                if ((((fwd ? f : r) >> b) & 1u) && rank == 0xFFu) rank = t;
+                t++;
+            }
+        }
+        const Kmer<W> ck = child_kmer<W>(e, cv, fwd, b);
+        const uint32_t sh = kmer_java_hash<W>(ck, e.g.k);
+        Node x;
+        node_child(e, cv, fwd, b, x);
+        uint32_t vh = sh;
+        vh = 31u * vh + (x.idx >= 0 ? record_java_hash<W>(e.g, x.idx) : 0u);   // CortexVertex.hashCode :82-91
+        vh = 31u * vh; vh = 31u * vh; vh = 31u * vh; vh = 31u * vh;            // locus, sources, copyIndex 0, index 0
+        const uint32_t actg = b == 0 ? 0u : (b == 1 ? 1u : (b == 3 ? 2u : 3u));
+        keys[n] = (jbucket16(vh) << 24) | (jbucket16(sh) << 16) | ((rank & 0xFFu) << 8) | (actg << 2) | b;
+        n++;
+    }
+    // insertion sort of at most 4 keys
+    for (int i = 1; i < n; i++) {
+        const uint32_t x = keys[i];
+        int j = i - 1;
+        while (j >= 0 && keys[j] > x) { keys[j + 1] = keys[j]; j--; }
+        keys[j + 1] = x;
+    }
+    for (int i = 0; i < n; i++) out[i] = (uint8_t)(keys[i] & 3u);
+    return n;
+}
+
+// ---- log helpers
+// a failed append: the strand's own block table is full (the host retries with a longer one) or the shared pool ran dry
+LDBG_DEV uint32_t append_failure(const DfsArgs& a, const StrandState& st) {
+    return (int)(st.pw.n / LDBG_PATH_BLOCK) >= a.w.max_blocks ? (uint32_t)ST_LOG_FULL : (uint32_t)ST_POOL_FULL;
+}
+template <int W>
+LDBG_DEV bool log_vertex(const DfsArgs& a, DfsLane<W>& L, const Node& v, const Kmer<W>& nk) {
+    StrandState& st = L.st;
+    if (!path_append(a.w, st.s, st.pw, pack_vertex(v))) return false;
+    if (v.idx < 0) {
+        if (!path_append(a.w, st.s, st.pw, DFS_KMER)) return false;
+        for (int i = 0; i < W; i++) if (!path_append(a.w, st.s, st.pw, kmer_word<W>(nk, i))) return false;
+    }
+    return true;
+}
+
+// dfs(cv, goForward, size, depth, visited, sinks) entered: TraversalEngine.java:356-371
+template <int W>
+LDBG_DEV void open_branch(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, const Node& av, const Kmer<W>& avk, uint32_t size) {
+    StrandState& st = L.st;
+    const EngineView& e = a.w.e;
+    if ((int)L.depth >= a.max_depth) { st.status = ST_DEPTH_OVERFLOW; return; }
+    L.log_start = st.pw.n;
+    L.size = size;
+    L.nlin = 1;
+    L.ss.flags = 0; L.ss.a = 0; L.ss.b = 0;
+    L.last_prev = false;
+    st.gV = 0;
+    st.cv = av;
+    L.nullk = avk;
+    if (!path_append(a.w, st.s, st.pw, DFS_OPEN) || !log_vertex<W>(a, L, av, avk)) { st.status = append_failure(a, st); return; }
+    st.quirk |= av.flip && !av.fj;
+    if (e.cursor_on) {                                   // seek(cv.getKmerAsString()) :363-365
+        if (++st.cu.epoch > LDBG_VT_EPOCH_MAX) {         // epoch numbers used up: forget every `seen` mark
+            for (uint32_t i = 0; i <= st.vt.mask; i++) st.vt.tab[i] = vt_with_seen(st.vt.tab[i], 0);
+            st.cu.epoch = 1;
+        }
+        cursor_seek(e, st.cu, ls, st.vt, st.cv, st.fwd);
+    }
+    L.phase = PH_ITER;
+}
+
+// the branch returns: a graph (success) or null
+template <int W>
+LDBG_DEV bool end_branch(const DfsArgs& a, DfsLane<W>& L, bool success) {
+    StrandState& st = L.st;
+    L.result = success;
+    if (L.depth == 0) {
+        if (success) { if (!path_append(a.w, st.s, st.pw, DFS_CLOSE)) st.status = append_failure(a, st); }
+        else { path_truncate(a.w, st.s, st.pw, 0); st.branch_null = true; }
+        return true;
+    }
+    L.phase = PH_UNDO;
+    L.undo_pos = L.log_start + 1;
+    L.undo_left = L.last_prev ? L.nlin - 1 : L.nlin;
+    return false;
+}
+
+// one micro-step; returns true when the strand has ended
+template <int W>
+LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t slot) {
+    StrandState& st = L.st;
+    const EngineView& e = a.w.e;
+    const bool fwd = st.fwd;
+    if (st.status != ST_OK) return true;
+    if ((st.vt.used + 8) * 4 > (st.vt.mask + 1) * 3) { st.status = ST_TABLE_FULL; return true; }   // at its maximum size and filling up
+
+    if (L.phase == PH_UNDO) {
+        if (L.undo_left > 0) {
+            const uint64_t en = path_read(a.w, st.s, L.undo_pos);
+            if (en == DFS_KMER) { L.undo_pos += 1 + W; return false; }
+            L.undo_pos++;
+            L.undo_left--;
+            const int64_t idx = path_idx(en);
+            if (idx >= 0) {
+                const uint32_t h = vt_locate(st.vt, idx, path_flip(en));
+                const uint64_t ev = st.vt.tab[h];
+                st.vt.tab[h] = vt_with_count(ev, vt_count_e(ev) - 1);
+            }
+            return false;
+        }
+        if (L.result) { if (!path_append(a.w, st.s, st.pw, DFS_CLOSE)) { st.status = append_failure(a, st); return true; } }
+        else path_truncate(a.w, st.s, st.pw, L.log_start);
+        L.depth--;
+        DfsFrame& F = a.frames[(size_t)slot * a.max_depth + L.depth];
+        if (L.result) F.any = 1;
+        st.cv = F.cv; st.gV = F.gV;
+        L.nlin = F.nlin; L.log_start = F.log_start; L.size = F.size; L.ss = F.ss;
+        L.last_prev = false;
+        L.phase = PH_CHILD;
+        return false;
+    }
+
+    if (L.phase == PH_CHILD) {
+        DfsFrame& F = a.frames[(size_t)slot * a.max_depth + L.depth];
+        if (F.next < F.nchild) {
+            const unsigned b = F.child[F.next];
+            F.next++;
+            Node av;
+            node_child_located(e, st.vt, F.cv, fwd, b, av);
+            Kmer<W> avk;
+#pragma unroll
+            for (int i = 0; i < W; i++) avk.w[i] = 0;
+            if (av.idx < 0) avk = child_kmer<W>(e, F.cv, fwd, b);
+            const uint32_t size = F.size + F.gV;
+            L.depth++;
+            open_branch<W>(a, L, ls, av, avk, size);
+            if (st.cv.npe && st.status == ST_OK) st.status = ST_NULLPTR;
+            return st.status != ST_OK;
+        }
+        bool ok = F.any != 0;
+        if (!ok) {      // hasTraversalSucceeded with childrenWereTraversed = true :462-468
+            TravState tc{(int)(F.size + F.gV), (int)L.depth, (int)F.gV, (int)F.adj, true, F.gV > (uint32_t)e.max_len};
+            StopEval<W> ev(e, a.env, L.sink_lo, L.sink_hi, st.cv, L.nullk);
+            ok = ev.has_succeeded(L.ss, tc);
+            if (ev.status != ST_OK) { st.status = ev.status; return true; }
+        }
+        return end_branch<W>(a, L, ok);
+    }
+
+    // ---- PH_ITER: one iteration of the do-loop :373-481
+    st.iters++;
+    Node& cv = st.cv;
+    const uint32_t m = fwd ? cv.next_mask : cv.prev_mask;
+    int adj = 0;
+    uint32_t avs_mask = 0;
+    Node av = cv;
+    if (e.cursor_on && st.cu.has) {                     // :379-407
+        av = cursor_step<W>(e, st.cu, ls, st.vt, fwd);
+        if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
+        const int cnt = node_count(st.vt, av);          // first copyIndex not in visited
+        av.copy = fwd ? cnt : -cnt;
+        adj = 1;
+    } else {
+        for (unsigned b = 0; b < 4; b++) {
+            if (!((m >> b) & 1u)) continue;
+            Node x;
+            node_child_located(e, st.vt, cv, fwd, b, x);
+            if (node_count(st.vt, x) > 0) continue;     // avs.removeAll(visited) :416-422
+            adj++;
+            av = x;
+            avs_mask |= 1u << b;
+        }
+    }
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    const uint64_t ecv = cv.idx >= 0 ? st.vt.tab[cv.vslot] : 0ull;
+    const bool previously = acopy < vt_count_e(ecv);    // :424
+    if (!previously && cv.idx >= 0) {
+        if (acopy + 1 > 32767) { st.status = ST_COPY_OVERFLOW; return true; }
+        st.vt.tab[cv.vslot] = vt_with_count(ecv, acopy + 1);   // visited.add(cv) :425
+    }
+    L.last_prev = previously;
+    bool succ = false, keep = false;
+    if (!previously) {
+        TravState ts{(int)(L.size + st.gV), (int)L.depth, (int)st.gV, adj, false, st.gV > (uint32_t)e.max_len};
+        StopEval<W> ev(e, a.env, L.sink_lo, L.sink_hi, cv, L.nullk);
+        succ = ev.has_succeeded(L.ss, ts);
+        bool fail = false;
+        if (ev.status == ST_OK) fail = ev.has_failed(L.ss, ts);
+        if (ev.status != ST_OK) { st.status = ev.status; return true; }
+        keep = !succ && !fail;
+    }
+    if (keep) {
+        if (adj == 1) {                                 // connectVertex + advance :432-440
+            Kmer<W> avk = L.nullk;
+            if (av.idx < 0) avk = child_kmer<W>(e, cv, fwd, av.base);
+            if (!log_vertex<W>(a, L, av, avk)) { st.status = append_failure(a, st); return true; }
+            st.gV = st.gV == 0 ? 2 : st.gV + 1;
+            L.nlin++;
+            st.quirk |= av.flip && !av.fj;
+            L.nullk = avk;
+            cv = av;
+            if (cv.npe) { st.status = ST_NULLPTR; return true; }
+            return false;
+        }
+        // a junction (or a dead end the rule wants to look beyond): children in the reference's order :441-468
+        DfsFrame& F = a.frames[(size_t)slot * a.max_depth + L.depth];
+        F.cv = cv; F.log_start = L.log_start; F.size = L.size; F.gV = st.gV; F.nlin = L.nlin; F.ss = L.ss;
+        F.next = 0; F.any = 0; F.adj = (uint8_t)adj;
+        F.nchild = adj > 0 ? (uint8_t)order_children<W>(a, st.vt, cv, fwd, avs_mask, F.child) : 0;
+        L.phase = PH_CHILD;
+        return false;
+    }
+    return end_branch<W>(a, L, !previously && succ);    // :470-478
+}
+
+template <int W>
+LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t s) {
+    StrandState& st = L.st;
+    const EngineView& e = a.w.e;
+    st.s = s;
+    st.fwd = (s & 1) != 0;
+    st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false; st.quirk = false;
+    st.pw.cur = nullptr; st.pw.n = 0; st.pw.nblk = 0;
+    st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true; st.cu.epoch = 0; st.cu.prof = nullptr;
+    ls_clear(ls);
+    L.depth = 0;
+    L.sink_lo = a.sink_off ? a.sink_off[s >> 1] : 0;
+    L.sink_hi = a.sink_off ? a.sink_off[(s >> 1) + 1] : 0;
+    if (!vt_alloc(a.w, st.vt, a.w.vcap_init < a.w.vcap_max ? a.w.vcap_init : a.w.vcap_max)) { st.status = ST_POOL_FULL; return false; }
+    const uint64_t* sw = a.w.seeds + (s >> 1) * W;
+    Kmer<W> sk;
+#pragma unroll
+    for (int i = 0; i < W; i++) sk.w[i] = sw[i];
+    Node v;
+    if (sw[0] != ~0ull) { node_find<W>(e, sk, v); node_locate(st.vt, v); }
+    else node_null(e, v);
+    if (v.npe) { st.status = ST_NULLPTR; return false; }
+    open_branch<W>(a, L, ls, v, sk, 0);
+    return st.status == ST_OK;
+}
+
+template <int W>
+LDBG_KERNEL void k_dfs(DfsArgs a) {
+    const int64_t slot = global_tid();
+    if (slot >= a.w.n_slots) return;
+#ifndef LDBG_HOSTSIM
+    __shared__ LsElem lds_store[LDBG_LS_FAST * 64];
+    LsElem* fast = lds_store + (threadIdx.x & 63u);
+    const uint32_t fast_stride = 64;
+#else
+    static LsElem lds_store[LDBG_LS_FAST];
+    LsElem* fast = lds_store;
+    const uint32_t fast_stride = 1;
+#endif
+    LinkStoreDev ls;
+    ls.fast = fast; ls.fast_cap = LDBG_LS_FAST; ls.fast_stride = fast_stride;
+    ls.el = a.w.ls + (size_t)slot * a.w.ecap;
+    ls.cap = a.w.ecap + LDBG_LS_FAST;
+    ls_clear(ls);
+    DfsLane<W> L;
+    L.st.vt.tab = nullptr; L.st.vt.mask = 0; L.st.vt.used = 0; L.st.status = ST_OK;
+    L.phase = PH_ITER;
+    bool active = false, exhausted = false;
+    while (wave_ballot(active || !exhausted) != 0ull) {
+        if (!active && !exhausted) {
+            const int64_t fi = (int64_t)atomic_add_u64(a.w.next_strand, 1ull);
+            if (fi >= a.w.n_strands) exhausted = true;
+            else {
+                const int64_t s = (int64_t)(((unsigned __int128)fi * (unsigned __int128)a.w.fetch_stride) % (unsigned __int128)a.w.n_strands);
+                const bool fwd = (s & 1) != 0;
+                if ((fwd && !a.w.run_fwd) || (!fwd && !a.w.run_rev)) {
+                    a.w.strand_n[s] = 0; a.w.status[s] = ST_BRANCH_NULL; a.w.iters[s] = 0; a.w.quirk[s] = 0;
+                } else {
+                    active = dfs_begin<W>(a, L, ls, s);
+                    if (!active) strand_finish(a.w, L.st);
+                }
+            }
+        }
+        wave_grow_tables(a.w, L.st, active);
+        if (active && dfs_step<W>(a, L, ls, slot)) { strand_finish(a.w, L.st); active = false; }
+    }
+}
+
+// per sink k-mer: its (record, orientation) key for the rules' sink tests
+template <int W>
+LDBG_KERNEL void k_sink_nodes(EngineView e, const uint64_t* words, int64_t n, uint64_t* keys) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        uint64_t key = 0;
+        if (words[i * W] != ~0ull) {
+            Kmer<W> sk;
+            for (int w = 0; w < W; w++) sk.w[w] = words[i * W + w];
+            Node v;
+            node_find<W>(e, sk, v);
+            if (v.idx >= 0) {
+                if (graph_row(e.g, v.idx)[e.g.flags_off] & LDBG_ROW_PALINDROME) v.flip = 0;
+                key = vt_key(v.idx, v.flip != 0);
+            }
+        }
+        keys[i] = key;
+    }
+}
+
+// bit i: record i of graph g is a record of the ROI graph
+template <int W>
+LDBG_KERNEL void k_roi_bits(GraphView g, GraphView rois, uint32_t* bits) {
+    for (int64_t i = global_tid(); i < rois.N; i += global_nthreads()) {
+        const Kmer<W> key = graph_key<W>(rois, i);
+        const int64_t idx = graph_find_canonical<W>(g, key);
+        if (idx >= 0) atomic_or_u32(&bits[idx >> 5], 1u << (idx & 31));
+    }
+}
+
+// k-mer words + coverages of a list of vertices (key = ((record + 1) << 1) | flip)
+template <int W>
+LDBG_KERNEL void k_gather_vertices(GraphView g, const uint64_t* keys, int64_t n, uint64_t* words, uint32_t* cov) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        const int64_t idx = (int64_t)(keys[i] >> 1) - 1;
+        Kmer<W> km = graph_key<W>(g, idx);
+        if (keys[i] & 1ull) km = kmer_revcomp<W>(km, g.k);
+        for (int w = 0; w < W; w++) words[i * W + w] = kmer_word<W>(km, w);
+        for (int c = 0; c < g.C; c++) cov[i * g.C + c] = graph_cov(g, idx, c);
+    }
+}
+
+// ------------------------------------------------------------------ host: graph assembly from the event logs
+namespace {
+
+struct VKey {
+    uint64_t id;       // ((record + 1) << 1) | flip, or (1 << 63) | interned k-mer number for a vertex without a record
+    int32_t copy, index;
+    bool operator==(const VKey& o) const { return id == o.id && copy == o.copy && index == o.index; }
+};
+struct VKeyHash {
+    size_t operator()(const VKey& k) const {
+        uint64_t x = k.id * 0x9E3779B97F4A7C15ull ^ ((uint64_t)(uint32_t)k.copy << 32 | (uint32_t)k.index) * 0xC2B2AE3D27D4EB4Full;
+        return (size_t)(x ^ (x >> 29));
+    }
+};
+struct PairHash { size_t operator()(const std::pair<int, int>& p) const { return (size_t)((uint64_t)(uint32_t)p.first << 32 | (uint32_t)p.second) * 0x9E3779B97F4A7C15ull; } };
+
+// the part of JGraphT's DirectedWeightedPseudograph the reference relies on: insertion-ordered vertex and edge
+// sets, addVertex/addEdge that refuse duplicates (CortexVertex.equals :67-80, CortexEdge.equals :42-57 — an edge
+// equals another with the same two endpoints in EITHER direction and the same colour), Graphs.addGraph
+struct HGraph {
+    std::vector<VKey> verts;
+    std::vector<DfsEdge> edges;
+    std::unordered_map<VKey, int, VKeyHash> vmap;
+    std::unordered_set<std::pair<int, int>, PairHash> dir;
+    std::unordered_set<uint64_t> und;
+    int add_vertex(const VKey& v) {
+        auto it = vmap.find(v);
+        if (it != vmap.end()) return it->second;
+        verts.push_back(v);
+        vmap.emplace(v, (int)verts.size() - 1);
+        return (int)verts.size() - 1;
+    }
+    bool contains_edge(int s, int t) const { return dir.count({s, t}) != 0; }
+    void add_edge(int s, int t, int color) {
+        const uint64_t key = ((uint64_t)(uint32_t)std::min(s, t) << 38) | ((uint64_t)(uint32_t)std::max(s, t) << 12) | (uint64_t)(uint32_t)(color & 0xFFF);
+        if (!und.insert(key).second) return;
+        dir.insert({s, t});
+        edges.push_back({s, t, color});
+    }
+    void add_graph(const HGraph& o) {
+        for (auto& v : o.verts) add_vertex(v);
+        for (auto& ed : o.edges) add_edge(add_vertex(o.verts[ed.src]), add_vertex(o.verts[ed.dst]), ed.color);
+    }
+    // connectVertex(g, cv, {pv} or {nv}) :494-516
+    void connect(const VKey& cv, const VKey& av, bool fwd, int color) {
+        const int ci = add_vertex(cv);
+        const int ai = add_vertex(av);
+        if (fwd) { if (!contains_edge(ci, ai)) add_edge(ci, ai, color); }
+        else { if (!contains_edge(ai, ci)) add_edge(ai, ci, color); }
+    }
+};
+
+struct LogParser {
+    const uint64_t* log;
+    int64_t n, pos = 0;
+    int W, color;
+    bool fwd;
+    std::vector<std::vector<uint64_t>>& null_kmers;    // interned k-mers of vertices without a record
+    std::unordered_map<std::string, uint32_t>& null_ids;
+
+    VKey read_vertex() {
+        const uint64_t en = log[pos++];
+        VKey v;
+        v.copy = path_copy(en); v.index = 0;
+        const int64_t idx = path_idx(en);
+        if (idx >= 0) v.id = ((uint64_t)(idx + 1) << 1) | (path_flip(en) ? 1ull : 0ull);
+        else {
+            if (pos >= n || log[pos] != DFS_KMER) throw StatusError(LDBG_ERR_HIP, "dfs log: a vertex without a record lacks its k-mer");
+            pos++;
+            std::string s((const char*)(log + pos), (size_t)W * 8);
+            auto it = null_ids.find(s);
+            uint32_t id;
+            if (it == null_ids.end()) {
+                id = (uint32_t)null_kmers.size();
+                null_kmers.emplace_back(log + pos, log + pos + W);
+                null_ids.emplace(s, id);
+            } else id = it->second;
+            pos += W;
+            v.id = DFS_MARK | id;
+        }
+        return v;
+    }
+    // one branch: the graph dfs(...) returned, and the vertex it started from
+    void parse_branch(HGraph& g, VKey& v0) {
+        if (pos >= n || log[pos] != DFS_OPEN) throw StatusError(LDBG_ERR_HIP, "dfs log: OPEN expected");
+        pos++;
+        v0 = read_vertex();
+        VKey cv = v0;
+        while (pos < n && !(log[pos] & DFS_MARK)) {
+            VKey av = read_vertex();
+            g.connect(cv, av, fwd, color);
+            cv = av;
+        }
+        while (pos < n && log[pos] == DFS_OPEN) {
+            HGraph branch;
+            VKey c0;
+            parse_branch(branch, c0);
+            branch.connect(cv, c0, fwd, color);         // :447-453
+            g.add_graph(branch);                        // Graphs.addGraph(g, branch) :454
+        }
+        if (pos >= n || log[pos] != DFS_CLOSE) throw StatusError(LDBG_ERR_HIP, "dfs log: CLOSE expected");
+        pos++;
+    }
+};
+
+// java.util.TimSort on fewer than 32 elements: countRunAndMakeAscending + binarySort.  toWalk's comparators
+// never return 0 (TraversalUtils.java:424-428), so the result depends on the algorithm, restated here.
+template <class T, class Cmp>
+void java_small_sort(std::vector<T>& v, Cmp cmp) {
+    const int n = (int)v.size();
+    if (n < 2) return;
+    int hi = 1;
+    if (cmp(v[hi++], v[0]) < 0) {
+        while (hi < n && cmp(v[hi], v[hi - 1]) < 0) hi++;
+        std::reverse(v.begin(), v.begin() + hi);
+    } else {
+        while (hi < n && cmp(v[hi], v[hi - 1]) >= 0) hi++;
+    }
+    for (int start = hi; start < n; start++) {
+        T pivot = v[start];
+        int l = 0, r = start;
+        while (l < r) { int mid = (l + r) >> 1; if (cmp(pivot, v[mid]) < 0) r = mid; else l = mid + 1; }
+        for (int i = start; i > l; i--) v[i] = v[i - 1];
+        v[l] = pivot;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host: Engine::dfs_batch
+static uint32_t next_pow2_u(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)std::min<uint64_t>(p, 1ull << 31); }
+static int grid_of(int64_t n, int block, int max_blocks) {
+    int64_t b = (n + block - 1) / block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, max_blocks));
+}
+
+void Engine::build_roi_bits() {
+    if (!rois || d_roi_bits_) return;
+    const GraphView& g = graph->view;
+    if (rois->hdr.k != graph->hdr.k) throw StatusError(LDBG_ERR_ARG, "the ROI graph must have the k-mer size of the traversed graph");
+    if (rois->device != graph->device) throw StatusError(LDBG_ERR_ARG, "the ROI graph must live on the device of the traversed graph");
+    rt::stream_t s = graph->stream;
+    const size_t words = (size_t)((g.N + 31) / 32 + 1);
+    d_roi_bits_ = rt::dmalloc(words * 4);
+    rt::dmemset(d_roi_bits_, 0, words * 4, s);
+    GraphView exact = g;
+    exact.java_tiny = 0;           // set membership, not findRecord: no Q1 here
+    if (rois->view.N > 0) {
+        const int grid = grid_of(rois->view.N, 256, 4096);
+        switch (g.W) {
+            case 1: LDBG_LAUNCH(k_roi_bits<1>, grid, 256, s, exact, rois->view, (uint32_t*)d_roi_bits_); break;
+            case 2: LDBG_LAUNCH(k_roi_bits<2>, grid, 256, s, exact, rois->view, (uint32_t*)d_roi_bits_); break;
+            case 3: LDBG_LAUNCH(k_roi_bits<3>, grid, 256, s, exact, rois->view, (uint32_t*)d_roi_bits_); break;
+            default: LDBG_LAUNCH(k_roi_bits<4>, grid, 256, s, exact, rois->view, (uint32_t*)d_roi_bits_); break;
+        }
+    }
+    rt::stream_sync(s);
+}
+
+DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets) {
+    if (cfg.connect_all_neighbors) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: connectAllNeighbors is not supported on the device path");
+    if (cfg.n_secondary > 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: secondary colours are not supported on the device path");
+    rt::set_device(graph->device);
+    build_roi_bits();
+    const int k = graph->hdr.k, W = graph->hdr.W;
+    std::vector<uint64_t> words((size_t)n * W);
+    for (int64_t i = 0; i < n; i++)
+        if (!ascii_to_words(sources + i * k, k, &words[i * W], W)) { for (int w = 0; w < W; w++) words[i * W + w] = ~0ull; }
+    const int64_t nsinks = sink_offsets ? sink_offsets[n] : 0;
+    std::vector<uint64_t> sink_words((size_t)std::max<int64_t>(1, nsinks) * W);
+    for (int64_t i = 0; i < nsinks; i++)
+        if (!ascii_to_words(sinks + i * k, k, &sink_words[i * W], W)) { for (int w = 0; w < W; w++) sink_words[i * W + w] = ~0ull; }
+
+    std::unique_ptr<DfsBatch> out(new DfsBatch);
+    out->k = k; out->W = W; out->C = graph->hdr.C;
+    out->results.resize((size_t)n);
+    out->traversed = 0;
+    std::vector<std::pair<int64_t, int64_t>> todo{{0, n}};
+    while (!todo.empty()) {
+        auto [first, cnt] = todo.back();
+        todo.pop_back();
+        if (cnt <= 0) continue;
+        if (!dfs_chunk(words, sink_words, sink_offsets, first, cnt, *out)) {
+            if (cnt == 1) throw StatusError(LDBG_ERR_HIP, "dfs: pools too small for a single seed: not enough device memory");
+            todo.push_back({first + cnt / 2, cnt - cnt / 2});
+            todo.push_back({first, cnt / 2});
+        }
+    }
+    dfs_traversed_ += out->traversed;
+    return out.release();
+}
+
+// returns false when a pool ran dry (the caller splits the chunk)
+bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
+                       int64_t first, int64_t n, DfsBatch& out) {
+    const int W = graph->hdr.W, C = graph->hdr.C;
+    rt::stream_t s = graph->stream;
+    const int64_t ns = 2 * n;
+    // a strand's visited table holds the vertices of one root-to-leaf chain of branches
+    const uint64_t chain = std::min<uint64_t>((uint64_t)(cfg.max_branch_length + 12) * 64ull, (uint64_t)graph->view.N * 2 + 64);
+    const uint32_t vcap_max = std::max<uint32_t>(64u, next_pow2_u(2ull * chain));
+    // entries one strand's log may hold: the vertices of every branch that returned a graph
+    const int max_blocks = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(dfs_log_blocks, (((int64_t)cfg.max_branch_length + 2) * 8 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK + 1));
+    ensure_scratch(ns, link_store_capacity, max_blocks);
+    if (vpool_dirty_ > 0) rt::dmemset(d_vpool_, 0, (size_t)std::min<uint64_t>(vpool_dirty_, vpool_entries_) * 8, s);
+
+    struct Tmp { std::vector<void*> p; ~Tmp() { for (void* x : p) rt::dfree(x); } void* get(size_t nbytes) { void* x = rt::dmalloc(nbytes); p.push_back(x); return x; } } tmp;
+    uint64_t* d_seeds = (uint64_t*)tmp.get((size_t)n * W * 8);
+    rt::h2d(d_seeds, &seed_words[first * W], (size_t)n * W * 8, s);
+    const int64_t sink_lo = sink_offsets ? sink_offsets[first] : 0, sink_hi = sink_offsets ? sink_offsets[first + n] : 0;
+    const int64_t nsk = sink_hi - sink_lo;
+    uint64_t* d_sink_words = (uint64_t*)tmp.get((size_t)std::max<int64_t>(1, nsk) * W * 8);
+    uint64_t* d_sink_keys = (uint64_t*)tmp.get((size_t)std::max<int64_t>(1, nsk) * 8);
+    int64_t* d_sink_off = nullptr;
+    if (sink_offsets) {
+        std::vector<int64_t> off((size_t)n + 1);
+        for (int64_t i = 0; i <= n; i++) off[i] = sink_offsets[first + i] - sink_lo;
+        d_sink_off = (int64_t*)tmp.get((size_t)(n + 1) * 8);
+        rt::h2d(d_sink_off, off.data(), (size_t)(n + 1) * 8, s);
+        rt::stream_sync(s);    // `off` leaves scope
+        if (nsk > 0) {
+            rt::h2d(d_sink_words, &sink_words[sink_lo * W], (size_t)nsk * W * 8, s);
+            const int g = grid_of(nsk, 256, 1024);
+            switch (W) {
+                case 1: LDBG_LAUNCH(k_sink_nodes<1>, g, 256, s, view, (const uint64_t*)d_sink_words, nsk, d_sink_keys); break;
+                case 2: LDBG_LAUNCH(k_sink_nodes<2>, g, 256, s, view, (const uint64_t*)d_sink_words, nsk, d_sink_keys); break;
+                case 3: LDBG_LAUNCH(k_sink_nodes<3>, g, 256, s, view, (const uint64_t*)d_sink_words, nsk, d_sink_keys); break;
+                default: LDBG_LAUNCH(k_sink_nodes<4>, g, 256, s, view, (const uint64_t*)d_sink_words, nsk, d_sink_keys); break;
+            }
+        }
+    }
+    uint64_t* d_term = (uint64_t*)tmp.get((size_t)ns * W * 8);
+    uint32_t* d_strand_n = (uint32_t*)tmp.get((size_t)ns * 4);
+    uint32_t* d_status = (uint32_t*)tmp.get((size_t)ns * 4);
+    uint32_t* d_iters = (uint32_t*)tmp.get((size_t)ns * 4);
+    uint8_t* d_quirk = (uint8_t*)tmp.get((size_t)ns);
+    unsigned long long* d_ctr = (unsigned long long*)tmp.get(32);
+    rt::dmemset(d_ctr, 0, 32, s);
+
+    DfsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w.e = view;
+    a.w.e.dbg = 0;
+    a.w.seeds = d_seeds;
+    a.w.n_strands = ns;
+    a.w.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
+    a.w.n_slots = std::min<int64_t>(a.w.n_slots, (int64_t)3 * 256 * 64);
+    a.w.n_slots = std::max<int64_t>(64, (a.w.n_slots / 64) * 64);
+    {
+        auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
+        int64_t stp = 7919;
+        while (gcd(stp, ns) != 1) stp++;
+        a.w.fetch_stride = stp % ns ? stp % ns : 1;
+    }
+    a.w.run_rev = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_REVERSE;
+    a.w.run_fwd = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_FORWARD;
+    a.w.next_strand = d_ctr; a.w.next_block = d_ctr + 1; a.w.vnext = d_ctr + 2;
+    a.w.pool = (uint64_t*)d_pool_; a.w.n_blocks = n_blocks_;
+    a.w.block_table = (uint32_t*)d_block_table_; a.w.max_blocks = max_blocks;
+    a.w.strand_n = d_strand_n; a.w.status = d_status; a.w.iters = d_iters; a.w.quirk = d_quirk;
+    a.w.term = d_term;
+    a.w.vpool = (uint64_t*)d_vpool_; a.w.vpool_entries = vpool_entries_; a.w.vcap_max = vcap_max; a.w.vcap_init = LDBG_VT_INITIAL;
+    a.w.ls = (LsElem*)d_ls_; a.w.ecap = ecap_;
+    a.env.rois = rois ? rois->view : GraphView{};
+    if (!rois) a.env.rois.N = -1;
+    a.env.roi_bits = (const uint32_t*)d_roi_bits_;
+    a.env.sink_keys = d_sink_keys; a.env.sink_words = d_sink_words;
+    a.sink_off = d_sink_off;
+    a.max_depth = dfs_max_depth;
+    a.n_trav = 0;
+    for (int i = 0; i < cfg.n_traversal; i++) {          // LinkedHashSet: first occurrence keeps its place
+        bool dup = false;
+        for (int j = 0; j < a.n_trav; j++) dup |= a.trav_order[j] == (uint8_t)cfg.traversal_colors[i];
+        if (!dup) a.trav_order[a.n_trav++] = (uint8_t)cfg.traversal_colors[i];
+    }
+    const size_t frame_bytes = (size_t)a.w.n_slots * (size_t)a.max_depth * sizeof(DfsFrame);
+    if (frame_bytes > d_frames_bytes_) { rt::dfree(d_frames_); d_frames_ = rt::dmalloc(frame_bytes); d_frames_bytes_ = frame_bytes; }
+    a.frames = (DfsFrame*)d_frames_;
+
+    rt::Event e0, e1;
+    e0.record(s);
+    const int grid = (int)(a.w.n_slots / 64);
+    switch (W) {
+        case 1: LDBG_LAUNCH(k_dfs<1>, grid, 64, s, a); break;
+        case 2: LDBG_LAUNCH(k_dfs<2>, grid, 64, s, a); break;
+        case 3: LDBG_LAUNCH(k_dfs<3>, grid, 64, s, a); break;
+        default: LDBG_LAUNCH(k_dfs<4>, grid, 64, s, a); break;
+    }
+    e1.record(s);
+    std::vector<uint32_t> strand_n(ns), status(ns), iters(ns);
+    rt::d2h(strand_n.data(), d_strand_n, (size_t)ns * 4, s);
+    rt::d2h(status.data(), d_status, (size_t)ns * 4, s);
+    rt::d2h(iters.data(), d_iters, (size_t)ns * 4, s);
+    unsigned long long ctr[4] = {0, 0, 0, 0};
+    rt::d2h(ctr, d_ctr, 32, s);
+    rt::stream_sync(s);
+    vpool_dirty_ = ctr[2];
+    profile_add("dfs", rt::Event::elapsed_ms(e0, e1));
+
+    for (int64_t i = 0; i < ns; i++) if (status[i] == ST_POOL_FULL) return false;
+    // errors the reference raises as exceptions abort the call (first seed in input order)
+    for (int64_t i = 0; i < ns; i++) {
+        const std::string where = " (seed " + std::to_string(first + i / 2) + ")";
+        switch (status[i]) {
+            case ST_NULLPTR: throw StatusError(LDBG_ERR_NULLPOINTER, "dfs dereferenced a missing record / ROI graph (NullPointerException in the reference)" + where);
+            case ST_STOPPER_CONFIG: throw StatusError(LDBG_ERR_CORTEXJDK, "This stopper requires a list of novel kmers be provided." + where);
+            case ST_LINKSTORE_FULL: throw StatusError(LDBG_ERR_CAPACITY, "LINKSTORE_FULL");
+            case ST_DEPTH_OVERFLOW: throw StatusError(LDBG_ERR_CAPACITY, "DEPTH_OVERFLOW");
+            case ST_LOG_FULL: throw StatusError(LDBG_ERR_CAPACITY, "LOG_FULL");
+            case ST_TABLE_FULL: throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs visited more vertices along one chain of branches than the per-seed table holds" + where);
+            case ST_COPY_OVERFLOW: throw StatusError(LDBG_ERR_UNSUPPORTED, "a vertex was visited more than 32767 times in one branch chain" + where);
+            default: break;
+        }
+    }
+    for (int64_t i = 0; i < ns; i++) out.traversed += iters[i];
+
+    // dense logs -> host
+    std::vector<int64_t> strand_off((size_t)ns + 1, 0);
+    for (int64_t i = 0; i < ns; i++) strand_off[i + 1] = strand_off[i] + strand_n[i];
+    const int64_t total = strand_off[ns];
+    std::vector<uint64_t> log((size_t)std::max<int64_t>(1, total));
+    if (total > 0) {
+        int64_t* d_off = (int64_t*)tmp.get((size_t)(ns + 1) * 8);
+        uint64_t* d_dense = (uint64_t*)tmp.get((size_t)total * 8);
+        rt::h2d(d_off, strand_off.data(), (size_t)(ns + 1) * 8, s);
+        launch_compact_paths(d_off, ns, d_dense, max_blocks);
+        rt::d2h(log.data(), d_dense, (size_t)total * 8, s);
+        rt::stream_sync(s);
+    }
+
+    // replay the JGraphT container semantics (dfs(source, sinks) :64-106)
+    const int color = cfg.traversal_colors[0];
+    const bool op_and = cfg.combination_operator == LDBG_OP_AND;
+    std::vector<uint64_t> gather_keys;
+    for (int64_t i = 0; i < n; i++) {
+        DfsGraphHost& r = out.results[(size_t)(first + i)];
+        std::unordered_map<std::string, uint32_t> null_ids;
+        HGraph dir_g[2];
+        bool have[2] = {false, false};
+        VKey seed_v{0, 0, 0};
+        for (int d = 0; d < 2; d++) {
+            const int64_t sidx = 2 * i + d;
+            if (status[sidx] != ST_OK) continue;       // ST_BRANCH_NULL: that direction returned null
+            have[d] = true;
+            if (strand_n[sidx] == 0) continue;
+            LogParser lp{log.data() + strand_off[sidx], (int64_t)strand_n[sidx], 0, W, color, d == 1, r.null_kmers, null_ids};
+            VKey v0;
+            lp.parse_branch(dir_g[d], v0);
+            seed_v = v0;
+        }
+        const bool run_r = a.w.run_rev != 0, run_f = a.w.run_fwd != 0;
+        const bool null_r = !run_r || !have[0], null_f = !run_f || !have[1];
+        r.is_null = op_and ? (null_r || null_f) : (null_r && null_f);
+        if (r.is_null) continue;
+        HGraph m;
+        for (int d = 0; d < 2; d++) {
+            if (!have[d]) continue;
+            // every vertex but the seed gets index -1 (reverse) / +1 (forward) :75-83, then Graphs.addGraph :85-99
+            HGraph rel;
+            std::vector<VKey> vs = dir_g[d].verts;
+            for (auto& v : vs) if (!(v == seed_v)) v.index = d == 0 ? -1 : 1;
+            for (auto& v : vs) rel.add_vertex(v);
+            for (auto& ed : dir_g[d].edges) rel.add_edge(rel.add_vertex(vs[ed.src]), rel.add_vertex(vs[ed.dst]), ed.color);
+            m.add_graph(rel);
+        }
+        r.verts.resize(m.verts.size());
+        for (size_t v = 0; v < m.verts.size(); v++) {
+            DfsVertex& o = r.verts[v];
+            const VKey& kv = m.verts[v];
+            o.copy = kv.copy; o.index = kv.index;
+            if (kv.id & DFS_MARK) { o.rec = -1; o.flip = 0; o.slot = -(int64_t)(kv.id & 0xFFFFFFFFull) - 1; }
+            else { o.rec = (int64_t)(kv.id >> 1) - 1; o.flip = (uint8_t)(kv.id & 1ull); o.slot = (int64_t)gather_keys.size(); gather_keys.push_back(kv.id); }
+        }
+        r.edges = std::move(m.edges);
+    }
+    // k-mers and coverages of the vertices, gathered from the probe rows in one launch
+    const int64_t ng = (int64_t)gather_keys.size();
+    std::vector<uint64_t> gw((size_t)std::max<int64_t>(1, ng) * W);
+    std::vector<uint32_t> gc((size_t)std::max<int64_t>(1, ng) * C);
+    if (ng > 0) {
+        uint64_t* d_keys = (uint64_t*)tmp.get((size_t)ng * 8);
+        uint64_t* d_w = (uint64_t*)tmp.get((size_t)ng * W * 8);
+        uint32_t* d_c = (uint32_t*)tmp.get((size_t)ng * C * 4);
+        rt::h2d(d_keys, gather_keys.data(), (size_t)ng * 8, s);
+        const int g = grid_of(ng, 256, 4096);
+        switch (W) {
+            case 1: LDBG_LAUNCH(k_gather_vertices<1>, g, 256, s, graph->view, (const uint64_t*)d_keys, ng, d_w, d_c); break;
+            case 2: LDBG_LAUNCH(k_gather_vertices<2>, g, 256, s, graph->view, (const uint64_t*)d_keys, ng, d_w, d_c); break;
+            case 3: LDBG_LAUNCH(k_gather_vertices<3>, g, 256, s, graph->view, (const uint64_t*)d_keys, ng, d_w, d_c); break;
+            default: LDBG_LAUNCH(k_gather_vertices<4>, g, 256, s, graph->view, (const uint64_t*)d_keys, ng, d_w, d_c); break;
+        }
+        rt::d2h(gw.data(), d_w, (size_t)ng * W * 8, s);
+        rt::d2h(gc.data(), d_c, (size_t)ng * C * 4, s);
+        rt::stream_sync(s);
+    }
+    for (int64_t i = 0; i < n; i++) {
+        DfsGraphHost& r = out.results[(size_t)(first + i)];
+        r.words.resize(r.verts.size() * (size_t)W);
+        r.cov.assign(r.verts.size() * (size_t)C, 0);
+        for (size_t v = 0; v < r.verts.size(); v++) {
+            const DfsVertex& o = r.verts[v];
+            if (o.rec >= 0) {
+                for (int w = 0; w < W; w++) r.words[v * W + w] = gw[(size_t)o.slot * W + w];
+                for (int c = 0; c < C; c++) r.cov[v * C + c] = gc[(size_t)o.slot * C + c];
+            } else {
+                const auto& nk = r.null_kmers[(size_t)(-o.slot - 1)];
+                for (int w = 0; w < W; w++) r.words[v * W + w] = nk[w];
+            }
+        }
+    }
+    return true;
+}
+
+// TraversalUtils.toWalk(g, seed, colour) + toContig (TraversalUtils.java:367-488) over an assembled result
+std::string DfsBatch::walk_contig(int64_t i, const char* seed, int color) const {
+    const DfsGraphHost& r = results.at((size_t)i);
+    if (r.is_null) return std::string();
+    if (color < 0 || color >= C) throw StatusError(LDBG_ERR_ARG, "colour out of range");
+    std::vector<uint64_t> sw((size_t)W);
+    const bool seed_ok = ascii_to_words(seed, k, sw.data(), W);
+    const int nv = (int)r.verts.size();
+    auto words_eq = [&](int v) { for (int w = 0; w < W; w++) if (r.words[(size_t)v * W + w] != sw[w]) return false; return true; };
+    int sv = -1;
+    for (int v = 0; v < nv; v++)      // :392-397 first vertex (insertion order) with the smallest copyIndex
+        if (seed_ok && r.verts[v].rec >= 0 && words_eq(v) && (int32_t)r.cov[(size_t)v * C + color] > 0 &&
+            (sv < 0 || r.verts[v].copy < r.verts[sv].copy)) sv = v;
+    if (sv < 0) return std::string();
+    std::vector<std::vector<int>> out_e((size_t)nv), in_e((size_t)nv);
+    for (int e = 0; e < (int)r.edges.size(); e++) { out_e[r.edges[e].src].push_back(e); in_e[r.edges[e].dst].push_back(e); }
+    std::vector<int> walk{sv}, rev_part;
+    auto extend = [&](bool fwd) {
+        std::unordered_set<int> seen;
+        int cv = sv;
+        while (cv >= 0 && !seen.count(cv)) {
+            std::vector<int> nvs;
+            for (int e : (fwd ? out_e[cv] : in_e[cv]))
+                if (r.edges[e].color == color) nvs.push_back(fwd ? r.edges[e].dst : r.edges[e].src);
+            auto self = std::find(nvs.begin(), nvs.end(), cv);     // Graphs.successorListOf ... remove(cv) :409-411
+            if (self != nvs.end()) nvs.erase(self);
+            int nxt = -1;
+            if (nvs.size() == 1) nxt = nvs[0];
+            else if (nvs.size() > 1) {
+                bool same = true;
+                for (size_t j = 1; j < nvs.size(); j++) {       // canonical k-mers compared pair by pair :418-422
+                    if (r.verts[nvs[0]].rec < 0 || r.verts[nvs[j]].rec < 0) throw StatusError(LDBG_ERR_NULLPOINTER, "toWalk: getCanonicalKmer() on a null record");
+                    if (r.verts[nvs[j]].rec != r.verts[nvs[0]].rec) { same = false; break; }
+                }
+                if (same) {
+                    if (fwd) java_small_sort(nvs, [&](int x, int y) { return r.verts[x].copy < r.verts[y].copy ? -1 : 1; });
+                    else java_small_sort(nvs, [&](int x, int y) { return r.verts[x].copy > r.verts[y].copy ? -1 : 1; });
+                    nxt = nvs[0];
+                }
+            }
+            if (nxt >= 0) { if (fwd) walk.push_back(nxt); else rev_part.push_back(nxt); seen.insert(cv); }
+            cv = nxt;
+        }
+    };
+    extend(true);
+    extend(false);
+    std::reverse(rev_part.begin(), rev_part.end());
+    rev_part.insert(rev_part.end(), walk.begin(), walk.end());
+    std::string contig, km((size_t)k, 'N');
+    for (size_t j = 0; j < rev_part.size(); j++) {       // toContig :367-381: first k-mer, then last characters
+        words_to_ascii(&r.words[(size_t)rev_part[j] * W], k, W, &km[0]);
+        if (j == 0) contig = km; else contig.push_back(km[(size_t)k - 1]);
+    }
+    return contig;
+}
+
+}  // namespace ldbg

@@ -32,7 +32,11 @@ enum : uint32_t {
     ST_LINKSTORE_FULL = 2, // per-walk link store capacity exceeded -> host retries with a larger store
     ST_BRANCH_NULL = 3,    // dfs branch returned null
     ST_COPY_OVERFLOW = 4,  // more than 32767 copies of one vertex
-    ST_POOL_FULL = 5       // path block / table pool exhausted -> host splits the batch
+    ST_POOL_FULL = 5,      // path block / table pool exhausted -> host splits the batch
+    ST_STOPPER_CONFIG = 6, // the stopping rule needs a ROI graph that was not configured (CortexJDKException in the reference)
+    ST_DEPTH_OVERFLOW = 7, // dfs recursion deeper than the frame stack -> host retries with a deeper one
+    ST_TABLE_FULL = 8,     // a strand's visited table reached its maximum size
+    ST_LOG_FULL = 9        // a strand's dfs log outgrew its block table -> host retries with a longer one
 };
 
 // ---- path entry: one vertex of a branch, 8 bytes
@@ -160,7 +164,9 @@ LDBG_HOSTDEV void node_null(const EngineView& e, Node& n) {   // not a k-mer (no
 // zeroed pool when a strand starts (4096 entries) and regrown x4 when half full, so memory follows the
 // walk lengths.  A vertex is located once (when it is first looked up as a neighbour); later updates go
 // straight to its slot.
-//  entry: bits 0..33 key = ((record index + 1) << 1) | flip (never 0) ; bits 48..62 copies visited ; bit 63 seen
+//  entry: bits 0..33 key = ((record index + 1) << 1) | flip (never 0) ; bits 34..47 seen epoch ; bits 48..62 copies visited
+//  `seen` is cleared by every seek() (TraversalEngine.java:333): a k-mer is in the cursor's seen set when its entry
+//  carries the cursor's current epoch (1..16383; a dfs branch = a new epoch, dfs.cpp sweeps the table on wrap-around)
 struct VisitedTable {
     uint64_t* tab;
     uint32_t mask;   // capacity - 1
@@ -191,7 +197,9 @@ LDBG_HOSTDEV uint32_t vt_locate(VisitedTable& t, int64_t idx, bool flip) {
     }
 }
 LDBG_HOSTDEV int vt_count_e(uint64_t e) { return (int)((e >> 48) & 0x7FFFull); }
-LDBG_HOSTDEV bool vt_seen_e(uint64_t e) { return (e >> 63) != 0; }
+#define LDBG_VT_EPOCH_MAX 0x3FFFu
+LDBG_HOSTDEV bool vt_seen_e(uint64_t e, uint32_t epoch) { return (uint32_t)((e >> 34) & LDBG_VT_EPOCH_MAX) == epoch; }
+LDBG_HOSTDEV uint64_t vt_with_seen(uint64_t e, uint32_t epoch) { return (e & ~((uint64_t)LDBG_VT_EPOCH_MAX << 34)) | ((uint64_t)epoch << 34); }
 LDBG_HOSTDEV uint64_t vt_with_count(uint64_t e, int c) { return (e & ~(0x7FFFull << 48)) | ((uint64_t)(c & 0x7FFF) << 48); }
 LDBG_HOSTDEV void node_locate(VisitedTable& t, Node& n) { if (n.idx >= 0) n.vslot = vt_locate(t, n.idx, n.flip != 0); }
 // timing experiment (EngineView.dbg & 16): a 64-entry direct-mapped pseudo table, collisions ignored — wrong results
@@ -370,6 +378,7 @@ struct Cursor {
     bool has;
     bool first;         // specificLinksFiles == null: the next step re-seeks and initialises the link store
     uint32_t status;
+    uint32_t epoch;     // current generation of the `seen` set (never 0)
 };
 
 // initializeLinkStore / updateLinkStore (:548-597): links of vertex v, if its record carries any
@@ -422,10 +431,10 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
         node_child_located(e, vt, t, fwd, lowbit4(m), x);
         const uint64_t ex = x.idx >= 0 ? vt.tab[x.vslot] : 0ull;
         if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_child += p1 - p0; p0 = p1; }
-        if (!vt_seen_e(ex) || s.n > 0) {                // :262
+        if (!vt_seen_e(ex, cu.epoch) || s.n > 0) {      // :262
             cu.nxt = x;
             has = true;
-            if (x.idx >= 0 && !(e.dbg & 2u)) vt.tab[x.vslot] = ex | (1ull << 63);   // seen.add(nextKmer)
+            if (x.idx >= 0 && !(e.dbg & 2u)) vt.tab[x.vslot] = vt_with_seen(ex, cu.epoch);   // seen.add(nextKmer)
         }
     } else if (pc > 1) {
         unsigned ch;

@@ -22,6 +22,24 @@ struct WalkChunk {
     std::vector<uint8_t> seed_ok;          // toWalk seed test: record present and coverage > 0
 };
 
+// ---- dfs results (dfs.cpp): the DirectedWeightedPseudograph<CortexVertex, CortexEdge> of every seed
+struct DfsVertex { int64_t rec; int64_t slot; int32_t copy, index; uint8_t flip; };
+struct DfsEdge { int src, dst, color; };
+struct DfsGraphHost {
+    bool is_null = true;                   // dfs() returned null
+    std::vector<DfsVertex> verts;          // insertion order
+    std::vector<DfsEdge> edges;            // insertion order
+    std::vector<uint64_t> words;           // [verts][W]
+    std::vector<uint32_t> cov;             // [verts][C]
+    std::vector<std::vector<uint64_t>> null_kmers;
+};
+struct DfsBatch {
+    int k = 0, W = 0, C = 0;
+    int64_t traversed = 0;
+    std::vector<DfsGraphHost> results;
+    std::string walk_contig(int64_t i, const char* seed, int color) const;
+};
+
 class Engine {
 public:
     explicit Engine(const ldbg_engine_config& cfg);
@@ -36,6 +54,11 @@ public:
     void walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len);
     void walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index);
     void clear_batch();
+    // dfs(source, sinks...) for n sources; sinks as CSR over ASCII k-mers (sink_offsets may be nullptr)
+    DfsBatch* dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets);
+    int dfs_max_depth = 64;
+    int dfs_log_blocks = 64;          // path blocks (1024 entries) one strand's dfs log may use
+    int64_t dfs_traversed() const { return dfs_traversed_; }
 
     int64_t batch_n = 0, batch_bytes = 0, batch_traversed = 0;
     std::vector<WalkChunk> chunks;
@@ -49,7 +72,14 @@ private:
     uint64_t n_blocks_ = 0, vpool_entries_ = 0, vpool_dirty_ = 0;
     uint32_t ecap_ = 0;
     int max_blocks_ = 0;
+    void* d_frames_ = nullptr; size_t d_frames_bytes_ = 0;
+    void* d_roi_bits_ = nullptr;
+    int64_t dfs_traversed_ = 0;
     std::unique_ptr<MergedLinks> merged_;
+    void build_roi_bits();
+    bool dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
+                   int64_t first, int64_t n, DfsBatch& out);
+    void launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks);
     void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks);
     void release_scratch();
     bool run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);

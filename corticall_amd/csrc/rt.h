@@ -80,6 +80,7 @@ LDBG_DEV int64_t global_nthreads() { return (int64_t)gridDim.x * blockDim.x; }
 LDBG_DEV unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 LDBG_DEV unsigned atomic_add_u32(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 LDBG_DEV unsigned atomic_min_u32(unsigned* p, unsigned v) { return atomicMin(p, v); }
+LDBG_DEV unsigned atomic_or_u32(unsigned* p, unsigned v) { return atomicOr(p, v); }
 LDBG_DEV unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
 LDBG_DEV unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { return atomicCAS(p, cmp, v); }
 // wavefront primitives (64 lanes on gfx950); kernels that use them are launched with 64-thread blocks
@@ -131,6 +132,7 @@ inline int64_t global_nthreads() { return sim_idx().nthreads; }
 inline unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 inline unsigned atomic_add_u32(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
 inline unsigned atomic_min_u32(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+inline unsigned atomic_or_u32(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { unsigned long long o = *p; if (o == cmp) *p = v; return o; }
 // a simulated "wave" is a single lane

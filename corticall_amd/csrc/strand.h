@@ -1,0 +1,186 @@
+// Device-side pieces shared by the walk kernel (walk.cpp) and the general dfs kernel (dfs.cpp): the strand
+// queue arguments, path-block storage, visited-table allocation and the wave-cooperative table regrowth.
+#pragma once
+#include "engine_host.h"
+
+namespace ldbg {
+
+// Path storage: every strand appends 8-byte vertex entries to 1024-entry blocks drawn from one pool
+// (one atomic per 1024 traversed k-mers), so memory follows the actual walk lengths instead of
+// maxLength per strand.
+#define LDBG_PATH_BLOCK 1024
+
+struct WalkArgs {
+    EngineView e;
+    const uint64_t* seeds;     // [n][W]; word 0 == ~0 marks a seed that is not a k-mer (non-ACGT)
+    int64_t n_strands;         // 2n: strand 2i = reverse, 2i+1 = forward
+    int64_t n_slots;
+    int64_t fetch_stride;      // strands are handed out in the order (i * fetch_stride) mod n_strands (coprime): neighbouring
+                               // seeds walk the same contig, and a wavefront full of identical long walks is the worst tail
+    int run_rev, run_fwd;
+    unsigned long long* next_strand;
+    uint64_t* pool;            // path blocks [n_blocks][LDBG_PATH_BLOCK]
+    unsigned long long* next_block;
+    uint64_t n_blocks;
+    uint32_t* block_table;     // [n_strands][max_blocks]
+    int max_blocks;
+    uint64_t* vpool;           // zeroed visited-table pool (entries)
+    unsigned long long* vnext;
+    uint64_t vpool_entries;
+    uint32_t vcap_max;         // largest table a strand may need
+    uint32_t vcap_init;        // size a strand's table starts with
+    uint32_t* strand_n;        // vertices in the strand's branch graph (0 = empty graph)
+    uint32_t* status;
+    uint32_t* iters;
+    uint8_t* quirk;            // [n_strands] the strand contains a Q6 vertex
+    uint64_t* term;            // [n_strands][W]
+    LsElem* ls;                // [n_slots][ecap]
+    uint32_t ecap;
+    unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
+    unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
+    StepProf* st_prof;              // diagnostics: [n_strands] time split of the cursor step
+};
+#define LDBG_VT_INITIAL 4096u
+#ifndef LDBG_LS_FAST
+#define LDBG_LS_FAST 32u          // link-store elements per lane kept in LDS (48 KB per 64-lane workgroup)
+#endif
+
+LDBG_DEV uint64_t pack_vertex(const Node& v) { return path_pack(v.idx, v.flip != 0, v.base, v.copy, v.flip && !v.fj); }
+
+struct PathWriter {
+    uint64_t* cur;       // current block
+    uint32_t n;          // entries written
+    uint32_t nblk;       // blocks this strand owns (a truncated log keeps its blocks and writes them again)
+};
+LDBG_DEV bool path_append(const WalkArgs& a, int64_t s, PathWriter& pw, uint64_t entry) {
+    const uint32_t off = pw.n & (LDBG_PATH_BLOCK - 1);
+    if (off == 0) {
+        const uint32_t bi = pw.n / LDBG_PATH_BLOCK;
+        if (bi < pw.nblk) pw.cur = a.pool + (uint64_t)a.block_table[s * a.max_blocks + bi] * LDBG_PATH_BLOCK;
+        else {
+            if ((int)bi >= a.max_blocks) return false;
+            const uint64_t b = (uint64_t)atomic_add_u64(a.next_block, 1ull);
+            if (b >= a.n_blocks) return false;
+            a.block_table[s * a.max_blocks + bi] = (uint32_t)b;
+            pw.cur = a.pool + b * LDBG_PATH_BLOCK;
+            pw.nblk = bi + 1;
+        }
+    }
+    if (!(a.e.dbg & 1u)) pw.cur[off] = entry;
+    pw.n++;
+    return true;
+}
+LDBG_DEV uint64_t path_read(const WalkArgs& a, int64_t s, uint32_t pos) {
+    return a.pool[(uint64_t)a.block_table[s * a.max_blocks + pos / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK + (pos & (LDBG_PATH_BLOCK - 1))];
+}
+// drop everything from entry `n` on
+LDBG_DEV void path_truncate(const WalkArgs& a, int64_t s, PathWriter& pw, uint32_t n) {
+    pw.n = n;
+    if (n & (LDBG_PATH_BLOCK - 1)) pw.cur = a.pool + (uint64_t)a.block_table[s * a.max_blocks + n / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK;
+}
+
+// carve a zeroed table of `cap` entries out of the pool
+LDBG_DEV bool vt_alloc(const WalkArgs& a, VisitedTable& vt, uint32_t cap) {
+    const uint64_t o = (uint64_t)atomic_add_u64(a.vnext, (unsigned long long)cap);
+    if (o + cap > a.vpool_entries) return false;
+    vt.tab = a.vpool + o;
+    vt.mask = cap - 1;
+    vt.used = 0;
+    return true;
+}
+
+// one strand = private dfs(cv, goForward, 0, 0, {}, sinks) for ContigStopper (TraversalEngine.java:356-482),
+// advanced one loop iteration per call so that the lanes of a wave stay busy with different strands
+struct StrandState {
+    int64_t s;
+    Node cv;
+    Cursor cu;
+    PathWriter pw;
+    VisitedTable vt;
+    uint32_t gV, iters, status;
+    bool fwd, branch_null, quirk;
+};
+
+LDBG_DEV void strand_finish(const WalkArgs& a, StrandState& st) {
+    a.strand_n[st.s] = (st.branch_null || st.status != ST_OK) ? 0u : st.pw.n;
+    a.status[st.s] = st.status != ST_OK ? st.status : (st.branch_null ? (uint32_t)ST_BRANCH_NULL : (uint32_t)ST_OK);
+    a.iters[st.s] = st.iters;
+    a.quirk[st.s] = st.quirk ? 1 : 0;
+#ifndef LDBG_HOSTSIM
+    if (a.st_times) a.st_times[2 * st.s + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+// returns false when the strand ended at once
+template <int W>
+LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, int64_t s) {
+    const EngineView& e = a.e;
+    st.s = s;
+#ifndef LDBG_HOSTSIM
+    if (a.st_times) a.st_times[2 * s] = __builtin_amdgcn_s_memrealtime();
+#endif
+    st.fwd = (s & 1) != 0;
+    st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false; st.quirk = false;
+    st.pw.cur = nullptr; st.pw.n = 0; st.pw.nblk = 0;
+    st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true; st.cu.epoch = 1;
+    st.cu.prof = a.st_prof ? a.st_prof + s : nullptr;
+    ls_clear(ls);
+    if (!vt_alloc(a, st.vt, a.vcap_init < a.vcap_max ? a.vcap_init : a.vcap_max)) { st.status = ST_POOL_FULL; return false; }
+    const uint64_t* sw = a.seeds + (s >> 1) * W;
+    Kmer<W> sk;
+#pragma unroll
+    for (int i = 0; i < W; i++) sk.w[i] = sw[i];
+    if (sw[0] != ~0ull) { node_find<W>(e, sk, st.cv); node_locate(st.vt, st.cv); }
+    else node_null(e, st.cv);   // not a k-mer: findRecord misses (Q4)
+    if (st.cv.npe) { st.status = ST_NULLPTR; return false; }
+    if (e.cursor_on) cursor_seek(e, st.cu, ls, st.vt, st.cv, st.fwd);   // :363-365
+    return true;
+}
+
+// Regrowing a strand's visited table is a wave-cooperative operation: a lane that rehashed its own table
+// alone would stall the other 63 lanes of its wavefront for as long as the table is big.  Every lane whose
+// table is half full raises its hand (ballot); for each of them in turn the whole wavefront moves that
+// lane's entries into a table 4x the size (CAS inserts), then the owner re-locates the vertices whose
+// slots it carries.
+LDBG_DEV void wave_grow_tables(const WalkArgs& a, StrandState& st, bool active) {
+    const uint32_t cap = st.vt.mask + 1;
+    const bool need = active && st.status == ST_OK && (st.vt.used + 8) * 2 > cap && cap < a.vcap_max;
+    unsigned long long ballot = wave_ballot(need);
+    const int lane = wave_lane();
+    while (ballot) {
+        const int L = __builtin_ctzll(ballot);
+        ballot &= ballot - 1;
+        uint64_t new_tab = 0;
+        uint32_t new_cap = 0;
+        if (lane == L) {
+            uint64_t c = (uint64_t)cap * 4;
+            if (c > a.vcap_max) c = a.vcap_max;
+            VisitedTable nt;
+            if (vt_alloc(a, nt, (uint32_t)c)) { new_tab = (uint64_t)(uintptr_t)nt.tab; new_cap = (uint32_t)c; }
+            else st.status = ST_POOL_FULL;
+        }
+        const uint64_t* old_tab = (const uint64_t*)(uintptr_t)wave_bcast_u64((uint64_t)(uintptr_t)st.vt.tab, L);
+        const uint32_t old_mask = wave_bcast_u32(st.vt.mask, L);
+        unsigned long long* nt_tab = (unsigned long long*)(uintptr_t)wave_bcast_u64(new_tab, L);
+        const uint32_t nt_mask = wave_bcast_u32(new_cap, L) - 1;
+        if (nt_tab) {
+            for (uint32_t i = (uint32_t)lane; i <= old_mask; i += (uint32_t)wave_size()) {
+                const uint64_t e = old_tab[i];
+                if (e == 0) continue;
+                uint32_t h = vt_hash(e & LDBG_VT_KEY_MASK) & nt_mask;
+                while (atomic_cas_u64(&nt_tab[h], 0ull, (unsigned long long)e) != 0ull) h = (h + 1) & nt_mask;
+            }
+            wave_fence();
+            if (lane == L) {
+                st.vt.tab = (uint64_t*)nt_tab;
+                st.vt.mask = nt_mask;       // `used` is unchanged: every entry moved
+                const uint32_t used = st.vt.used;
+                node_locate(st.vt, st.cv);
+                if (a.e.cursor_on) { node_locate(st.vt, st.cu.cur); if (st.cu.has) node_locate(st.vt, st.cu.nxt); }
+                st.vt.used = used;
+            }
+        }
+    }
+}
+
+}  // namespace ldbg

@@ -112,6 +112,82 @@ class CortexVertex:
     def __repr__(self): return "CortexVertex{sk=%s, index=%d, copyIndex=%d}" % (self._kmer, self._index, self._copyIndex)
 
 
+class _DfsBatch:
+    """owner of one ldbg_dfs_result handle; DfsGraph objects keep it alive"""
+
+    def __init__(self, engine, h):
+        self.engine, self.h = engine, h
+
+    def graph(self, i):
+        e = self.engine
+        isnull, nv, ne = C.c_int(), C.c_int64(), C.c_int64()
+        e._lib.check(e._d.ldbg_dfs_result_sizes(self.h, C.c_int64(i), C.byref(isnull), C.byref(nv), C.byref(ne)))
+        if isnull.value:
+            return None
+        return DfsGraph(self, i, nv.value, ne.value)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.engine._d.ldbg_dfs_result_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class DfsGraph:
+    """The DirectedWeightedPseudograph<CortexVertex, CortexEdge> dfs() returns (TraversalEngine.java:64-106):
+    vertices and edges in insertion order; edge weight is always 1.0."""
+
+    def __init__(self, batch, i, nv, ne):
+        self._batch, self._i, self.nv, self.ne = batch, i, nv, ne
+        self._raw = None
+
+    def _fetch(self):
+        if self._raw is None:
+            e = self._batch.engine
+            W = e._graph.getKmerBits()
+            words = np.zeros((max(1, self.nv), W), dtype=np.uint64)
+            rec = np.zeros(max(1, self.nv), dtype=np.int64)
+            copy = np.zeros(max(1, self.nv), dtype=np.int32)
+            index = np.zeros(max(1, self.nv), dtype=np.int32)
+            es, et, ec = (np.zeros(max(1, self.ne), dtype=np.int32) for _ in range(3))
+            P = lambda a: a.ctypes.data_as(C.c_void_p)
+            e._lib.check(e._d.ldbg_dfs_result_get(self._batch.h, C.c_int64(self._i), P(words), P(rec), P(copy), P(index), P(es), P(et), P(ec)))
+            self._raw = (words[:self.nv], rec[:self.nv], copy[:self.nv], index[:self.nv], es[:self.ne], et[:self.ne], ec[:self.ne])
+        return self._raw
+
+    def vertex_tuples(self):
+        """-> list of (kmer, record index or -1, copyIndex, index) in insertion order"""
+        words, rec, copy, index = self._fetch()[:4]
+        k = self._batch.engine._graph.getKmerSize()
+        return [(CortexRecord(words[j], [0], [0], k).getKmerAsString(), int(rec[j]), int(copy[j]), int(index[j])) for j in range(self.nv)]
+
+    def edge_tuples(self):
+        """-> list of (source vertex number, target vertex number, colour) in insertion order"""
+        es, et, ec = self._fetch()[4:]
+        return [(int(es[j]), int(et[j]), int(ec[j])) for j in range(self.ne)]
+
+    def vertexSet(self):
+        g = self._batch.engine._graph
+        cache = {}
+        out = []
+        for kmer, r, ci, ix in self.vertex_tuples():
+            if r >= 0 and r not in cache:
+                cache[r] = g.getRecord(r)
+            out.append(CortexVertex(kmer, cache.get(r), ci, ix))
+        return out
+
+    def walk_contig(self, seed, color):
+        """TraversalUtils.toContig(TraversalUtils.toWalk(g, seed, color))"""
+        e = self._batch.engine
+        cap = self.nv + e._graph.getKmerSize() + 8
+        buf = C.create_string_buffer(cap)
+        ln = C.c_int64()
+        e._lib.check(e._d.ldbg_dfs_result_walk(self._batch.h, C.c_int64(self._i), _as_bytes(seed), C.c_int(color), buf, C.c_int64(cap), C.byref(ln)))
+        return buf.value.decode()
+
+
 class TraversalUtils:
     """J/utils/traversal/TraversalUtils.java (the members on the hot path)"""
 
@@ -283,9 +359,33 @@ class TraversalEngine:
         return self.walk_vertices(0)
 
     def dfs(self, source, *sinks):   # :64-106
+        """-> DfsGraph, or None where the reference returns null"""
+        if len(sinks) == 1 and not isinstance(sinks[0], (str, bytes)):
+            sinks = tuple(sinks[0])
+        return self.dfs_batch([source], [list(sinks)])[0]
+
+    def dfs_batch(self, sources, sinks=None):
+        """dfs(source, sinks...) for every source in one device launch; sinks: per source a list of k-mers (or None).
+        -> list of DfsGraph / None"""
+        k = self._graph.getKmerSize()
+        n = len(sources)
+        src = np.frombuffer(b"".join(_as_bytes(s) for s in sources), dtype=np.uint8)
+        sink_buf, off = None, None
+        if sinks is not None:
+            flat = [_as_bytes(x) for ss in sinks for x in ss]
+            off = np.zeros(n + 1, dtype=np.int64)
+            off[1:] = np.cumsum([len(ss) for ss in sinks])
+            sink_buf = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8)
         res = C.c_void_p()
-        self._lib.check(self._d.ldbg_engine_dfs_batch(self._h, _as_bytes(source), C.c_int64(1), None, None, C.byref(res)))
-        raise NotImplementedError
+        self._lib.check(self._d.ldbg_engine_dfs_batch(
+            self._h, src.ctypes.data_as(C.c_char_p), C.c_int64(n),
+            sink_buf.ctypes.data_as(C.c_char_p) if sink_buf is not None else None,
+            off.ctypes.data_as(C.c_void_p) if off is not None else None, C.byref(res)))
+        batch = _DfsBatch(self, res)
+        t = C.c_int64()
+        self._lib.check(self._d.ldbg_engine_dfs_kmers_traversed(self._h, C.byref(t)))
+        self.dfs_kmers_traversed = t.value
+        return [batch.graph(i) for i in range(n)]
 
     def seek(self, sk):          # :321-335
         self._lib.check(self._d.ldbg_engine_seek(self._h, _as_bytes(sk)))

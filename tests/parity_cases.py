@@ -386,6 +386,10 @@ def case_hash_collision(orc, lib, tmp):
                 n_npe += exp is None
         idx, _, _ = cs.g.find_batch([x, orc.revcomp(x)])
         assert idx[0] == idx[1] >= 0
+        # dfs graphs through the colliding k-mer (children order, sinks, Q6 vertices in the log)
+        for links in ([], ["a"]):
+            for stopper in ("ExplorationStopper", "DestinationStopper", "VisualizationStopper"):
+                compare_dfs(cs, seeds, sinks=[[h1[4 * k:5 * k], orc.revcomp(x)] for _ in seeds], trav=[0], stopper=stopper, links=links, max_len=300)
         # cursor through the colliding k-mer, both ways, against the oracle's cursor
         oe, e = cs.engines(trav=[0], links=["a"])
         for start, fwd in ((h1[k:2 * k], True), (h1[5 * k:6 * k], False)):
@@ -398,3 +402,168 @@ def case_hash_collision(orc, lib, tmp):
                 ov = oe.next() if fwd else oe.previous()
                 v = e.next() if fwd else e.previous()
                 assert ov[0] == v.getKmerAsString() and (ov[1] >= 0) == (v.getCortexRecord() is not None)
+
+
+# ------------------------------------------------------------------ dfs with stopping rules vs oracle
+def dfs_engines(case, trav, stopper, links=(), rois=None, join=(), recruit=(), op=OR, direction=BOTH, max_len=75000):
+    """rois: (oracle graph, product graph) or None"""
+    oe = case.orc.Engine(case.og, trav, links=[case.olinks[s] for s in links], rois=rois[0] if rois else None,
+                         joining_colors=join, recruitment_colors=recruit, op_and=(op == AND), direction=direction,
+                         max_length=max_len, stopper=stopper)
+    f = (TraversalEngineFactory(lib=case.lib).traversalColors(*trav).graph(case.g).combinationOperator(op)
+         .traversalDirection(direction).maxBranchLength(max_len).stoppingRule(stopper))
+    if join:
+        f.joiningColors(*join)
+    if recruit:
+        f.recruitmentColors(*recruit)
+    if rois:
+        f.rois(rois[1])
+    if links:
+        f.links(*[case.links[s] for s in links])
+    return oe, f.make()
+
+
+def _oracle_dfs(case, oe, seed, sinks, color):
+    try:
+        r = oe.dfs(seed, sinks)
+    except case.orc.OracleError as ex:
+        return ("error", "NullPointerException" if "NullPointerException" in str(ex) else "CortexJDKException")
+    if r.is_null:
+        r.free()
+        return None
+    try:
+        contig = r.walk(seed, color)
+    except case.orc.OracleError:
+        contig = "<error>"
+    out = (r.vertices(), r.edges(), contig)
+    r.free()
+    return out
+
+
+def _product_dfs_one(e, g, seed, color):
+    if g is None:
+        return None
+    try:
+        contig = g.walk_contig(seed, color)
+    except ca.JavaNullPointerException:
+        contig = "<error>"
+    return (g.vertex_tuples(), g.edge_tuples(), contig)
+
+
+def compare_dfs(case, seeds, sinks=None, **cfg):
+    """every seed's dfs graph (vertices and edges in insertion order), toWalk/toContig of it, and the errors the
+    reference raises, against the oracle"""
+    oe, e = dfs_engines(case, **cfg)
+    color = cfg["trav"][0]
+    seeds = list(seeds)
+    sinks = sinks if sinks is not None else [[] for _ in seeds]
+    it0 = oe.kmers_traversed()
+    exp = [_oracle_dfs(case, oe, s, sk, color) for s, sk in zip(seeds, sinks)]
+    exp_iters = oe.kmers_traversed() - it0
+    n_err = sum(1 for x in exp if isinstance(x, tuple) and x[0] == "error")
+    if n_err == 0:
+        got = [_product_dfs_one(e, g, s, color) for g, s in zip(e.dfs_batch(seeds, sinks), seeds)]
+        assert e.dfs_kmers_traversed == exp_iters, (e.dfs_kmers_traversed, exp_iters)
+    else:       # an exception aborts a batch call, like the reference's loop would: compare seed by seed
+        got = []
+        for s, sk in zip(seeds, sinks):
+            try:
+                got.append(_product_dfs_one(e, e.dfs_batch([s], [sk])[0], s, color))
+            except ca.JavaNullPointerException:
+                got.append(("error", "NullPointerException"))
+            except ca.CortexJDKException:
+                got.append(("error", "CortexJDKException"))
+    for i, s in enumerate(seeds):
+        assert got[i] == exp[i], (s, sinks[i], cfg, got[i], exp[i])
+    return exp
+
+
+def case_dfs_rules(orc, lib, tmp, k, seed, with_links):
+    """every stopping rule on a three-colour graph with repeats, bubbles and a ROI graph of child-only k-mers"""
+    rng = random.Random(seed * 104729 + k)
+    base = genome_with_repeats(rng, 700, n_rep=5, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+    kid = mutate(rng, base, snv=0.02, indel=0.004)
+    dad = mutate(rng, base, snv=0.02, indel=0.003)
+    haps = [("kid", [kid]), ("mom", [base]), ("dad", [dad])]
+    reads = None
+    if with_links:
+        rl = max(3 * k, 40)
+        reads = {"kid": [kid[i:i + rl] for i in range(0, max(1, len(kid) - rl + 1), max(1, rl // 4))] + [kid[-rl:]]}
+    cs = Case(orc, tmp, lib, haps, k, link_samples=(["kid"] if with_links else []), reads=reads, name="dfs%d_%d_%d" % (k, seed, int(with_links)))
+    # ROI graph: the k-mers only the child has
+    parents = set()
+    for h in (base, dad):
+        parents |= {orc.canonical(h[i:i + k]) for i in range(len(h) - k + 1)}
+    novel = [kid[i:i + k] for i in range(len(kid) - k + 1) if orc.canonical(kid[i:i + k]) not in parents]
+    roi_path = str(tmp / "rois.ctx")
+    orc.build_graph(roi_path, [("kid", novel or [kid[:k]])], k)
+    rois = (orc.Graph(roi_path, tuned=True), CortexGraph(roi_path, lib=lib))
+    kmers = cs.all_kmers()
+    seeds = rng.sample(kmers, min(40, len(kmers)))
+    seeds = [s if rng.random() < 0.5 else orc.revcomp(s) for s in seeds] + novel[:10] + [rand_seq(rng, k), kid[:k], kid[-k:]]
+    L = ["kid"] if with_links else []
+    ML = 300
+    # sinks: a child k-mer 5..150 bases downstream of the seed (gap closing), or unrelated ones
+    pos = {kid[i:i + k]: i for i in range(len(kid) - k + 1)}
+    sinks = []
+    for s in seeds:
+        i = pos.get(s, pos.get(orc.revcomp(s)))
+        if i is None:
+            sinks.append([rand_seq(rng, k)])
+            continue
+        j = min(len(kid) - k, i + rng.randint(5, 150))
+        t = kid[j:j + k]
+        sinks.append([t if s in pos else orc.revcomp(kid[max(0, i - rng.randint(5, 150)):][:k])] + ([rand_seq(rng, k)] if rng.random() < 0.3 else []))
+    for stopper in ca.traversal.STOPPING_RULES:
+        if stopper == "CycleCollapsingContigStopper" and k < 15:
+            continue        # forks at every junction until everything is visited: exponential in the reference as well
+        cfg = dict(trav=[0], stopper=stopper, links=L, max_len=ML, join=[1, 2], rois=rois)
+        if stopper == "NovelKmerLimitedContigStopper":
+            # never fails and only succeeds after a novel k-mer: from anywhere else the reference forks without end
+            nov = set(novel) | {orc.revcomp(x) for x in novel}
+            sel = [i for i, s in enumerate(seeds) if s in nov]
+            compare_dfs(cs, [seeds[i] for i in sel], sinks=[sinks[i] for i in sel], **cfg)
+            continue
+        compare_dfs(cs, seeds, sinks=sinks, **cfg)
+    # variations on the rules the reference's commands use most
+    compare_dfs(cs, seeds, sinks=sinks, trav=[0], stopper="DestinationStopper", links=L, max_len=ML, direction=FORWARD)
+    compare_dfs(cs, seeds, sinks=sinks, trav=[0], stopper="DestinationStopper", links=L, max_len=40, direction=REVERSE, op=AND)
+    compare_dfs(cs, seeds, trav=[0, 2], stopper="ExplorationStopper", links=L, max_len=ML)
+    compare_dfs(cs, seeds, trav=[1], stopper="ExplorationStopper", max_len=ML, recruit=[0])
+    if k >= 15:
+        compare_dfs(cs, seeds, trav=[0], stopper="CycleCollapsingContigStopper", links=L, max_len=ML, op=AND)
+    compare_dfs(cs, seeds, trav=[0], stopper="NovelPartitionStopper", links=L, max_len=ML)              # no ROI graph: the reference throws
+    compare_dfs(cs, seeds, trav=[0], stopper="BubbleOpeningStopper", links=L, max_len=ML, join=[1])     # no ROI graph: NullPointerException
+    compare_dfs(cs, seeds, trav=[0], stopper="ContigStopper", links=L, max_len=ML)
+    for g in rois:
+        g.close()
+
+
+def case_dfs_dense(orc, lib, tmp, seed):
+    """tiny k: junctions everywhere, deep recursion, many failing branches (visited-set undo, log truncation)"""
+    rng = random.Random(1000 + seed)
+    k = rng.choice([4, 5, 6])
+    g1 = "".join(rng.choice("ACGT") for _ in range(rng.randint(40, 120)))
+    g2 = mutate(rng, g1, snv=0.06)
+    reads = {"a": [g1[i:i + 5 * k] for i in range(0, len(g1), k)]}
+    cs = Case(orc, tmp, lib, [("a", [g1]), ("b", [g2])], k, link_samples=["a"], reads=reads, name="dd%d" % seed)
+    seeds = cs.all_kmers()
+    seeds = seeds[:30] + [orc.revcomp(s) for s in seeds[:30]]
+    sinks = [[rng.choice(seeds), rng.choice(seeds)] for _ in seeds]
+    # only rules that bound their own recursion: the others fork without end on a graph this dense (in the reference too),
+    # and with links a walk circles a cycle for ever unless the rule looks at reachedMaxBranchLength / branchSize
+    for stopper in ("DestinationStopper", "ExplorationStopper", "GapClosingStopper", "VisualizationStopper", "BubbleClosingStopper",
+                    "PairedReadClosingStopper"):
+        compare_dfs(cs, seeds, sinks=sinks, trav=[0], stopper=stopper, max_len=60, join=[1])
+    for stopper in ("DestinationStopper", "ExplorationStopper", "VisualizationStopper", "PairedReadClosingStopper"):
+        compare_dfs(cs, seeds, sinks=sinks, trav=[0], stopper=stopper, links=["a"], max_len=60, join=[1])
+    compare_dfs(cs, seeds, sinks=sinks, trav=[0, 1], stopper="ExplorationStopper", max_len=60)
+
+
+def test_ref_dfs_with_sinks(orc, lib, tmp):                       # TraversalEngineTest.java:389-410
+    hap = "GTGTGCTAGGTCTATAGTTATAGGCGCGTCTCCGCAAAAATCGT"
+    cs = Case(orc, tmp, lib, [("test", [hap])], 5, link_samples=["test"], name="v12")
+    e = (TraversalEngineFactory(lib=lib).traversalColors(0).traversalDirection(BOTH).combinationOperator(OR)
+         .graph(cs.g).links(cs.links["test"]).make())
+    g = e.dfs(hap[:5], hap[-5:])
+    assert g.walk_contig(hap[:5], 0) == hap

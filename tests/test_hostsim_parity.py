@@ -41,3 +41,14 @@ def test_long_walks(orc, lib, tmp_path): pc.case_long_walks(orc, lib, tmp_path)
 
 
 def test_hash_collision(orc, lib, tmp_path): pc.case_hash_collision(orc, lib, tmp_path)
+
+
+@pytest.mark.parametrize("k,seed,links", [(9, 2, False), (21, 3, False), (31, 4, True), (47, 5, True)])
+def test_dfs_rules(orc, lib, tmp_path, k, seed, links): pc.case_dfs_rules(orc, lib, tmp_path, k, seed, links)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_dfs_dense(orc, lib, tmp_path, seed): pc.case_dfs_dense(orc, lib, tmp_path, seed)
+
+
+def test_ref_dfs_with_sinks(orc, lib, tmp_path): pc.test_ref_dfs_with_sinks(orc, lib, tmp_path)
