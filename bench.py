@@ -74,6 +74,102 @@ def cpu_baseline(prefix, args, gpu_contigs, seeds_ascii):
     }, n, mismatches
 
 
+def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist, sync, t_load):
+    """configs[3]: dfs with DestinationStopper (the gap-closing configuration of Call.java:759-779) from every seed
+    towards the child k-mer 200-2000 bp downstream on the seed's own link-guided contig."""
+    import numpy as np
+    import torch
+    from corticall_amd import FORWARD, OR, DestinationStopper, TraversalEngineFactory
+    k = args.k
+    arena, offs, wl = walk_eng.walk_batch_arrays(seeds)
+    rng = np.random.default_rng(0xC0FFEE05)
+    sink = np.empty_like(seeds)
+    for i in range(len(seeds)):
+        c = arena[offs[i]:offs[i + 1]]
+        sd = seeds[i].tobytes()
+        p = c.tobytes().find(sd) if len(c) >= k else -1
+        if p < 0:                      # seed not on its own contig (empty walk): an unrelated sink, the search fails
+            sink[i] = seeds[(i + 1) % len(seeds)]
+            continue
+        d = int(rng.integers(200, 2001))
+        q = min(len(c) - k, p + d)
+        sink[i] = c[q:q + k]
+    sink_off = np.arange(len(seeds) + 1, dtype=np.int64)
+    sink_buf = np.ascontiguousarray(sink).reshape(-1)
+    src = np.ascontiguousarray(seeds).reshape(-1)
+    eng = (TraversalEngineFactory().traversalColors(g.getColorForSampleName("child")).traversalDirection(FORWARD)
+           .combinationOperator(OR).stoppingRule(DestinationStopper).maxBranchLength(args.max_len).graph(g).links(links).make())
+    n = len(seeds)
+    for _ in range(args.warmup):
+        eng.dfs_batch_arrays(src, n, sink_buf, sink_off)
+    ca.profile_reset()
+    sync()
+    t0 = time.time()
+    traversed = 0
+    found = 0
+    for _ in range(args.steps):
+        b = eng.dfs_batch_arrays(src, n, sink_buf, sink_off)
+        traversed += eng.dfs_kmers_traversed
+    sync()
+    dt = time.time() - t0
+    dfs_ms, launches = ca.profile_get("dfs")
+    found = sum(1 for i in range(n) if b.graph(i) is not None)
+    tot_trav, tot_seeds, max_dt = traversed, n * args.steps, dt
+    if dist is not None:
+        t = torch.tensor([float(traversed), float(n * args.steps)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        tot_trav, tot_seeds, max_dt = int(t[0].item()), int(t[1].item()), m[0].item()
+    if rank == 0:
+        N, W, C = g.getNumRecords(), g.getKmerBits(), g.getNumColors()
+        M = max(2, links.numKmersWithLinks)
+        b_find = math.ceil(math.log2(N)) * 8 * W + 5 * C
+        b_link = math.ceil(math.log2(M)) * 8 * W
+        avg_ms = dfs_ms / max(1, launches)
+        achieved = (traversed / max(1, launches)) * (b_find + b_link) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "k-mers traversed/sec (whole node) + contigs/sec, k=47 3-color LdBG",
+            "value": tot_trav / max_dt, "unit": "k-mers traversed/s", "contigs_per_s": tot_seeds / max_dt,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": "configs[3]: same %.1f Mb 3-colour k=%d LdBG with child links; dfs with DestinationStopper, FORWARD, from %d seeds per GPU "
+                            "to the child k-mer 200-2000 bp downstream on the seed's contig; timed: the C-ABI call (kernel, log download, "
+                            "graph assembly on the host)" % (args.genome_len / 1e6, k, n, ),
+                "records": N, "seeds_per_gpu": n, "kmers_traversed_per_step": traversed // args.steps, "sinks_reached": found,
+                "multi_gpu": "replicated graph, seeds partitioned, no data-path collective" if world > 1 else "single GPU",
+                "load_seconds": round(t_load, 2),
+            },
+            "roofline": {"bound": "hbm", "kernel": "k_dfs<%d>" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_kmer": b_find + b_link,
+                         "avg_launch_ms": avg_ms, "launches": launches},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import pyoracle as orc
+            og = orc.Graph(prefix + ".ctx", use_cache=True, tuned=False)
+            ol = orc.Links(prefix + ".ctp.gz")
+            oe = orc.Engine(og, [0], links=[ol], stopper="DestinationStopper", max_length=args.max_len, direction=orc.FORWARD)
+            t1 = time.time()
+            i = mism = 0
+            while i < n and time.time() - t1 < args.cpu_seconds:
+                r = oe.dfs(seeds[i].tobytes().decode(), [sink[i].tobytes().decode()])
+                gi = b.graph(i)
+                same = (gi is None) == r.is_null and (r.is_null or (gi.vertex_tuples() == r.vertices() and gi.edge_tuples() == r.edges()))
+                mism += 0 if same else 1
+                r.free()
+                i += 1
+            dtc = time.time() - t1
+            out["cpu_baseline"] = {"value": oe.kmers_traversed() / dtc, "unit": "k-mers traversed/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d seeds (%d k-mers traversed in %.1f s), oracle in faithful mode" % (i, oe.kmers_traversed(), dtc),
+                                   "contigs_per_s": i / dtc}
+            out["parity"] = "%d/%d sampled dfs graphs bit-exact vs oracle (vertices and edges in insertion order)" % (i - mism, i)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +182,8 @@ def main():
     ap.add_argument("--repeat-families", type=int, default=4000)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c3", "c4"], default="c3",
+                    help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
     ap.add_argument("--use-seeds", type=int, default=0, help="experiment: walk only the first N seeds")
     ap.add_argument("--no-links", action="store_true", help="experiment: walk without the link annotations")
     ap.add_argument("--no-strict", action="store_true", help="experiment: CanonicalKmer.isFlipped by comparison (not Java-exact, Q6)")
@@ -128,6 +226,9 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+
+    if args.workload == "c4":
+        return bench_c4(args, ca, g, links, eng, seeds, st, prefix, rank, world, dist, sync, t_load)
 
     for _ in range(args.warmup):
         eng.walk_batch_arrays(seeds, fetch=False)

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <functional>
 #include <unordered_map>
+#include <thread>
 #include <unordered_set>
 
 #include "stoppers.h"
@@ -460,47 +461,55 @@ struct VKeyHash {
         return (size_t)(x ^ (x >> 29));
     }
 };
-struct PairHash { size_t operator()(const std::pair<int, int>& p) const { return (size_t)((uint64_t)(uint32_t)p.first << 32 | (uint32_t)p.second) * 0x9E3779B97F4A7C15ull; } };
-
-// the part of JGraphT's DirectedWeightedPseudograph the reference relies on: insertion-ordered vertex and edge
+// The part of JGraphT's DirectedWeightedPseudograph the reference relies on: insertion-ordered vertex and edge
 // sets, addVertex/addEdge that refuse duplicates (CortexVertex.equals :67-80, CortexEdge.equals :42-57 — an edge
-// equals another with the same two endpoints in EITHER direction and the same colour), Graphs.addGraph
+// equals another with the same two endpoints in EITHER direction and the same colour), Graphs.addGraph.
+// The hash indices are built lazily: a branch's own vertices are new by construction (they were not in `visited`),
+// and so is everything its FIRST returning child brings; only a second returning child (siblings do not see each
+// other's visited sets) can repeat vertices or edges.
 struct HGraph {
     std::vector<VKey> verts;
     std::vector<DfsEdge> edges;
+    bool indexed = false;
     std::unordered_map<VKey, int, VKeyHash> vmap;
-    std::unordered_set<std::pair<int, int>, PairHash> dir;
-    std::unordered_set<uint64_t> und;
-    int add_vertex(const VKey& v) {
-        auto it = vmap.find(v);
-        if (it != vmap.end()) return it->second;
+    std::unordered_set<uint64_t> dir, und;
+    static uint64_t dir_key(int s, int t) { return ((uint64_t)(uint32_t)s << 32) | (uint32_t)t; }
+    static uint64_t und_key(int s, int t, int color) {
+        return ((uint64_t)(uint32_t)std::min(s, t) << 38) | ((uint64_t)(uint32_t)std::max(s, t) << 12) | (uint64_t)(uint32_t)(color & 0xFFF);
+    }
+    void ensure_index() {
+        if (indexed) return;
+        indexed = true;
+        vmap.reserve(verts.size() * 2);
+        for (size_t i = 0; i < verts.size(); i++) vmap.emplace(verts[i], (int)i);
+        for (auto& e : edges) { dir.insert(dir_key(e.src, e.dst)); und.insert(und_key(e.src, e.dst, e.color)); }
+    }
+    int add_vertex_new(const VKey& v) {                 // caller knows v is not in the graph
         verts.push_back(v);
-        vmap.emplace(v, (int)verts.size() - 1);
+        if (indexed) vmap.emplace(v, (int)verts.size() - 1);
         return (int)verts.size() - 1;
     }
-    bool contains_edge(int s, int t) const { return dir.count({s, t}) != 0; }
-    void add_edge(int s, int t, int color) {
-        const uint64_t key = ((uint64_t)(uint32_t)std::min(s, t) << 38) | ((uint64_t)(uint32_t)std::max(s, t) << 12) | (uint64_t)(uint32_t)(color & 0xFFF);
-        if (!und.insert(key).second) return;
-        dir.insert({s, t});
+    int add_vertex(const VKey& v) {
+        ensure_index();
+        auto it = vmap.find(v);
+        if (it != vmap.end()) return it->second;
+        return add_vertex_new(v);
+    }
+    void add_edge_new(int s, int t, int color) {        // caller knows no equal edge exists
         edges.push_back({s, t, color});
+        if (indexed) { dir.insert(dir_key(s, t)); und.insert(und_key(s, t, color)); }
     }
-    void add_graph(const HGraph& o) {
-        for (auto& v : o.verts) add_vertex(v);
-        for (auto& ed : o.edges) add_edge(add_vertex(o.verts[ed.src]), add_vertex(o.verts[ed.dst]), ed.color);
-    }
-    // connectVertex(g, cv, {pv} or {nv}) :494-516
-    void connect(const VKey& cv, const VKey& av, bool fwd, int color) {
-        const int ci = add_vertex(cv);
-        const int ai = add_vertex(av);
-        if (fwd) { if (!contains_edge(ci, ai)) add_edge(ci, ai, color); }
-        else { if (!contains_edge(ai, ci)) add_edge(ai, ci, color); }
+    void add_edge(int s, int t, int color) {            // Graph.addEdge: refused when an equal CortexEdge is present
+        ensure_index();
+        if (!und.insert(und_key(s, t, color)).second) return;
+        dir.insert(dir_key(s, t));
+        edges.push_back({s, t, color});
     }
 };
 
 struct LogParser {
     const uint64_t* log;
-    int64_t n, pos = 0;
+    int64_t n, pos;
     int W, color;
     bool fwd;
     std::vector<std::vector<uint64_t>>& null_kmers;    // interned k-mers of vertices without a record
@@ -528,23 +537,49 @@ struct LogParser {
         }
         return v;
     }
-    // one branch: the graph dfs(...) returned, and the vertex it started from
-    void parse_branch(HGraph& g, VKey& v0) {
+    void add_link(HGraph& g, int ci, int ai) { if (fwd) g.add_edge_new(ci, ai, color); else g.add_edge_new(ai, ci, color); }
+    // One branch: the graph dfs(...) returned, the vertex it started from and where that vertex sits in the graph
+    // (-1: not in it — a branch that decided at its first vertex returns an empty graph, :373-481).
+    void parse_branch(HGraph& g, VKey& v0, int& v0_index) {
         if (pos >= n || log[pos] != DFS_OPEN) throw StatusError(LDBG_ERR_HIP, "dfs log: OPEN expected");
         pos++;
         v0 = read_vertex();
+        v0_index = -1;
         VKey cv = v0;
-        while (pos < n && !(log[pos] & DFS_MARK)) {
-            VKey av = read_vertex();
-            g.connect(cv, av, fwd, color);
-            cv = av;
+        int cv_index = -1;
+        while (pos < n && !(log[pos] & DFS_MARK)) {          // connectVertex(g, cv, {av}) per step :432-440
+            const VKey av = read_vertex();
+            if (cv_index < 0) { cv_index = g.add_vertex_new(cv); v0_index = cv_index; }
+            const int ai = g.add_vertex_new(av);
+            add_link(g, cv_index, ai);
+            cv = av; cv_index = ai;
         }
+        int merged = 0;
+        std::vector<int> map;
         while (pos < n && log[pos] == DFS_OPEN) {
-            HGraph branch;
+            HGraph br;
             VKey c0;
-            parse_branch(branch, c0);
-            branch.connect(cv, c0, fwd, color);         // :447-453
-            g.add_graph(branch);                        // Graphs.addGraph(g, branch) :454
+            int c0_index;
+            parse_branch(br, c0, c0_index);
+            // connectVertex(branch, cv, {av}) :447-453 — cv was in `visited`, so the branch cannot contain it
+            const int br_cv = br.add_vertex_new(cv);
+            if (c0_index < 0) c0_index = br.add_vertex_new(c0);
+            add_link(br, br_cv, c0_index);
+            // Graphs.addGraph(g, branch) :454 — vertices in the branch's order, then its edges
+            map.resize(br.verts.size());
+            if (merged == 0 && !g.indexed) {
+                for (size_t j = 0; j < br.verts.size(); j++) {
+                    if ((int)j == br_cv) { if (cv_index < 0) cv_index = g.add_vertex_new(cv); map[j] = cv_index; }
+                    else map[j] = g.add_vertex_new(br.verts[j]);
+                }
+                for (auto& ed : br.edges) g.add_edge_new(map[ed.src], map[ed.dst], ed.color);
+            } else {
+                for (size_t j = 0; j < br.verts.size(); j++) map[j] = g.add_vertex(br.verts[j]);
+                if (cv_index < 0) cv_index = map[(size_t)br_cv];
+                for (auto& ed : br.edges) g.add_edge(map[ed.src], map[ed.dst], ed.color);
+            }
+            if (v0_index < 0 && cv == v0) v0_index = cv_index;
+            merged++;
         }
         if (pos >= n || log[pos] != DFS_CLOSE) throw StatusError(LDBG_ERR_HIP, "dfs log: CLOSE expected");
         pos++;
@@ -776,50 +811,86 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         rt::stream_sync(s);
     }
 
-    // replay the JGraphT container semantics (dfs(source, sinks) :64-106)
+    // replay the JGraphT container semantics (dfs(source, sinks) :64-106); seeds are independent -> host threads
     const int color = cfg.traversal_colors[0];
     const bool op_and = cfg.combination_operator == LDBG_OP_AND;
+    const bool run_r = a.w.run_rev != 0, run_f = a.w.run_fwd != 0;
+    const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)16, n / 64 + 1}));
+    std::vector<std::vector<uint64_t>> thread_keys((size_t)n_threads);
+    std::vector<std::string> thread_err((size_t)n_threads);
+    auto assemble_range = [&](int t, int64_t lo, int64_t hi) {
+        try {
+            std::vector<uint64_t>& keys = thread_keys[(size_t)t];
+            for (int64_t i = lo; i < hi; i++) {
+                DfsGraphHost& r = out.results[(size_t)(first + i)];
+                std::unordered_map<std::string, uint32_t> null_ids;
+                HGraph dir_g[2];
+                bool have[2] = {false, false};
+                int seed_at[2] = {-1, -1};
+                for (int d = 0; d < 2; d++) {
+                    const int64_t sidx = 2 * i + d;
+                    if (status[sidx] != ST_OK) continue;       // ST_BRANCH_NULL: that direction returned null
+                    have[d] = true;
+                    if (strand_n[sidx] == 0) continue;
+                    LogParser lp{log.data() + strand_off[sidx], (int64_t)strand_n[sidx], 0, W, color, d == 1, r.null_kmers, null_ids};
+                    VKey v0;
+                    lp.parse_branch(dir_g[d], v0, seed_at[d]);
+                }
+                const bool null_r = !run_r || !have[0], null_f = !run_f || !have[1];
+                r.is_null = op_and ? (null_r || null_f) : (null_r && null_f);
+                if (r.is_null) continue;
+                // every vertex but the seed gets index -1 (reverse) / +1 (forward) :75-83, then Graphs.addGraph of the
+                // reverse and the forward graph :85-99 — the two can only share the seed (all other indices differ)
+                int seed_m = -1;
+                std::vector<int> map;
+                for (int d = 0; d < 2; d++) {
+                    if (!have[d]) continue;
+                    const HGraph& g = dir_g[d];
+                    map.resize(g.verts.size());
+                    for (size_t v = 0; v < g.verts.size(); v++) {
+                        const bool is_seed = (int)v == seed_at[d];
+                        if (is_seed && seed_m >= 0) { map[v] = seed_m; continue; }
+                        DfsVertex o;
+                        const VKey& kv = g.verts[v];
+                        o.copy = kv.copy; o.index = is_seed ? 0 : (d == 0 ? -1 : 1);
+                        if (kv.id & DFS_MARK) { o.rec = -1; o.flip = 0; o.slot = -(int64_t)(kv.id & 0xFFFFFFFFull) - 1; }
+                        else { o.rec = (int64_t)(kv.id >> 1) - 1; o.flip = (uint8_t)(kv.id & 1ull); o.slot = (int64_t)keys.size(); keys.push_back(kv.id); }
+                        map[v] = (int)r.verts.size();
+                        if (is_seed) seed_m = map[v];
+                        r.verts.push_back(o);
+                    }
+                    for (auto& ed : g.edges) {
+                        const int s2 = map[ed.src], t2 = map[ed.dst];
+                        bool dup = false;
+                        if (s2 == seed_m && t2 == seed_m)      // a self-loop on the seed is the only edge both directions could hold
+                            for (auto& x : r.edges) dup |= x.src == s2 && x.dst == t2 && x.color == ed.color;
+                        if (!dup) r.edges.push_back({s2, t2, ed.color});
+                    }
+                }
+            }
+        } catch (const std::exception& ex) { thread_err[(size_t)t] = ex.what(); }
+    };
+    {
+        std::vector<std::thread> pool;
+        const int64_t per = (n + n_threads - 1) / n_threads;
+        for (int t = 1; t < n_threads; t++) pool.emplace_back(assemble_range, t, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
+        assemble_range(0, 0, std::min<int64_t>(n, per));
+        for (auto& th : pool) th.join();
+        for (auto& er : thread_err) if (!er.empty()) throw StatusError(LDBG_ERR_HIP, er);
+    }
+    // slots were numbered per thread: make them global
     std::vector<uint64_t> gather_keys;
-    for (int64_t i = 0; i < n; i++) {
-        DfsGraphHost& r = out.results[(size_t)(first + i)];
-        std::unordered_map<std::string, uint32_t> null_ids;
-        HGraph dir_g[2];
-        bool have[2] = {false, false};
-        VKey seed_v{0, 0, 0};
-        for (int d = 0; d < 2; d++) {
-            const int64_t sidx = 2 * i + d;
-            if (status[sidx] != ST_OK) continue;       // ST_BRANCH_NULL: that direction returned null
-            have[d] = true;
-            if (strand_n[sidx] == 0) continue;
-            LogParser lp{log.data() + strand_off[sidx], (int64_t)strand_n[sidx], 0, W, color, d == 1, r.null_kmers, null_ids};
-            VKey v0;
-            lp.parse_branch(dir_g[d], v0);
-            seed_v = v0;
+    {
+        std::vector<int64_t> base((size_t)n_threads + 1, 0);
+        for (int t = 0; t < n_threads; t++) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)thread_keys[(size_t)t].size();
+        gather_keys.reserve((size_t)base[(size_t)n_threads]);
+        for (int t = 0; t < n_threads; t++) gather_keys.insert(gather_keys.end(), thread_keys[(size_t)t].begin(), thread_keys[(size_t)t].end());
+        const int64_t per = (n + n_threads - 1) / n_threads;
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t off = base[(size_t)std::min<int64_t>(n_threads - 1, i / per)];
+            if (off == 0) continue;
+            for (auto& o : out.results[(size_t)(first + i)].verts) if (o.rec >= 0) o.slot += off;
         }
-        const bool run_r = a.w.run_rev != 0, run_f = a.w.run_fwd != 0;
-        const bool null_r = !run_r || !have[0], null_f = !run_f || !have[1];
-        r.is_null = op_and ? (null_r || null_f) : (null_r && null_f);
-        if (r.is_null) continue;
-        HGraph m;
-        for (int d = 0; d < 2; d++) {
-            if (!have[d]) continue;
-            // every vertex but the seed gets index -1 (reverse) / +1 (forward) :75-83, then Graphs.addGraph :85-99
-            HGraph rel;
-            std::vector<VKey> vs = dir_g[d].verts;
-            for (auto& v : vs) if (!(v == seed_v)) v.index = d == 0 ? -1 : 1;
-            for (auto& v : vs) rel.add_vertex(v);
-            for (auto& ed : dir_g[d].edges) rel.add_edge(rel.add_vertex(vs[ed.src]), rel.add_vertex(vs[ed.dst]), ed.color);
-            m.add_graph(rel);
-        }
-        r.verts.resize(m.verts.size());
-        for (size_t v = 0; v < m.verts.size(); v++) {
-            DfsVertex& o = r.verts[v];
-            const VKey& kv = m.verts[v];
-            o.copy = kv.copy; o.index = kv.index;
-            if (kv.id & DFS_MARK) { o.rec = -1; o.flip = 0; o.slot = -(int64_t)(kv.id & 0xFFFFFFFFull) - 1; }
-            else { o.rec = (int64_t)(kv.id >> 1) - 1; o.flip = (uint8_t)(kv.id & 1ull); o.slot = (int64_t)gather_keys.size(); gather_keys.push_back(kv.id); }
-        }
-        r.edges = std::move(m.edges);
     }
     // k-mers and coverages of the vertices, gathered from the probe rows in one launch
     const int64_t ng = (int64_t)gather_keys.size();

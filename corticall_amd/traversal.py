@@ -367,7 +367,6 @@ class TraversalEngine:
     def dfs_batch(self, sources, sinks=None):
         """dfs(source, sinks...) for every source in one device launch; sinks: per source a list of k-mers (or None).
         -> list of DfsGraph / None"""
-        k = self._graph.getKmerSize()
         n = len(sources)
         src = np.frombuffer(b"".join(_as_bytes(s) for s in sources), dtype=np.uint8)
         sink_buf, off = None, None
@@ -376,16 +375,24 @@ class TraversalEngine:
             off = np.zeros(n + 1, dtype=np.int64)
             off[1:] = np.cumsum([len(ss) for ss in sinks])
             sink_buf = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8)
+        batch = self.dfs_batch_arrays(src, n, sink_buf, off)
+        return [batch.graph(i) for i in range(n)]
+
+    def dfs_batch_arrays(self, src, n, sink_buf=None, sink_off=None):
+        """array form: src u8[n*k], sink_buf u8[*], sink_off i64[n+1] (CSR over sink k-mers) -> result batch handle
+        (graph(i) materialises seed i)"""
         res = C.c_void_p()
+        t0 = C.c_int64()
+        self._lib.check(self._d.ldbg_engine_dfs_kmers_traversed(self._h, C.byref(t0)))
         self._lib.check(self._d.ldbg_engine_dfs_batch(
             self._h, src.ctypes.data_as(C.c_char_p), C.c_int64(n),
             sink_buf.ctypes.data_as(C.c_char_p) if sink_buf is not None else None,
-            off.ctypes.data_as(C.c_void_p) if off is not None else None, C.byref(res)))
+            sink_off.ctypes.data_as(C.c_void_p) if sink_off is not None else None, C.byref(res)))
         batch = _DfsBatch(self, res)
         t = C.c_int64()
         self._lib.check(self._d.ldbg_engine_dfs_kmers_traversed(self._h, C.byref(t)))
-        self.dfs_kmers_traversed = t.value
-        return [batch.graph(i) for i in range(n)]
+        self.dfs_kmers_traversed = t.value - t0.value
+        return batch
 
     def seek(self, sk):          # :321-335
         self._lib.check(self._d.ldbg_engine_seek(self._h, _as_bytes(sk)))
