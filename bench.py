@@ -74,6 +74,88 @@ def cpu_baseline(prefix, args, gpu_contigs, seeds_ascii):
     }, n, mismatches
 
 
+def bench_c2(args, ca, rank, local_rank, world, dist):
+    """configs[1]: synthetic 10 Mb 1-colour k=31 graph, batches of random-access lookups (50 % present, random
+    orientation; 50 % random absent), queries resident in HBM.  --sharded: the table is hash-partitioned over the
+    ranks and every batch is routed with all-to-all exchanges (corticall_amd/distributed.py)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from tools import synth
+    from corticall_amd import CortexGraph
+    from corticall_amd.distributed import ShardedCortexGraph, pack_kmers
+    k, L = 31, 10_000_000
+    d = os.environ.get("LDBG_BENCH_DIR", "/tmp/ldbg_bench")
+    os.makedirs(d, exist_ok=True)
+    prefix = os.path.join(d, "c2_L%d_k%d" % (L, k))
+    if not os.path.exists(prefix + ".ctx"):
+        synth.generate(prefix, L, k, colours=1, with_links=False, seed=0xC0FFEE01, n_chrom=1, n_repeat_families=0, repeat_copies=0,
+                       n_indels=0, n_dnm=0, n_tandem=0, n_seeds=100000, threads=min(16, os.cpu_count() or 1))
+    present = np.fromfile(prefix + ".seeds", dtype=np.uint8).reshape(-1, k)
+    rng = np.random.default_rng(0xC0FFEE02 + rank)
+    n = args.lookups
+    q = np.empty((n, k), dtype=np.uint8)
+    half = n // 2
+    q[:half] = present[rng.integers(0, len(present), half)]
+    q[half:] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n - half, k))]
+    q = q[rng.permutation(n)]
+    dev = torch.device("cuda", local_rank)
+    words = torch.from_numpy(pack_kmers(q, k).view(np.int64)).to(dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    if args.sharded:
+        g = ShardedCortexGraph(prefix + ".ctx", device=local_rank)
+        N, W, Cc = g.getNumRecords(), g.W, g.C
+        step = lambda: g.find_packed_dev(words)
+    else:
+        g = CortexGraph(prefix + ".ctx", device=local_rank)
+        N, W, Cc = g.getNumRecords(), g.getKmerBits(), g.getNumColors()
+        idx = torch.empty(n, dtype=torch.int64, device=dev)
+        cov = torch.empty((n, Cc), dtype=torch.int32, device=dev)
+        edges = torch.empty((n, Cc), dtype=torch.uint8, device=dev)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        step = lambda: g._lib.check(g._d.ldbg_graph_find_dev(g._h, P(words), C.c_int64(n), P(idx), P(cov), P(edges), None))
+    for _ in range(args.warmup):
+        step()
+    ca.profile_reset()
+    sync()
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.time() - t0
+    find_ms, launches = ca.profile_get("find")
+    max_dt = dt
+    if dist is not None:
+        m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        max_dt = m[0].item()
+    if rank == 0:
+        b_find = math.ceil(math.log2(N)) * 8 * W + 5 * Cc
+        avg_ms = find_ms / max(1, launches)
+        per_launch = n if not args.sharded else n       # every rank's shard answers about n lookups per step
+        achieved = per_launch * b_find / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        found = int((idx >= 0).sum().item()) if not args.sharded else int(g.find_batch(q)[0].sum())
+        print(json.dumps({
+            "metric": "random-access lookups/sec (configs[1]; not the headline metric)", "value": world * n * args.steps / max_dt, "unit": "lookups/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 10 Mb 1-colour k=31 graph, %d lookups per step and GPU (50%% present)%s"
+                                   % (n, ", table hash-sharded over the ranks, all-to-all routed" if args.sharded else ""),
+                       "records": N, "found": found},
+            "roofline": {"bound": "hbm", "kernel": "k_find<%d>" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_lookup": b_find,
+                         "avg_launch_ms": avg_ms, "launches": launches},
+        }))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist, sync, t_load):
     """configs[3]: dfs with DestinationStopper (the gap-closing configuration of Call.java:759-779) from every seed
     towards the child k-mer 200-2000 bp downstream on the seed's own link-guided contig."""
@@ -182,7 +264,9 @@ def main():
     ap.add_argument("--repeat-families", type=int, default=4000)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c3", "c4"], default="c3",
+    ap.add_argument("--lookups", type=int, default=100000, help="c2: lookups per step (configs[1] says 100k)")
+    ap.add_argument("--sharded", action="store_true", help="c2: hash-shard the table over the ranks and route lookups with all-to-all")
+    ap.add_argument("--workload", choices=["c3", "c4", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
     ap.add_argument("--use-seeds", type=int, default=0, help="experiment: walk only the first N seeds")
     ap.add_argument("--no-links", action="store_true", help="experiment: walk without the link annotations")
@@ -195,14 +279,20 @@ def main():
     import numpy as np
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import corticall_amd as ca
     from corticall_amd import BOTH, OR, ContigStopper, CortexGraph, CortexLinks, TraversalEngineFactory
+
+    if args.workload == "c2":
+        return bench_c2(args, ca, rank, local_rank, world, dist)
 
     prefix, st = workload_files(args, 0)        # same graph on every rank
     seeds = np.fromfile(prefix + ".seeds", dtype=np.uint8).reshape(-1, args.k)

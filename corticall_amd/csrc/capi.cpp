@@ -83,6 +83,9 @@ ldbg_status ldbg_graph_info(const ldbg_graph* g, int* k, int* W, int* C, int64_t
     });
 }
 ldbg_status ldbg_graph_device(const ldbg_graph* g, int* device) { *device = g->g.device; return LDBG_OK; }
+ldbg_status ldbg_graph_set_shard(ldbg_graph* g, int is_shard) {
+    return guard([&] { g->g.view.java_tiny = (!is_shard && g->g.view.N <= 2) ? 1 : 0; });
+}
 ldbg_status ldbg_graph_sample_name(const ldbg_graph* g, int color, char* buf, int buflen) {
     return guard([&] {
         if (color < 0 || color >= g->g.hdr.C) throw StatusError(LDBG_ERR_ARG, "colour out of range");
@@ -138,6 +141,29 @@ ldbg_status ldbg_graph_find_dev(const ldbg_graph* g, const uint64_t* d_packed, i
     return guard([&] {
         rt::set_device(g->g.device);
         g->g.find_dev(d_packed, n, d_idx, d_cov, d_edges, stream ? (rt::stream_t)stream : g->g.stream);
+    });
+}
+ldbg_status ldbg_shard_owner_dev(int k, const uint64_t* d_packed, int64_t n, int world, uint64_t* d_canon, int32_t* d_owner, void* stream) {
+    return guard([&] {
+        shard_owner_dev(k, d_packed, n, world, d_canon, d_owner, (rt::stream_t)stream);
+        rt::stream_sync((rt::stream_t)stream);
+    });
+}
+ldbg_status ldbg_shard_owner(int k, const uint64_t* packed, int64_t n, int world, int device, int32_t* owner) {
+    return guard([&] {
+        if (n <= 0) return;
+        if (rt::device_count() <= device) throw StatusError(LDBG_ERR_HIP, "no HIP device " + std::to_string(device) + " available (libldbg has no CPU fallback)");
+        rt::set_device(device);
+        const int W = (k + 31) / 32;
+        rt::stream_t s = rt::stream_create();
+        uint64_t* dq = (uint64_t*)rt::dmalloc((size_t)n * W * 8);
+        int32_t* d_o = (int32_t*)rt::dmalloc((size_t)n * 4);
+        rt::h2d(dq, packed, (size_t)n * W * 8, s);
+        shard_owner_dev(k, dq, n, world, nullptr, d_o, s);
+        rt::d2h(owner, d_o, (size_t)n * 4, s);
+        rt::stream_sync(s);
+        rt::dfree(dq); rt::dfree(d_o);
+        rt::stream_destroy(s);
     });
 }
 ldbg_status ldbg_graph_find(const ldbg_graph* g, const uint64_t* packed, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {

@@ -173,8 +173,50 @@ LDBG_KERNEL void k_find(GraphView g, const uint64_t* packed, int64_t n, int64_t*
     }
 }
 
+// owner of a k-mer in a table hash-partitioned over `world` devices: a 64-bit mix of the CANONICAL k-mer's words.
+// Queries that are not k-mers (Q4) go to shard 0, where they miss like everywhere else.
+LDBG_HOSTDEV uint64_t shard_mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+template <int W>
+LDBG_KERNEL void k_owner(int k, const uint64_t* packed, int64_t n, int world, uint64_t* canon_out, int32_t* owner_out) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        Kmer<W> q;
+#pragma unroll
+        for (int w = 0; w < W; w++) q.w[w] = packed[i * W + w];
+        const int top = 2 * k - 64 * (W - 1);
+        const bool valid = top >= 64 || (q.w[0] >> top) == 0;
+        int32_t owner = 0;
+        if (valid) {
+            bool f;
+            q = kmer_canonical<W>(q, k, &f);
+            uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+            for (int w = 0; w < W; w++) h = shard_mix64(h ^ kmer_word<W>(q, w));
+            owner = (int32_t)(h % (uint64_t)world);
+        }
+        if (canon_out) for (int w = 0; w < W; w++) canon_out[i * W + w] = kmer_word<W>(q, w);
+        owner_out[i] = owner;
+    }
+}
+static int grid_for(int64_t n, int block, int max_blocks);
+void shard_owner_dev(int k, const uint64_t* d_packed, int64_t n, int world, uint64_t* d_canon, int32_t* d_owner, rt::stream_t s) {
+    if (n <= 0) return;
+    if (k <= 0 || k > 128 || world <= 0) throw StatusError(LDBG_ERR_ARG, "shard_owner: bad k or world size");
+    const int W = (k + 31) / 32;
+    const int grid = grid_for(n, 256, 256 * 16);
+    switch (W) {
+        case 1: LDBG_LAUNCH(k_owner<1>, grid, 256, s, k, d_packed, n, world, d_canon, d_owner); break;
+        case 2: LDBG_LAUNCH(k_owner<2>, grid, 256, s, k, d_packed, n, world, d_canon, d_owner); break;
+        case 3: LDBG_LAUNCH(k_owner<3>, grid, 256, s, k, d_packed, n, world, d_canon, d_owner); break;
+        default: LDBG_LAUNCH(k_owner<4>, grid, 256, s, k, d_packed, n, world, d_canon, d_owner); break;
+    }
+}
+
 // ------------------------------------------------------------------ host side
-static int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 8) {
+static int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 8);
+static int grid_for(int64_t n, int block, int max_blocks) {
     int64_t b = (n + block - 1) / block;
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;

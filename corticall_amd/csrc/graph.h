@@ -105,6 +105,9 @@ private:
     void upload(const uint8_t* records_host);
 };
 
+// hash partitioning of the table over devices (graph.cpp)
+void shard_owner_dev(int k, const uint64_t* d_packed, int64_t n, int world, uint64_t* d_canon, int32_t* d_owner, rt::stream_t s);
+
 // timing registry for bench.py (ldbg_profile_get)
 void profile_add(const char* family, double ms);
 

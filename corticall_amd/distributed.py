@@ -1,0 +1,178 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  Two regimes:
+
+* replicas — the table fits one GPU (configs C2-C4 are ~2 GB): every rank loads the graph, the seeds are
+  partitioned, there is NO data-path collective; `partition()` / `gather_strings()` below are all it needs.
+* hash-sharded table — `ShardedCortexGraph`: rank r keeps the records whose canonical k-mer hashes to r (still
+  sorted, so the per-shard lookup is the unchanged HIP find kernel).  A batch of findRecord queries is routed
+  with ONE exchange each way: canonicalise + owner on the device (ldbg_shard_owner_dev), bucket by owner,
+  all-to-all the queries, local find (ldbg_graph_find_dev), all-to-all the answers back.
+
+torch is plumbing here (device buffers, process group, collectives); every computation on k-mers is a kernel
+behind the C ABI.
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+from . import _native
+from .graph import CortexGraph
+
+
+def partition(n, rank, world):
+    """contiguous share of n independent units (seeds) for `rank` -> (first, count)"""
+    per, extra = divmod(int(n), int(world))
+    first = rank * per + min(rank, extra)
+    return first, per + (1 if rank < extra else 0)
+
+
+def gather_strings(local, group=None):
+    """all ranks' lists of strings, concatenated in rank order, on every rank"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = [None] * world
+    dist.all_gather_object(out, list(local), group=group)
+    return [s for part in out for s in part]
+
+
+def ctx_header(buf):
+    """Cortex v6 header (CortexGraph.java:66-168, docs/ctx_spec.md) -> dict(k, W, C, data_offset)"""
+    if bytes(buf[0:6]) != b"CORTEX":
+        raise _native.CortexJDKException("The file does not appear to be a Cortex graph (bad magic)")
+    version, k, W, Cc = struct.unpack_from("<IIII", buf, 6)
+    if version != 6:
+        raise _native.CortexJDKException("The file is a Cortex graph of version %d; only version 6 is supported" % version)
+    p = 22 + 4 * Cc + 8 * Cc
+    for _ in range(Cc):
+        (ln,) = struct.unpack_from("<I", buf, p)
+        p += 4 + ln
+    p += 16 * Cc
+    for _ in range(Cc):
+        p += 4 + 4 + 4
+        (ln,) = struct.unpack_from("<I", buf, p)
+        p += 4 + ln
+    if bytes(buf[p:p + 6]) != b"CORTEX":
+        raise _native.CortexJDKException("The Cortex graph header does not end with the magic word")
+    return {"k": k, "W": W, "C": Cc, "data_offset": p + 6}
+
+
+_LUT = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _LUT[_c] = _i
+    _LUT[ord(chr(_c).lower())] = _i
+
+
+def pack_kmers(ascii_kmers, k):
+    """ASCII u8[n,k] -> packed words u64[n,W] (word 0 most significant); a non-ACGT k-mer gets all-ones words,
+    which every kernel treats as "not a k-mer" (Q4)"""
+    a = np.ascontiguousarray(ascii_kmers, dtype=np.uint8).reshape(-1, k)
+    W = (k + 31) // 32
+    codes = _LUT[a]
+    bad = (codes == 255).any(axis=1)
+    codes = np.where(codes == 255, 0, codes).astype(np.uint64)
+    words = np.zeros((a.shape[0], W), dtype=np.uint64)
+    for i in range(k):
+        bit = 2 * (k - 1 - i)
+        words[:, W - 1 - (bit >> 6)] |= codes[:, i] << np.uint64(bit & 63)
+    words[bad] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    return words
+
+
+class ShardedCortexGraph:
+    """A .ctx table hash-partitioned over the ranks of a process group."""
+
+    def __init__(self, path, device=0, lib=None, group=None, chunk_records=1 << 22):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self._group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._lib = lib or _native.default_lib()
+        self._d = self._lib.dll
+        self.path = str(path)
+        raw = np.memmap(self.path, dtype=np.uint8, mode="r")
+        h = ctx_header(raw)
+        self.k, self.W, self.C = h["k"], h["W"], h["C"]
+        rec = 8 * self.W + 5 * self.C
+        n_all = (raw.size - h["data_offset"]) // rec
+        records = raw[h["data_offset"]:h["data_offset"] + n_all * rec].reshape(n_all, rec)
+        # cut this rank's shard: owner of every record's k-mer, a chunk at a time (the rule lives in the library)
+        mine = []
+        for lo in range(0, n_all, chunk_records):
+            blk = records[lo:lo + chunk_records]
+            keys = np.ascontiguousarray(blk[:, :8 * self.W]).view("<u8").reshape(-1, self.W)
+            owner = np.empty(len(blk), dtype=np.int32)
+            self._lib.check(self._d.ldbg_shard_owner(self.k, keys.ctypes.data_as(C.c_void_p), C.c_int64(len(blk)), self.world,
+                                                     int(device), owner.ctypes.data_as(C.c_void_p)))
+            mine.append(np.ascontiguousarray(blk[owner == self.rank]))
+        shard = np.concatenate(mine) if mine else np.zeros((0, rec), dtype=np.uint8)
+        image = np.concatenate([np.asarray(raw[:h["data_offset"]]), shard.reshape(-1)])
+        self.shard = CortexGraph(self.path + "#shard%d" % self.rank, device=device, lib=self._lib, image=image)
+        self._lib.check(self._d.ldbg_graph_set_shard(self.shard._h, 1))
+        self.device = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
+        n = torch.tensor([self.shard.getNumRecords()], dtype=torch.int64, device=self.device)
+        dist.all_reduce(n, group=group)
+        self.numRecords = int(n.item())
+
+    def getNumRecords(self): return self.numRecords
+    def getKmerSize(self): return self.k
+    def getNumColors(self): return self.C
+
+    def _ptr(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def find_batch(self, kmers):
+        """findRecord for this rank's queries (every rank calls, with its own batch — possibly empty).
+        kmers: ASCII np.uint8[n,k] or list of str -> (found bool[n], cov i32[n,C], edges u8[n,C], owner i32[n], local_idx i64[n])"""
+        torch = self._torch
+        if not isinstance(kmers, np.ndarray):
+            kmers = np.frombuffer(b"".join(x.encode() if isinstance(x, str) else bytes(x) for x in kmers), dtype=np.uint8)
+        q = torch.from_numpy(pack_kmers(kmers, self.k).view(np.int64)).to(self.device)
+        found, l_cov, l_edges, owner, l_idx = self.find_packed_dev(q)
+        return (found.cpu().numpy(), l_cov.cpu().numpy(), l_edges.cpu().numpy(), owner.cpu().numpy(), l_idx.cpu().numpy())
+
+    def find_packed_dev(self, q):
+        """device form: q = packed k-mer words, int64[n, W] on this rank's device (all-ones words = not a k-mer)
+        -> (found, cov, edges, owner, local_idx) as device tensors; nothing touches the host but the split sizes"""
+        torch, dist = self._torch, self._dist
+        n, W, Cc, world = q.shape[0], self.W, self.C, self.world
+        canon = torch.empty_like(q)
+        owner = torch.empty(max(1, n), dtype=torch.int32, device=self.device)[:n]
+        if n:
+            self._lib.check(self._d.ldbg_shard_owner_dev(self.k, self._ptr(q), C.c_int64(n), world, self._ptr(canon), self._ptr(owner), None))
+        # bucket by owner
+        order = torch.argsort(owner.to(torch.int64), stable=True)
+        send = canon[order].contiguous()
+        send_counts = torch.bincount(owner.to(torch.int64), minlength=world)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self._group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        m = int(sum(rc))
+        recv = torch.empty((m, W), dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=self._group)
+        # local lookups
+        idx = torch.full((max(1, m),), -1, dtype=torch.int64, device=self.device)[:m]
+        cov = torch.zeros((max(1, m), Cc), dtype=torch.int32, device=self.device)[:m]
+        edges = torch.zeros((max(1, m), Cc), dtype=torch.uint8, device=self.device)[:m]
+        if m:
+            self._lib.check(self._d.ldbg_graph_find_dev(self.shard._h, self._ptr(recv), C.c_int64(m), self._ptr(idx), self._ptr(cov), self._ptr(edges), None))
+        # answers travel back along the same splits
+        r_idx = torch.empty(n, dtype=torch.int64, device=self.device)
+        r_cov = torch.empty((n, Cc), dtype=torch.int32, device=self.device)
+        r_edges = torch.empty((n, Cc), dtype=torch.uint8, device=self.device)
+        dist.all_to_all_single(r_idx, idx.contiguous(), output_split_sizes=sc, input_split_sizes=rc, group=self._group)
+        dist.all_to_all_single(r_cov, cov.contiguous(), output_split_sizes=sc, input_split_sizes=rc, group=self._group)
+        dist.all_to_all_single(r_edges, edges.contiguous(), output_split_sizes=sc, input_split_sizes=rc, group=self._group)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(n, device=self.device)
+        l_idx, l_cov, l_edges = r_idx[inv], r_cov[inv], r_edges[inv]
+        found = l_idx >= 0
+        if self.numRecords <= 2:       # Q1 is a property of the whole graph (CortexGraph.java:274-282)
+            found = torch.zeros_like(found)
+            l_idx = torch.full_like(l_idx, -1)
+            l_cov, l_edges = torch.zeros_like(l_cov), torch.zeros_like(l_edges)
+        return found, l_cov, l_edges, owner, l_idx
+
+    def close(self):
+        self.shard.close()

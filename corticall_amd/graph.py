@@ -85,12 +85,17 @@ class CortexRecord:
 class CortexGraph:
     """J/utils/io/graph/cortex/CortexGraph.java — here: a .ctx file resident in MI355X HBM."""
 
-    def __init__(self, path, device=0, lib=None):
+    def __init__(self, path, device=0, lib=None, image=None):
+        """image: bytes-like .ctx image to load instead of the file at `path` (ldbg_graph_open_memory)"""
         self._lib = lib or _native.default_lib()
         self._d = self._lib.dll
         self.path = str(path)
         h = C.c_void_p()
-        self._lib.check(self._d.ldbg_graph_open(self.path.encode(), int(device), C.byref(h)))
+        if image is None:
+            self._lib.check(self._d.ldbg_graph_open(self.path.encode(), int(device), C.byref(h)))
+        else:
+            buf = np.frombuffer(image, dtype=np.uint8)
+            self._lib.check(self._d.ldbg_graph_open_memory(buf.ctypes.data_as(C.c_void_p), C.c_int64(buf.size), int(device), C.byref(h)))
         self._h = h
         k, W, Cc, N, v = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
         self._lib.check(self._d.ldbg_graph_info(h, C.byref(k), C.byref(W), C.byref(Cc), C.byref(N), C.byref(v)))

@@ -67,6 +67,10 @@ ldbg_status ldbg_graph_close(ldbg_graph* g);                                    
 /* getKmerSize/getKmerBits/getNumColors/getNumRecords/getVersion   CortexGraph.java:325-335 */
 ldbg_status ldbg_graph_info(const ldbg_graph* g, int* k, int* W, int* C, int64_t* N, int* version);
 ldbg_status ldbg_graph_device(const ldbg_graph* g, int* device);
+/* A shard of a hash-partitioned table (corticall_amd/distributed.py) must answer membership exactly: quirk Q1
+ * (findRecord never finds anything in a graph of <= 2 records, CortexGraph.java:274-282) is a property of the whole
+ * graph and is applied by the partitioned front end.  is_shard != 0 turns Q1 off for this handle. */
+ldbg_status ldbg_graph_set_shard(ldbg_graph* g, int is_shard);
 /* getSampleName(color) / getColor(color)                          CortexGraph.java:329,335 */
 ldbg_status ldbg_graph_sample_name(const ldbg_graph* g, int color, char* buf, int buflen);
 typedef struct {
@@ -99,6 +103,14 @@ ldbg_status ldbg_graph_find_ascii(const ldbg_graph* g, const char* kmers, int64_
                                   int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out);
 ldbg_status ldbg_graph_find_dev(const ldbg_graph* g, const uint64_t* d_packed, int64_t n,
                                 int64_t* d_idx_out, uint32_t* d_cov_out, uint8_t* d_edges_out, void* stream);
+
+/* ------------------------------------------------------------------ hash partitioning over devices
+ * owner[i] = mix64(canonical k-mer i) mod world — the rule by which the sorted table is split into per-device
+ * shards (each still sorted) and by which a lookup is routed to the shard that can answer it.  The _dev form
+ * works on device buffers (d_canon, n x W canonical words, may be NULL) and is what the exchange step of
+ * corticall_amd/distributed.py calls between its all-to-alls; the host form is used when the shards are cut. */
+ldbg_status ldbg_shard_owner_dev(int k, const uint64_t* d_packed, int64_t n, int world, uint64_t* d_canon, int32_t* d_owner, void* stream);
+ldbg_status ldbg_shard_owner(int k, const uint64_t* packed, int64_t n, int world, int device, int32_t* owner);
 
 /* ------------------------------------------------------------------ links: L3-L4
  * new CortexLinks(path) -> CortexLinksMap        J/utils/io/graph/links/CortexLinks.java:16-25,

@@ -1,0 +1,146 @@
+"""N > 1 paths on CPU: two gloo ranks, kernels through the TEST-ONLY host simulation (tests/hostsim).
+ * hash-sharded table: every rank holds its shard; findRecord batches are routed with all-to-all exchanges and
+   must answer exactly like the oracle on the whole graph
+ * replicas: seeds partitioned over the ranks, contigs gathered — identical to a single-process run"""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def _sharded_worker(rank, world, port, paths):
+    dist = _init(rank, world, port)
+    try:
+        from corticall_amd.distributed import ShardedCortexGraph
+        from oracle import pyoracle as orc
+        from tests import hostsim
+        lib = hostsim.load()
+        for path in paths:
+            og = orc.Graph(path, tuned=True)
+            sg = ShardedCortexGraph(path, lib=lib, chunk_records=1000)
+            assert sg.getNumRecords() == og.N
+            n_mine = sg.shard.getNumRecords()
+            rng = random.Random(17 + rank)
+            kmers = [og.record_string(i).split()[0] for i in rng.sample(range(og.N), min(og.N, 300))]
+            qs = [k if rng.random() < 0.5 else orc.revcomp(k) for k in kmers]
+            qs += ["".join(rng.choice("ACGT") for _ in range(og.k)) for _ in range(100)] + ["N" * og.k]
+            if rank == 1:
+                qs = qs[:57]                       # ragged batches; the exchange must cope
+            found, cov, edges, owner, lidx = sg.find_batch(qs)
+            for i, q in enumerate(qs):
+                eidx, ecov, eedges = og.find(q)
+                assert bool(found[i]) == (eidx >= 0), (path, q)
+                if eidx >= 0:
+                    assert ecov == [int(c) for c in cov[i]] and eedges == [int(x) for x in edges[i]], (q, ecov, cov[i])
+                    assert 0 <= lidx[i] and 0 <= owner[i] < world
+                else:
+                    assert lidx[i] == -1 and not cov[i].any() and not edges[i].any()
+            # an empty batch on one rank while the other asks
+            found, *_ = sg.find_batch(qs[:5] if rank == 0 else [])
+            assert len(found) == (5 if rank == 0 else 0)
+            # the shards partition the table
+            import torch
+            t = torch.tensor([n_mine])
+            dist.all_reduce(t)
+            assert int(t.item()) == og.N and (og.N < 20 or 0 < n_mine < og.N)
+            sg.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _replica_worker(rank, world, port, ctx, ctp, seeds, expected):
+    _init(rank, world, port)
+    import torch.distributed as dist
+    try:
+        from corticall_amd import BOTH, OR, ContigStopper, CortexGraph, CortexLinks, TraversalEngineFactory
+        from corticall_amd.distributed import gather_strings, partition
+        from tests import hostsim
+        lib = hostsim.load()
+        g = CortexGraph(ctx, lib=lib)
+        e = (TraversalEngineFactory(lib=lib).traversalColors(0).traversalDirection(BOTH).combinationOperator(OR)
+             .stoppingRule(ContigStopper).graph(g).links(CortexLinks(ctp, g)).maxBranchLength(300).make())
+        first, cnt = partition(len(seeds), rank, world)
+        contigs, _ = e.walk_batch(seeds[first:first + cnt]) if cnt else ([], None)
+        everything = gather_strings(contigs)
+        assert everything == expected
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, args, world=2):
+    import torch.multiprocessing as mp
+    mp.spawn(fn, args=(world, _free_port()) + tuple(args), nprocs=world, join=True)
+
+
+def test_partition_covers_everything():
+    from corticall_amd.distributed import partition
+    for n in (0, 1, 7, 64, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [partition(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+
+
+def test_pack_kmers_matches_library(orc):
+    from corticall_amd.distributed import pack_kmers
+    rng = random.Random(3)
+    for k in (5, 31, 32, 33, 47, 64, 65):
+        ks = ["".join(rng.choice("ACGT") for _ in range(k)) for _ in range(20)]
+        a = np.frombuffer("".join(ks).encode(), dtype=np.uint8).reshape(-1, k)
+        w = pack_kmers(a, k)
+        for i, s in enumerate(ks):
+            assert [int(x) for x in w[i]] == orc.encode_kmer(s)
+    assert (pack_kmers(np.frombuffer(b"ACNGT", dtype=np.uint8).reshape(1, 5), 5) == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_find_two_ranks(orc, tmp_path):
+    from tests import parity_cases as pc
+    rng = random.Random(11)
+    paths = [os.path.join(GOLDEN, "two_short_contigs.ctx")]
+    for k, ncol in ((21, 1), (47, 3)):
+        haps = [("s%d" % c, [pc.rand_seq(rng, 1500)]) for c in range(ncol)]
+        p = str(tmp_path / ("sh%d.ctx" % k))
+        orc.build_graph(p, haps, k)
+        paths.append(p)
+    tiny = str(tmp_path / "tiny.ctx")                 # 2 records: Q1 — nothing is ever found
+    orc.build_graph(tiny, [("a", ["ACGTA"])], 4)
+    paths.append(tiny)
+    _spawn(_sharded_worker, (paths,))
+
+
+@pytest.mark.timeout(300)
+def test_replicas_two_ranks(orc, tmp_path):
+    from tests import hostsim, parity_cases as pc
+    rng = random.Random(5)
+    lib = hostsim.load()
+    g1 = pc.genome_with_repeats(rng, 1200)
+    cs = pc.Case(orc, tmp_path, lib, [("a", [g1])], 21, link_samples=["a"], name="rep")
+    seeds = rng.sample(cs.all_kmers(), 41)
+    oe, e = cs.engines(trav=[0], links=["a"], max_len=300)
+    expected, _ = e.walk_batch(seeds)
+    km = np.frombuffer("".join(seeds).encode(), dtype=np.uint8).reshape(len(seeds), 21)
+    arena, offs, _ = oe.walk_batch(km)
+    assert expected == [arena.tobytes()[offs[i]:offs[i + 1]].decode() for i in range(len(seeds))]
+    _spawn(_replica_worker, (cs.path, str(tmp_path / "rep.a.ctp.gz"), seeds, expected))

@@ -1,6 +1,7 @@
 """THE parity gate: every case of tests/parity_cases.py through the HIP library (libldbg.so, gfx950)
 on a real MI355X, compared bit-exactly with the CPU oracle.  Run with `pytest -m gpu`."""
 import pytest
+import torch  # noqa: F401  (before libldbg: both bring a HIP runtime; torch's must be the one that initialises first)
 
 from tests import parity_cases as pc
 
@@ -55,3 +56,33 @@ def test_dfs_dense(orc, lib, tmp_path, seed): pc.case_dfs_dense(orc, lib, tmp_pa
 
 
 def test_ref_dfs_with_sinks(orc, lib, tmp_path): pc.test_ref_dfs_with_sinks(orc, lib, tmp_path)
+
+
+def test_sharded_find_one_rank_rccl(orc, lib, tmp_path):
+    """the exchange path of corticall_amd/distributed.py over RCCL with device buffers (one rank: this box has one GPU;
+    the two-rank case runs on gloo in tests/test_distributed.py)"""
+    import os
+    import random
+    import torch.distributed as dist
+    from corticall_amd.distributed import ShardedCortexGraph
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        rng = random.Random(2)
+        p = str(tmp_path / "sh.ctx")
+        orc.build_graph(p, [("a", [pc.rand_seq(rng, 3000)]), ("b", [pc.rand_seq(rng, 2000)])], 47)
+        og = orc.Graph(p, tuned=True)
+        sg = ShardedCortexGraph(p, lib=lib)
+        kmers = [og.record_string(i).split()[0] for i in rng.sample(range(og.N), 500)]
+        qs = [k if rng.random() < 0.5 else orc.revcomp(k) for k in kmers] + [pc.rand_seq(rng, 47) for _ in range(200)] + ["N" * 47]
+        found, cov, edges, owner, lidx = sg.find_batch(qs)
+        for i, q in enumerate(qs):
+            eidx, ecov, eedges = og.find(q)
+            assert bool(found[i]) == (eidx >= 0)
+            if eidx >= 0:
+                assert ecov == [int(c) for c in cov[i]] and eedges == [int(x) for x in edges[i]] and lidx[i] == eidx
+        assert len(sg.find_batch([])[0]) == 0
+        sg.close()
+    finally:
+        dist.destroy_process_group()
