@@ -62,6 +62,11 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
     VisitedTable vt;
     vt.tab = vtab; vt.mask = vcap - 1; vt.used = st.vt_used;
     if (vt.used * 2 > vcap) { st.status = ST_POOL_FULL; return; }   // more steps since seek() than the cursor's `seen` table holds
+    // the nodes were saved by an earlier launch: bring their cached table entries up to date
+    node_locate(vt, st.cur);
+    if (st.has_next) node_locate(vt, st.nxt);
+    if (st.has_prev) node_locate(vt, st.prv);
+    vt.used = st.vt_used;
     LinkStoreDev ls;
     ls.fast = nullptr; ls.fast_cap = 0; ls.fast_stride = 0;
     ls.el = els; ls.cap = ecap; ls.n = st.ls_n; ls.java_cap = st.ls_java_cap; ls.nkeys = st.ls_nkeys; ls.next_seq = st.ls_next_seq;

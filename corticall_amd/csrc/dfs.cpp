@@ -2,7 +2,7 @@
 // (J/utils/traversal/TraversalEngine.java:64-106) and its private recursive branch method (:356-482).
 //
 // Device side.  One strand = (seed, direction) per lane, exactly like the contig walks (walk.cpp), but a
-// branch that reaches a junction recurses into its children.  The recursion is an explicit stack of 64-byte
+// branch that reaches a junction recurses into its children.  The recursion is an explicit stack of 72-byte
 // frames in HBM, touched only at junctions; the lane advances by micro-steps (one loop iteration of :373-481,
 // one child launch, or one entry of a visited-set undo) so that the 64 lanes of a wavefront keep working on
 // their own strands in lock step.
@@ -42,9 +42,9 @@ struct DfsFrame {
     StopState ss;
     uint8_t child[4];                     // child bases in the reference's iteration order
     uint8_t nchild, next, any, adj;
-    uint32_t pad[2];
+    uint32_t pad;
 };
-static_assert(sizeof(DfsFrame) == 64, "frame is one cache line");
+static_assert(sizeof(DfsFrame) == 72, "frame layout");
 
 struct DfsArgs {
     WalkArgs w;
@@ -188,6 +188,9 @@ LDBG_DEV void open_branch(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, con
         if (++st.cu.epoch > LDBG_VT_EPOCH_MAX) {         // epoch numbers used up: forget every `seen` mark
             for (uint32_t i = 0; i <= st.vt.mask; i++) st.vt.tab[i] = vt_with_seen(st.vt.tab[i], 0);
             st.cu.epoch = 1;
+            const uint32_t used = st.vt.used;
+            node_locate(st.vt, st.cv);                   // its cached entry carries an old mark
+            st.vt.used = used;
         }
         cursor_seek(e, st.cu, ls, st.vt, st.cv, st.fwd);
     }
@@ -227,8 +230,8 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
             L.undo_left--;
             const int64_t idx = path_idx(en);
             if (idx >= 0) {
-                const uint32_t h = vt_locate(st.vt, idx, path_flip(en));
-                const uint64_t ev = st.vt.tab[h];
+                uint64_t ev;
+                const uint32_t h = vt_locate(st.vt, idx, path_flip(en), &ev);
                 st.vt.tab[h] = vt_with_count(ev, vt_count_e(ev) - 1);
             }
             return false;
@@ -282,7 +285,8 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
     if (e.cursor_on && st.cu.has) {                     // :379-407
         av = cursor_step<W>(e, st.cu, ls, st.vt, fwd);
         if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
-        const int cnt = node_count(st.vt, av);          // first copyIndex not in visited
+        if (st.cu.has) { node_sync(cv, st.cu.nxt); node_sync(av, st.cu.nxt); }   // the `seen` mark may sit in a slot they hold
+        const int cnt = node_count(av);                 // first copyIndex not in visited
         av.copy = fwd ? cnt : -cnt;
         adj = 1;
     } else {
@@ -290,18 +294,20 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
             if (!((m >> b) & 1u)) continue;
             Node x;
             node_child_located(e, st.vt, cv, fwd, b, x);
-            if (node_count(st.vt, x) > 0) continue;     // avs.removeAll(visited) :416-422
+            if (node_count(x) > 0) continue;            // avs.removeAll(visited) :416-422
             adj++;
             av = x;
             avs_mask |= 1u << b;
         }
     }
     const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
-    const uint64_t ecv = cv.idx >= 0 ? st.vt.tab[cv.vslot] : 0ull;
+    const uint64_t ecv = cv.idx >= 0 ? cv.vent : 0ull;
     const bool previously = acopy < vt_count_e(ecv);    // :424
     if (!previously && cv.idx >= 0) {
         if (acopy + 1 > 32767) { st.status = ST_COPY_OVERFLOW; return true; }
-        st.vt.tab[cv.vslot] = vt_with_count(ecv, acopy + 1);   // visited.add(cv) :425
+        node_store(st.vt, cv, vt_with_count(ecv, acopy + 1));   // visited.add(cv) :425
+        node_sync(av, cv);
+        if (e.cursor_on) { node_sync(st.cu.cur, cv); if (st.cu.has) node_sync(st.cu.nxt, cv); }
     }
     L.last_prev = previously;
     bool succ = false, keep = false;

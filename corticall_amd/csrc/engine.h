@@ -66,6 +66,8 @@ struct Node {
     int32_t idx;         // record index, -1 = null CortexRecord
     int32_t copy;        // CortexVertex.copyIndex
     uint32_t vslot;      // slot of this vertex in the walk's visited table (valid once located; idx >= 0)
+    uint64_t vent;       // the table entry at vslot, kept in step with every write (node_sync): the hot loop never
+                         // reads an entry back that it already holds
     uint8_t flip;        // vertex k-mer != canonical orientation (by comparison): part of the vertex identity
     uint8_t fj;          // CanonicalKmer.isFlipped() — by Arrays.hashCode inequality (quirk Q6)
     uint8_t npe;         // record missing while recruitment colours are set (Q14)
@@ -118,7 +120,7 @@ LDBG_HOSTDEV void node_child(const EngineView& e, const Node& p, bool fwd, unsig
     const unsigned j = fwd ? (!fj ? base : 4u + (3u - base)) : (!fj ? 4u + base : (3u - base));
     const uint32_t ent = graph_nbr(g, p.idx, (int)j);
     n.idx = (int32_t)(ent & 0x7FFFFFFFu) - 1;
-    n.copy = 0; n.vslot = 0; n.base = (uint8_t)base;
+    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base;
     bool flip = (((ent >> 31) & 1u) != 0) != fj;
     if (n.idx >= 0 && (graph_row(g, n.idx)[g.flags_off] & LDBG_ROW_PALINDROME)) flip = false;   // rc(x) == x
     n.flip = flip ? 1 : 0;      // (for a vertex without a record the flag is not part of any comparison)
@@ -147,14 +149,14 @@ LDBG_HOSTDEV void node_find(const EngineView& e, const Kmer<W>& sk, Node& n) {
     bool fc;
     Kmer<W> c = kmer_canonical<W>(sk, e.g.k, &fc);
     n.idx = (int32_t)graph_find_canonical<W>(e.g, c);
-    n.copy = 0; n.vslot = 0; n.base = 0;
+    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = 0;
     n.flip = fc ? 1 : 0;
     node_fill(e, n);
     if (n.idx < 0 && e.strict_flip && fc)   // no record to carry the collision bit: hash the strings (rare path)
         n.fj = kmer_java_hash<W>(c, e.g.k) != kmer_java_hash<W>(sk, e.g.k) ? 1 : 0;
 }
 LDBG_HOSTDEV void node_null(const EngineView& e, Node& n) {   // not a k-mer (non-ACGT): findRecord misses (Q4)
-    n.idx = -1; n.copy = 0; n.vslot = 0; n.flip = 0; n.fj = 0; n.lflags = 0; n.base = 0;
+    n.idx = -1; n.copy = 0; n.vslot = 0; n.vent = 0; n.flip = 0; n.fj = 0; n.lflags = 0; n.base = 0;
     n.next_mask = n.prev_mask = 0;
     n.npe = e.recruit_mask != 0 ? 1 : 0;
 }
@@ -183,34 +185,55 @@ LDBG_HOSTDEV uint64_t vt_key(int64_t idx, bool flip) { return ((uint64_t)(idx + 
 struct LsDebug { uint64_t adds = 0, newkeys = 0, choices = 0, scan = 0, maxn = 0, steps = 0, sum_n = 0; };
 inline LsDebug& ls_debug() { static LsDebug d; return d; }
 #endif
-LDBG_HOSTDEV uint32_t vt_locate(VisitedTable& t, int64_t idx, bool flip) {
-    const uint64_t key = vt_key(idx, flip);
-    uint32_t h = vt_hash(key) & t.mask;
+// probe from slot h, whose entry e has already been read; returns the slot and its entry
+LDBG_HOSTDEV uint32_t vt_probe_from(VisitedTable& t, uint64_t key, uint32_t h, uint64_t e, uint64_t* ent) {
     while (true) {
 #ifdef LDBG_HOSTSIM
         ls_debug().scan++;
 #endif
-        const uint64_t e = t.tab[h];
-        if (e == 0) { t.tab[h] = key; t.used++; return h; }
-        if ((e & LDBG_VT_KEY_MASK) == key) return h;
+        if (e == 0) { t.tab[h] = key; t.used++; *ent = key; return h; }
+        if ((e & LDBG_VT_KEY_MASK) == key) { *ent = e; return h; }
         h = (h + 1) & t.mask;
+        e = t.tab[h];
     }
+}
+LDBG_HOSTDEV uint32_t vt_locate(VisitedTable& t, int64_t idx, bool flip, uint64_t* ent) {
+    const uint64_t key = vt_key(idx, flip);
+    const uint32_t h = vt_hash(key) & t.mask;
+    return vt_probe_from(t, key, h, t.tab[h], ent);
 }
 LDBG_HOSTDEV int vt_count_e(uint64_t e) { return (int)((e >> 48) & 0x7FFFull); }
 #define LDBG_VT_EPOCH_MAX 0x3FFFu
 LDBG_HOSTDEV bool vt_seen_e(uint64_t e, uint32_t epoch) { return (uint32_t)((e >> 34) & LDBG_VT_EPOCH_MAX) == epoch; }
 LDBG_HOSTDEV uint64_t vt_with_seen(uint64_t e, uint32_t epoch) { return (e & ~((uint64_t)LDBG_VT_EPOCH_MAX << 34)) | ((uint64_t)epoch << 34); }
 LDBG_HOSTDEV uint64_t vt_with_count(uint64_t e, int c) { return (e & ~(0x7FFFull << 48)) | ((uint64_t)(c & 0x7FFF) << 48); }
-LDBG_HOSTDEV void node_locate(VisitedTable& t, Node& n) { if (n.idx >= 0) n.vslot = vt_locate(t, n.idx, n.flip != 0); }
-// timing experiment (EngineView.dbg & 16): a 64-entry direct-mapped pseudo table, collisions ignored — wrong results
-LDBG_HOSTDEV void node_locate_dbg(const uint32_t dbg, VisitedTable& t, Node& n) {
-    if (dbg & 16u) { if (n.idx >= 0) n.vslot = vt_hash(vt_key(n.idx, n.flip != 0)) & 63u; }
-    else node_locate(t, n);
-}
-LDBG_HOSTDEV int node_count(const VisitedTable& t, const Node& n) { return n.idx >= 0 ? vt_count_e(t.tab[n.vslot]) : 0; }
+LDBG_HOSTDEV void node_locate(VisitedTable& t, Node& n) { if (n.idx >= 0) n.vslot = vt_locate(t, n.idx, n.flip != 0, &n.vent); }
+LDBG_HOSTDEV int node_count(const Node& n) { return n.idx >= 0 ? vt_count_e(n.vent) : 0; }
+// a write to the table: through the node that holds the slot ...
+LDBG_HOSTDEV void node_store(VisitedTable& t, Node& n, uint64_t val) { t.tab[n.vslot] = val; n.vent = val; }
+// ... and into every other live node that refers to the same vertex (a walk can stand on a k-mer and look at it)
+LDBG_HOSTDEV void node_sync(Node& n, const Node& written) { if (n.idx >= 0 && written.idx >= 0 && n.vslot == written.vslot) n.vent = written.vent; }
+// neighbour `base` of p, with its table slot.  The first probe of the table is issued before the neighbour's row is
+// read (for odd k the orientation, hence the key, is known from p's neighbour index alone), so the two accesses overlap.
 LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const Node& p, bool fwd, unsigned base, Node& n) {
-    node_child(e, p, fwd, base, n);
-    node_locate_dbg(e.dbg, t, n);
+    const GraphView& g = e.g;
+    const bool fj = p.fj != 0;
+    const unsigned j = fwd ? (!fj ? base : 4u + (3u - base)) : (!fj ? 4u + base : (3u - base));
+    const uint32_t ent = graph_nbr(g, p.idx, (int)j);
+    n.idx = (int32_t)(ent & 0x7FFFFFFFu) - 1;
+    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base;
+    bool flip = (((ent >> 31) & 1u) != 0) != fj;
+    const bool early = n.idx >= 0 && (g.k & 1);          // odd k: no palindromes
+    uint64_t key = 0, e0 = 0;
+    uint32_t h = 0;
+    if (early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = t.tab[h]; }
+    if (n.idx >= 0 && !(g.k & 1) && (graph_row(g, n.idx)[g.flags_off] & LDBG_ROW_PALINDROME)) flip = false;   // rc(x) == x
+    n.flip = flip ? 1 : 0;
+    node_fill(e, n);
+    if (n.idx >= 0) {
+        if (!early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = t.tab[h]; }
+        n.vslot = vt_probe_from(t, key, h, e0, &n.vent);
+    }
 }
 
 // ---- per-walk LinkStore (J/utils/traversal/LinkStore.java), elements kept in insertion order.
@@ -384,7 +407,7 @@ struct Cursor {
 // initializeLinkStore / updateLinkStore (:548-597): links of vertex v, if its record carries any
 template <int W>
 LDBG_HOSTDEV void cursor_add_links(const EngineView& e, LinkStoreDev& s, const Node& v, bool fwd) {
-    if (!(v.lflags & e.link_flag_mask) || (e.dbg & 4u)) return;
+    if (!(v.lflags & e.link_flag_mask)) return;
     Kmer<W> c = graph_key<W>(e.g, v.idx);
     int64_t m = links_find<W>(e.links, e.g.k, c);
     if (m >= 0) ls_add(e.links, s, m, v.flip != 0, fwd);
@@ -429,12 +452,15 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
     if (pc == 1) {
         Node x;
         node_child_located(e, vt, t, fwd, lowbit4(m), x);
-        const uint64_t ex = x.idx >= 0 ? vt.tab[x.vslot] : 0ull;
+        const uint64_t ex = x.idx >= 0 ? x.vent : 0ull;
         if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_child += p1 - p0; p0 = p1; }
         if (!vt_seen_e(ex, cu.epoch) || s.n > 0) {      // :262
+            if (x.idx >= 0 && !vt_seen_e(ex, cu.epoch)) {                // seen.add(nextKmer)
+                node_store(vt, x, vt_with_seen(ex, cu.epoch));
+                node_sync(cu.cur, x);
+            }
             cu.nxt = x;
             has = true;
-            if (x.idx >= 0 && !(e.dbg & 2u)) vt.tab[x.vslot] = vt_with_seen(ex, cu.epoch);   // seen.add(nextKmer)
         }
     } else if (pc > 1) {
         unsigned ch;

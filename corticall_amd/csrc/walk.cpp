@@ -24,7 +24,8 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) 
     if (e.cursor_on && st.cu.has) {                     // :379-407
         av = cursor_step<W>(e, st.cu, ls, st.vt, fwd);
         if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
-        const int cnt = node_count(st.vt, av);          // first unused copyIndex
+        if (st.cu.has) { node_sync(cv, st.cu.nxt); node_sync(av, st.cu.nxt); }   // the `seen` mark may sit in a slot they hold
+        const int cnt = node_count(av);                 // first unused copyIndex
         av.copy = fwd ? cnt : -cnt;
         adj = 1;
     } else {
@@ -32,17 +33,19 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) 
             if (!((m >> b) & 1u)) continue;
             Node x;
             node_child_located(e, st.vt, cv, fwd, b, x);
-            if (node_count(st.vt, x) > 0) continue;                 // avs.removeAll(seen) :416-422
+            if (node_count(x) > 0) continue;                        // avs.removeAll(seen) :416-422
             adj++;
             av = x;
         }
     }
     const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
-    const uint64_t ecv = cv.idx >= 0 ? st.vt.tab[cv.vslot] : 0ull;
+    const uint64_t ecv = cv.idx >= 0 ? cv.vent : 0ull;
     const bool previously = acopy < vt_count_e(ecv);                    // :424
     if (!previously && cv.idx >= 0) {
         if (acopy + 1 > 32767) { st.status = ST_COPY_OVERFLOW; return true; }
-        if (!(e.dbg & 8u)) st.vt.tab[cv.vslot] = vt_with_count(ecv, acopy + 1);            // visited.add(cv) :425
+        node_store(st.vt, cv, vt_with_count(ecv, acopy + 1));           // visited.add(cv) :425
+        node_sync(av, cv);
+        if (e.cursor_on) { node_sync(st.cu.cur, cv); if (st.cu.has) node_sync(st.cu.nxt, cv); }
     }
     const bool reached = st.gV > (uint32_t)e.max_len;                   // :428
     if (previously) { st.branch_null = true; return true; }             // :470-478, traversalSucceeded() still false
