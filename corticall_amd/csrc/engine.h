@@ -248,8 +248,10 @@ struct LsElem {
     uint32_t key_seq;  // insertion sequence number of this element's key in the Java HashMap
     uint16_t len;
     uint16_t pos;
-    uint16_t comp;     // junction string is used complemented (LinkStore.java:25)
-    uint16_t pad;
+    uint8_t comp;      // junction string is used complemented (LinkStore.java:25)
+    uint8_t nxn;       // junction bases cached in nx (> 0 whenever pos < len)
+    uint16_t nx;       // the next nxn <= 8 junction bases from `pos` on (2 bits each, complemented already): the
+                       // junction logic reads the pool of junction strings once per 8 positions
 };
 struct LinkStoreDev {
     LsElem* fast;       // the first `fast_cap` elements live here (LDS in the walk kernel), element i at fast[i * fast_stride]
@@ -270,6 +272,22 @@ LDBG_HOSTDEV void ls_clear(LinkStoreDev& s) { s.n = 0; s.java_cap = 0; s.nkeys =
 LDBG_HOSTDEV unsigned ls_char(const LinksView& L, const LsElem& x, uint32_t i) {
     unsigned b = L.bases[x.str_off + i];
     return x.comp ? 3u - b : b;
+}
+// refill the cache of upcoming bases from position x.pos
+LDBG_HOSTDEV void ls_fill_nx(const LinksView& L, LsElem& x) {
+    uint32_t nx = 0, cnt = 0;
+    for (uint32_t i = 0; i < 8; i++) {
+        if ((uint32_t)x.pos + i >= x.len) break;
+        nx |= (uint32_t)ls_char(L, x, (uint32_t)x.pos + i) << (2 * i);
+        cnt++;
+    }
+    x.nx = (uint16_t)nx; x.nxn = (uint8_t)cnt;
+}
+LDBG_HOSTDEV unsigned ls_cur(const LsElem& x) { return x.nx & 3u; }          // junctions.charAt(pos)
+LDBG_HOSTDEV void ls_advance(const LinksView& L, LsElem& x) {               // pos++ (pos + 1 < len holds)
+    x.pos++;
+    x.nx >>= 2; x.nxn--;
+    if (x.nxn == 0) ls_fill_nx(L, x);
 }
 LDBG_HOSTDEV bool ls_same_string(const LinksView& L, const LsElem& a, const LsElem& b) {
     if (a.str_off == b.str_off && a.comp == b.comp) return true;
@@ -292,8 +310,9 @@ LDBG_HOSTDEV void ls_add(const LinksView& L, LinkStoreDev& s, int64_t m, bool qu
         bool lgf = (jr.is_fw != 0) != query_flipped;    // recordOrientationMatchesKmer == cjr.isForward() :24
         if (lgf != fwd) continue;
         LsElem x;
-        x.str_off = jr.str_off; x.birth = s.age; x.hash = lgf ? jr.hash_asis : jr.hash_comp; x.pad = 0;
+        x.str_off = jr.str_off; x.birth = s.age; x.hash = lgf ? jr.hash_asis : jr.hash_comp;
         x.len = (uint16_t)jr.len; x.pos = 0; x.comp = lgf ? 0 : 1; x.key_seq = 0;
+        ls_fill_nx(L, x);
         // an element with the same junction string?  newest first: a walk circling a repeat re-adds the links it
         // added one revolution ago, so the match sits near the end of the (insertion-ordered) array
         bool have = false;
@@ -330,7 +349,7 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
     for (uint32_t i = 0; i < s.n; i++) {
         const LsElem x = ls_get(s, i);
         if (x.birth != minbirth) break;
-        unsigned c = ls_char(L, x, x.pos);
+        unsigned c = ls_cur(x);
         uint32_t h = (uint32_t)x.hash;
         uint32_t b = (h ^ (h >> 16)) & (s.java_cap - 1);
         if (i == 0) { ch0 = c; best_b = b; best_seq = x.key_seq; }
@@ -342,7 +361,7 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
     if (!agree) return false;
     unsigned ch = ch0;
     for (uint32_t i = s.n; i-- > 0;)     // last element of that key's list wins (:129-133)
-        { const LsElem y = ls_get(s, i); if (y.key_seq == best_seq) { ch = ls_char(L, y, y.pos); break; } }
+        { const LsElem y = ls_get(s, i); if (y.key_seq == best_seq) { ch = ls_cur(y); break; } }
     // incrementPositionsAndExpire(choice): four elements at a time so that their loads overlap
     uint32_t w = 0, n_new = 0;
     uint32_t dead[8];
@@ -353,14 +372,14 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
         unsigned c[4];
         const uint32_t cnt = s.n - i0 < 4 ? s.n - i0 : 4;
         for (uint32_t q = 0; q < 4; q++) if (q < cnt) x[q] = ls_get(s, i0 + q);
-        for (uint32_t q = 0; q < 4; q++) if (q < cnt) c[q] = ls_char(L, x[q], x[q].pos);
+        for (uint32_t q = 0; q < 4; q++) if (q < cnt) c[q] = ls_cur(x[q]);
         for (uint32_t q = 0; q < 4; q++) {
             if (q >= cnt) break;
             if ((uint32_t)x[q].pos + 1 >= x[q].len || c[q] != ch) {
                 if (n_dead < 8) dead[n_dead++] = x[q].key_seq; else many_dead = true;
                 continue;
             }
-            x[q].pos++;
+            ls_advance(L, x[q]);
             n_new += x[q].birth == s.age;
             ls_set(s, w++, x[q]);
         }
@@ -433,15 +452,23 @@ LDBG_HOSTDEV int cursor_choice_base(const EngineView& e, const Node& t, uint32_t
         if (((m >> b) & 1u) && kmer_eq<W>(child_kmer<W>(e, t, fwd, b), cand)) return (int)b;
     return -1;
 }
+// what the walk kernel's wave-cooperative phases (lscoop.h) have already done for this step
+struct StepPre {
+    bool links_done;     // initializeLinkStore / updateLinkStore
+    bool choice_done;    // getNextJunctionChoice, with its result
+    bool choice_ok;
+    unsigned ch;
+};
 // next()/previous() (TraversalEngine.java:241-319); requires cu.has.  Returns the vertex stepped onto.
 template <int W>
-LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd) {
+LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd, const StepPre* pre = nullptr) {
     unsigned long long p0 = cu.prof ? LDBG_NOW() : 0ull;
+    const bool links_done = pre && pre->links_done;
     if (cu.first) {
         cu.first = false;                              // seek(cur) recomputes the same state; then
-        cursor_add_links<W>(e, s, cu.cur, fwd);        // initializeLinkStore :548-568
+        if (!links_done) cursor_add_links<W>(e, s, cu.cur, fwd);        // initializeLinkStore :548-568
     }
-    cursor_add_links<W>(e, s, cu.nxt, fwd);            // updateLinkStore :570-597
+    if (!links_done) cursor_add_links<W>(e, s, cu.nxt, fwd);            // updateLinkStore :570-597
     if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_links += p1 - p0; cu.prof->n_links += (cu.nxt.lflags & e.link_flag_mask) ? 1 : 0; p0 = p1; }
     Node t = cu.nxt;
     cu.cur = t;
@@ -463,8 +490,8 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
             has = true;
         }
     } else if (pc > 1) {
-        unsigned ch;
-        if (ls_next_choice(e.links, s, &ch)) {
+        unsigned ch = pre && pre->choice_done ? pre->ch : 0u;
+        if (pre && pre->choice_done ? pre->choice_ok : ls_next_choice(e.links, s, &ch)) {
             const int mb = cursor_choice_base<W>(e, t, m, fwd, ch);
             if (mb >= 0) { node_child_located(e, vt, t, fwd, (unsigned)mb, cu.nxt); has = true; }
         }

@@ -1,0 +1,171 @@
+// Wave-cooperative LinkStore operations for the walk kernel.
+//
+// A lane that adds links or takes a junction choice scans its whole link store (LinkStore.java:17-35, 92-144).  Done by
+// the lane alone, that scan is a chain of dependent loads while the other 63 lanes of the wavefront wait for it — and
+// with 64 strands per wavefront some lane is at a junction in most iterations.  Here the WHOLE wavefront carries out one
+// lane's (the owner's) operation: lane h handles elements h, h+64, ...; agreement, minimum and "last of the key" are
+// ballots and butterfly reductions; expiry is a ballot-prefix compaction.  The semantics are those of the one-lane
+// versions in engine.h (ls_add / ls_next_choice), which the cursor and dfs kernels keep using; both are held to the
+// oracle by the same parity cases.
+#pragma once
+#include "engine.h"
+
+namespace ldbg {
+
+// where the link stores of this wavefront's lanes live
+struct LsWave {
+    LsElem* fast;          // element i of lane L at fast[i * stride + L]   (LDS)
+    uint32_t stride;       // lanes per wavefront
+    uint32_t fast_cap;
+    LsElem* el;            // element i >= fast_cap of lane L at el[L * ecap + (i - fast_cap)]   (HBM)
+    uint32_t ecap;
+};
+LDBG_DEV LsElem lsw_get(const LsWave& v, int L, uint32_t i) {
+    return i < v.fast_cap ? v.fast[i * v.stride + (uint32_t)L] : v.el[(size_t)L * v.ecap + (i - v.fast_cap)];
+}
+LDBG_DEV void lsw_set(const LsWave& v, int L, uint32_t i, const LsElem& x) {
+    if (i < v.fast_cap) v.fast[i * v.stride + (uint32_t)L] = x; else v.el[(size_t)L * v.ecap + (i - v.fast_cap)] = x;
+}
+
+// the owner's store header, identical on every lane while the wavefront works on it
+struct LsHdr { uint32_t n, java_cap, nkeys, next_seq, age, n_new, cap; bool overflow; };
+LDBG_DEV LsHdr lsw_header(const LinkStoreDev& s, int L) {
+    LsHdr h;
+    h.n = wave_bcast_u32(s.n, L); h.java_cap = wave_bcast_u32(s.java_cap, L); h.nkeys = wave_bcast_u32(s.nkeys, L);
+    h.next_seq = wave_bcast_u32(s.next_seq, L); h.age = wave_bcast_u32(s.age, L); h.n_new = wave_bcast_u32(s.n_new, L);
+    h.cap = wave_bcast_u32(s.cap, L); h.overflow = wave_bcast_u32(s.overflow ? 1u : 0u, L) != 0;
+    return h;
+}
+LDBG_DEV void lsw_store_header(LinkStoreDev& s, const LsHdr& h) {
+    s.n = h.n; s.java_cap = h.java_cap; s.nkeys = h.nkeys; s.next_seq = h.next_seq; s.age = h.age; s.n_new = h.n_new; s.overflow = h.overflow;
+}
+
+// LinkStore.add (:17-35) of merged link record m into the owner's store
+LDBG_DEV void coop_add(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, int64_t m, bool query_flipped, bool fwd) {
+    const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
+    for (uint32_t j = Lk.off[m]; j < Lk.off[m + 1]; j++) {
+        const JuncRec jr = Lk.junc[j];
+        const bool lgf = (jr.is_fw != 0) != query_flipped;     // recordOrientationMatchesKmer == cjr.isForward() :24
+        if (lgf != fwd) continue;
+        LsElem x;
+        x.str_off = jr.str_off; x.birth = h.age; x.hash = lgf ? jr.hash_asis : jr.hash_comp;
+        x.len = (uint16_t)jr.len; x.pos = 0; x.comp = lgf ? 0 : 1; x.key_seq = 0;
+        ls_fill_nx(Lk, x);
+        // the newest element filed under the same junction string, if any
+        uint64_t found = 0;
+        for (uint32_t base = 0; base < h.n; base += WS) {
+            const uint32_t i = base + lane;
+            uint64_t cand = 0;
+            if (i < h.n) {
+                const LsElem y = lsw_get(v, L, i);
+                if (ls_same_string(Lk, y, x)) cand = ((uint64_t)(i + 1) << 32) | y.key_seq;
+            }
+            const uint64_t r = wave_max_u64(cand);
+            found = r > found ? r : found;
+        }
+        if (found) x.key_seq = (uint32_t)found;
+        else {
+            x.key_seq = h.next_seq++;
+            h.nkeys++;
+            if (h.java_cap == 0) h.java_cap = 16;
+            if (h.nkeys > h.java_cap * 3 / 4) h.java_cap *= 2;
+        }
+        if (h.n >= h.cap || jr.len >= 65535u || h.n >= 0x7FFFu) { h.overflow = true; return; }
+        if (lane == 0) lsw_set(v, L, h.n, x);
+        wave_fence();
+        h.n++;
+        h.n_new++;
+    }
+}
+
+LDBG_DEV bool lsw_keeps(const LsElem& x, unsigned ch) { return !((uint32_t)x.pos + 1 >= x.len || ls_cur(x) != ch); }
+
+// LinkStore.getNextJunctionChoice (:122-144) with getOldestLink (:92-119) and incrementPositionsAndExpire (:58-90)
+LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, unsigned* choice) {
+    if (h.n == 0) return false;
+    const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
+    const LsElem first = lsw_get(v, L, 0);
+    const uint32_t minbirth = first.birth;          // oldest = largest age = smallest birth; births never decrease along the array
+    const unsigned ch0 = ls_cur(first);
+    // the oldest links must agree on their next junction; the first of them in java.util.HashMap iteration order
+    // (bucket, key insertion order) names the key whose last element supplies the choice
+    bool disagree = false;
+    uint64_t best = ~0ull;
+    for (uint32_t base = 0; base < h.n; base += WS) {
+        const uint32_t i = base + lane;
+        bool old = false, differs = false;
+        uint64_t cand = ~0ull;
+        if (i < h.n) {
+            const LsElem x = lsw_get(v, L, i);
+            old = x.birth == minbirth;
+            differs = old && ls_cur(x) != ch0;
+            const uint32_t hh = (uint32_t)x.hash;
+            if (old) cand = ((uint64_t)((hh ^ (hh >> 16)) & (h.java_cap - 1)) << 32) | x.key_seq;
+        }
+        if (wave_ballot(differs) != 0ull) disagree = true;
+        const uint64_t r = wave_min_u64(cand);
+        best = r < best ? r : best;
+        if (wave_ballot(i < h.n && !old) != 0ull) break;       // past the prefix of oldest links
+    }
+    if (disagree) return false;
+    const uint32_t best_seq = (uint32_t)best;
+    uint64_t last = 0;
+    for (uint32_t base = 0; base < h.n; base += WS) {           // last element of that key's list wins (:129-133)
+        const uint32_t i = base + lane;
+        uint64_t cand = 0;
+        if (i < h.n) {
+            const LsElem x = lsw_get(v, L, i);
+            if (x.key_seq == best_seq) cand = ((uint64_t)(i + 1) << 2) | ls_cur(x);
+        }
+        const uint64_t r = wave_max_u64(cand);
+        last = r > last ? r : last;
+    }
+    const unsigned ch = (unsigned)(last & 3ull);
+    // keys whose last element expires leave the HashMap (:84-88): a dead element takes its key along unless a surviving
+    // element, or an earlier dead one (already counted), shares it
+    for (uint32_t base = 0; base < h.n; base += WS) {
+        const uint32_t i = base + lane;
+        LsElem x;
+        x.key_seq = 0;
+        bool dead = false;
+        if (i < h.n) { x = lsw_get(v, L, i); dead = !lsw_keeps(x, ch); }
+        unsigned long long db = wave_ballot(dead);
+        while (db) {
+            const int dl = __builtin_ctzll(db);
+            db &= db - 1;
+            const uint32_t ks = wave_bcast_u32(x.key_seq, dl);
+            const uint32_t di = base + (uint32_t)dl;
+            bool held = false;
+            for (uint32_t b2 = 0; b2 < h.n && !held; b2 += WS) {
+                const uint32_t j = b2 + lane;
+                bool hit = false;
+                if (j < h.n) {
+                    const LsElem y = lsw_get(v, L, j);
+                    hit = y.key_seq == ks && (j < di || lsw_keeps(y, ch)) && j != di;
+                }
+                held = wave_ballot(hit) != 0ull;
+            }
+            if (!held) h.nkeys--;
+        }
+    }
+    // incrementPositionsAndExpire(choice): survivors advance and close ranks
+    uint32_t w = 0, n_new = 0;
+    for (uint32_t base = 0; base < h.n; base += WS) {
+        const uint32_t i = base + lane;
+        LsElem x;
+        bool keep = false;
+        if (i < h.n) { x = lsw_get(v, L, i); keep = lsw_keeps(x, ch); }
+        if (keep) ls_advance(Lk, x);
+        const unsigned long long kb = wave_ballot(keep);
+        if (keep) lsw_set(v, L, w + (uint32_t)wave_count_below(kb), x);
+        n_new += (uint32_t)__builtin_popcountll(wave_ballot(keep && x.birth == h.age));
+        w += (uint32_t)__builtin_popcountll(kb);
+        wave_fence();
+    }
+    h.n = w;
+    h.n_new = n_new;
+    *choice = ch;
+    return true;
+}
+
+}  // namespace ldbg

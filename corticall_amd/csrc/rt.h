@@ -93,6 +93,14 @@ LDBG_DEV uint64_t wave_bcast_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 LDBG_DEV void wave_fence() { __threadfence_block(); }
+LDBG_DEV uint64_t wave_shfl_xor_u64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+// butterfly reductions: every lane receives the result
+LDBG_DEV uint64_t wave_min_u64(uint64_t v) { for (int m = 32; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o < v ? o : v; } return v; }
+LDBG_DEV uint64_t wave_max_u64(uint64_t v) { for (int m = 32; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o > v ? o : v; } return v; }
+LDBG_DEV int wave_count_below(unsigned long long ballot) { return __builtin_popcountll(ballot & ((1ull << wave_lane()) - 1ull)); }
 }  // namespace ldbg
 
 #else  // ------------------------------------------------------------------ LDBG_HOSTSIM (tests only)
@@ -142,6 +150,9 @@ inline unsigned long long wave_ballot(bool p) { return p ? 1ull : 0ull; }
 inline uint32_t wave_bcast_u32(uint32_t v, int) { return v; }
 inline uint64_t wave_bcast_u64(uint64_t v, int) { return v; }
 inline void wave_fence() {}
+inline uint64_t wave_min_u64(uint64_t v) { return v; }
+inline uint64_t wave_max_u64(uint64_t v) { return v; }
+inline int wave_count_below(unsigned long long) { return 0; }
 }  // namespace ldbg
 
 // sequential "launch": every simulated thread runs to completion in turn.  Kernels must therefore

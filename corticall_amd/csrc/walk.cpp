@@ -5,13 +5,14 @@
 #include <algorithm>
 #include <numeric>
 
+#include "lscoop.h"
 #include "strand.h"
 
 namespace ldbg {
 
 // one iteration of the do-loop at TraversalEngine.java:373-481; returns true when the branch has ended
 template <int W>
-LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) {
+LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, const StepPre& pre) {
     const EngineView& e = a.e;
     const int k = e.g.k;
     const bool fwd = st.fwd;
@@ -22,7 +23,7 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) 
     int adj = 0;
     Node av = cv;
     if (e.cursor_on && st.cu.has) {                     // :379-407
-        av = cursor_step<W>(e, st.cu, ls, st.vt, fwd);
+        av = cursor_step<W>(e, st.cu, ls, st.vt, fwd, &pre);
         if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
         if (st.cu.has) { node_sync(cv, st.cu.nxt); node_sync(av, st.cu.nxt); }   // the `seen` mark may sit in a slot they hold
         const int cnt = node_count(av);                 // first unused copyIndex
@@ -90,6 +91,9 @@ LDBG_KERNEL void k_walk(WalkArgs a) {
     ls.el = a.ls + (size_t)slot * a.ecap;
     ls.cap = a.ecap + LDBG_LS_FAST;
     ls_clear(ls);
+    LsWave lw;                                            // the link stores of this wavefront's lanes
+    lw.fast = fast - wave_lane(); lw.stride = fast_stride; lw.fast_cap = LDBG_LS_FAST;
+    lw.el = a.ls + (size_t)(slot - wave_lane()) * a.ecap; lw.ecap = a.ecap;
     StrandState st;
     st.vt.tab = nullptr; st.vt.mask = 0; st.vt.used = 0; st.status = ST_OK;
     bool active = false, exhausted = false;
@@ -111,7 +115,39 @@ LDBG_KERNEL void k_walk(WalkArgs a) {
             }
         }
         wave_grow_tables(a, st, active);
-        if (active && strand_step<W>(a, st, ls)) { strand_finish(a, st); active = false; }
+        // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
+        const bool cur_mode = active && st.status == ST_OK && a.e.cursor_on && st.cu.has;
+        int64_t m_cur = -1, m_nxt = -1;
+        if (cur_mode) {                                   // which merged link records this step adds (:548-597)
+            if (st.cu.first && (st.cu.cur.lflags & a.e.link_flag_mask))
+                m_cur = links_find<W>(a.e.links, a.e.g.k, graph_key<W>(a.e.g, st.cu.cur.idx));
+            if (st.cu.nxt.lflags & a.e.link_flag_mask)
+                m_nxt = links_find<W>(a.e.links, a.e.g.k, graph_key<W>(a.e.g, st.cu.nxt.idx));
+        }
+        StepPre pre;
+        pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0;
+        unsigned long long need = wave_ballot(m_cur >= 0 || m_nxt >= 0);
+        while (need) {
+            const int L = __builtin_ctzll(need);
+            need &= need - 1;
+            LsHdr h = lsw_header(ls, L);
+            const int64_t mc = (int64_t)wave_bcast_u64((uint64_t)m_cur, L), mn = (int64_t)wave_bcast_u64((uint64_t)m_nxt, L);
+            const uint32_t flags = wave_bcast_u32((st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u), L);
+            if (mc >= 0) coop_add(a.e.links, lw, L, h, mc, (flags & 1u) != 0, (flags & 4u) != 0);
+            if (mn >= 0 && !h.overflow) coop_add(a.e.links, lw, L, h, mn, (flags & 2u) != 0, (flags & 4u) != 0);
+            if (wave_lane() == L) lsw_store_header(ls, h);
+        }
+        const uint32_t nmask = cur_mode ? (st.fwd ? st.cu.nxt.next_mask : st.cu.nxt.prev_mask) : 0u;
+        need = wave_ballot(cur_mode && popc4(nmask) > 1);
+        while (need) {                                    // junction choices (:266-272)
+            const int L = __builtin_ctzll(need);
+            need &= need - 1;
+            LsHdr h = lsw_header(ls, L);
+            unsigned ch = 0;
+            const bool ok = coop_next_choice(a.e.links, lw, L, h, &ch);
+            if (wave_lane() == L) { lsw_store_header(ls, h); pre.choice_done = true; pre.choice_ok = ok; pre.ch = ch; }
+        }
+        if (active && strand_step<W>(a, st, ls, pre)) { strand_finish(a, st); active = false; }
     }
 #ifndef LDBG_HOSTSIM
     if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
