@@ -371,7 +371,7 @@ LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64
 }
 
 template <int W>
-LDBG_KERNEL void k_dfs(DfsArgs a) {
+LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
     const int64_t slot = global_tid();
     if (slot >= a.w.n_slots) return;
 #ifndef LDBG_HOSTSIM

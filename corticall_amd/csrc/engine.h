@@ -215,11 +215,14 @@ LDBG_HOSTDEV void node_store(VisitedTable& t, Node& n, uint64_t val) { t.tab[n.v
 LDBG_HOSTDEV void node_sync(Node& n, const Node& written) { if (n.idx >= 0 && written.idx >= 0 && n.vslot == written.vslot) n.vent = written.vent; }
 // neighbour `base` of p, with its table slot.  The first probe of the table is issued before the neighbour's row is
 // read (for odd k the orientation, hence the key, is known from p's neighbour index alone), so the two accesses overlap.
-LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const Node& p, bool fwd, unsigned base, Node& n) {
-    const GraphView& g = e.g;
+LDBG_HOSTDEV uint32_t node_child_entry(const EngineView& e, const Node& p, bool fwd, unsigned base) {
     const bool fj = p.fj != 0;
     const unsigned j = fwd ? (!fj ? base : 4u + (3u - base)) : (!fj ? 4u + base : (3u - base));
-    const uint32_t ent = graph_nbr(g, p.idx, (int)j);
+    return graph_nbr(e.g, p.idx, (int)j);
+}
+LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const Node& p, uint32_t ent, unsigned base, Node& n) {
+    const GraphView& g = e.g;
+    const bool fj = p.fj != 0;
     n.idx = (int32_t)(ent & 0x7FFFFFFFu) - 1;
     n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base;
     bool flip = (((ent >> 31) & 1u) != 0) != fj;
@@ -234,6 +237,9 @@ LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const
         if (!early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = t.tab[h]; }
         n.vslot = vt_probe_from(t, key, h, e0, &n.vent);
     }
+}
+LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const Node& p, bool fwd, unsigned base, Node& n) {
+    node_from_entry(e, t, p, node_child_entry(e, p, fwd, base), base, n);
 }
 
 // ---- per-walk LinkStore (J/utils/traversal/LinkStore.java), elements kept in insertion order.
@@ -283,6 +289,14 @@ LDBG_HOSTDEV void ls_fill_nx(const LinksView& L, LsElem& x) {
     }
     x.nx = (uint16_t)nx; x.nxn = (uint8_t)cnt;
 }
+// the cache of a new element (pos 0) comes with the junction record
+LDBG_HOSTDEV void ls_first_nx(const JuncRec& jr, LsElem& x) {
+    const uint32_t cnt = jr.len < 8u ? jr.len : 8u;
+    const uint32_t mask = (1u << (2 * cnt)) - 1u;
+    const uint32_t nx = jr.is_fw >> 16;
+    x.nx = (uint16_t)((x.comp ? ~nx : nx) & mask);      // complement of base b is 3 - b
+    x.nxn = (uint8_t)cnt;
+}
 LDBG_HOSTDEV unsigned ls_cur(const LsElem& x) { return x.nx & 3u; }          // junctions.charAt(pos)
 LDBG_HOSTDEV void ls_advance(const LinksView& L, LsElem& x) {               // pos++ (pos + 1 < len holds)
     x.pos++;
@@ -307,12 +321,12 @@ LDBG_HOSTDEV bool ls_key_alive(const LinkStoreDev& s, uint32_t key_seq, uint32_t
 LDBG_HOSTDEV void ls_add(const LinksView& L, LinkStoreDev& s, int64_t m, bool query_flipped, bool fwd) {
     for (uint32_t j = L.off[m]; j < L.off[m + 1]; j++) {
         const JuncRec jr = L.junc[j];
-        bool lgf = (jr.is_fw != 0) != query_flipped;    // recordOrientationMatchesKmer == cjr.isForward() :24
+        bool lgf = ((jr.is_fw & 1u) != 0) != query_flipped;    // recordOrientationMatchesKmer == cjr.isForward() :24
         if (lgf != fwd) continue;
         LsElem x;
         x.str_off = jr.str_off; x.birth = s.age; x.hash = lgf ? jr.hash_asis : jr.hash_comp;
         x.len = (uint16_t)jr.len; x.pos = 0; x.comp = lgf ? 0 : 1; x.key_seq = 0;
-        ls_fill_nx(L, x);
+        ls_first_nx(jr, x);
         // an element with the same junction string?  newest first: a walk circling a repeat re-adds the links it
         // added one revolution ago, so the match sits near the end of the (insertion-ordered) array
         bool have = false;
@@ -427,9 +441,8 @@ struct Cursor {
 template <int W>
 LDBG_HOSTDEV void cursor_add_links(const EngineView& e, LinkStoreDev& s, const Node& v, bool fwd) {
     if (!(v.lflags & e.link_flag_mask)) return;
-    Kmer<W> c = graph_key<W>(e.g, v.idx);
-    int64_t m = links_find<W>(e.links, e.g.k, c);
-    if (m >= 0) ls_add(e.links, s, m, v.flip != 0, fwd);
+    const uint32_t m = e.links.rec_of[v.idx];
+    if (m != 0xFFFFFFFFu) ls_add(e.links, s, (int64_t)m, v.flip != 0, fwd);
 }
 // seek(sk): cursor on v, unique neighbour in direction `fwd` looked up (TraversalEngine.java:321-335)
 LDBG_HOSTDEV void cursor_seek(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, const Node& v, bool fwd) {
@@ -458,17 +471,22 @@ struct StepPre {
     bool choice_done;    // getNextJunctionChoice, with its result
     bool choice_ok;
     unsigned ch;
+    bool has_child;
+    Node child;          // the single successor of the vertex stepped onto, located ahead of the link-store phases
 };
 // next()/previous() (TraversalEngine.java:241-319); requires cu.has.  Returns the vertex stepped onto.
-template <int W>
+// PRE: the link-store work of the step was done ahead by the caller (walk kernel) and arrives in *pre; the one-lane
+// LinkStore code is then not even compiled into the kernel.
+template <int W, bool PRE = false>
 LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd, const StepPre* pre = nullptr) {
     unsigned long long p0 = cu.prof ? LDBG_NOW() : 0ull;
-    const bool links_done = pre && pre->links_done;
+    const bool links_done = PRE;
     if (cu.first) {
         cu.first = false;                              // seek(cur) recomputes the same state; then
-        if (!links_done) cursor_add_links<W>(e, s, cu.cur, fwd);        // initializeLinkStore :548-568
+        if constexpr (!PRE) cursor_add_links<W>(e, s, cu.cur, fwd);     // initializeLinkStore :548-568
     }
-    if (!links_done) cursor_add_links<W>(e, s, cu.nxt, fwd);            // updateLinkStore :570-597
+    if constexpr (!PRE) cursor_add_links<W>(e, s, cu.nxt, fwd);         // updateLinkStore :570-597
+    (void)links_done;
     if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_links += p1 - p0; cu.prof->n_links += (cu.nxt.lflags & e.link_flag_mask) ? 1 : 0; p0 = p1; }
     Node t = cu.nxt;
     cu.cur = t;
@@ -478,7 +496,8 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
     const int pc = popc4(m);
     if (pc == 1) {
         Node x;
-        node_child_located(e, vt, t, fwd, lowbit4(m), x);
+        if (PRE && pre->has_child) x = pre->child;
+        else node_child_located(e, vt, t, fwd, lowbit4(m), x);
         const uint64_t ex = x.idx >= 0 ? x.vent : 0ull;
         if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_child += p1 - p0; p0 = p1; }
         if (!vt_seen_e(ex, cu.epoch) || s.n > 0) {      // :262
@@ -490,8 +509,11 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
             has = true;
         }
     } else if (pc > 1) {
-        unsigned ch = pre && pre->choice_done ? pre->ch : 0u;
-        if (pre && pre->choice_done ? pre->choice_ok : ls_next_choice(e.links, s, &ch)) {
+        unsigned ch = 0;
+        bool ok;
+        if constexpr (PRE) { ok = pre->choice_ok; ch = pre->ch; }
+        else ok = ls_next_choice(e.links, s, &ch);
+        if (ok) {
             const int mb = cursor_choice_base<W>(e, t, m, fwd, ch);
             if (mb >= 0) { node_child_located(e, vt, t, fwd, (unsigned)mb, cu.nxt); has = true; }
         }

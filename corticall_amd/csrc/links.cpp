@@ -153,6 +153,21 @@ LDBG_KERNEL void k_set_link_flags(GraphView g, uint8_t* probe, const uint64_t* k
     }
 }
 
+// rec_of[record] = merged link record of that graph record (0xFFFFFFFF: none): a walk standing on a record finds its links
+// with one load instead of a search of the link table
+template <int W>
+LDBG_KERNEL void k_link_rec_of(GraphView g, const uint64_t* keys, int64_t M, uint32_t* rec_of) {
+    for (int64_t i = global_tid(); i < M; i += global_nthreads()) {
+        Kmer<W> q;
+#pragma unroll
+        for (int w = 0; w < W; w++) q.w[w] = keys[i * W + w];
+        GraphView exact = g;
+        exact.java_tiny = 0;
+        int64_t idx = graph_find_canonical<W>(exact, q);
+        if (idx >= 0) rec_of[idx] = (uint32_t)i;
+    }
+}
+
 Links::Links(const std::string& path, const Graph& g) : device(g.device) {
     std::string text = gunzip_file(path);
     // header = lines from "{" to "}" (CortexLinksIterable.java:58-67)
@@ -299,6 +314,7 @@ MergedLinks::MergedLinks(const std::vector<const Links*>& sets, const Graph& g) 
                 jr.hash_asis = jstring_hash(j.junctions);
                 jr.hash_comp = jstring_hash(complement_ascii(j.junctions));
                 jr.is_fw = (rec_canon == j.is_fw) ? 1u : 0u;
+                uint32_t n_packed = 0;
                 for (char ch : j.junctions) {
                     uint8_t code;
                     switch (ch) {
@@ -306,6 +322,7 @@ MergedLinks::MergedLinks(const std::vector<const Links*>& sets, const Graph& g) 
                         default: throw StatusError(LDBG_ERR_UNSUPPORTED, std::string("junction string with a non-ACGT character '") + ch + "'");
                     }
                     bases.push_back(code);
+                    if (n_packed < 8) { jr.is_fw |= (uint32_t)code << (16 + 2 * n_packed); n_packed++; }
                 }
                 junc.push_back(jr);
             }
@@ -337,7 +354,20 @@ MergedLinks::MergedLinks(const std::vector<const Links*>& sets, const Graph& g) 
     d_off_ = up(off.data(), off.size() * 4);
     d_junc_ = up(junc.data(), junc.size() * sizeof(JuncRec));
     d_bases_ = up(bases.data(), bases.size());
+    const int64_t N = g.view.N;
+    d_rec_of_ = rt::dmalloc((size_t)std::max<int64_t>(1, N) * 4);
+    rt::dmemset(d_rec_of_, 0xFF, (size_t)std::max<int64_t>(1, N) * 4, s);
+    if (M > 0) {
+        const int grid = (int)std::min<int64_t>((M + 255) / 256, 2048);
+        switch (W) {
+            case 1: LDBG_LAUNCH(k_link_rec_of<1>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (uint32_t*)d_rec_of_); break;
+            case 2: LDBG_LAUNCH(k_link_rec_of<2>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (uint32_t*)d_rec_of_); break;
+            case 3: LDBG_LAUNCH(k_link_rec_of<3>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (uint32_t*)d_rec_of_); break;
+            default: LDBG_LAUNCH(k_link_rec_of<4>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (uint32_t*)d_rec_of_); break;
+        }
+    }
     rt::stream_sync(s);
+    view.rec_of = (const uint32_t*)d_rec_of_;
     view.M = M;
     view.keys = (const uint8_t*)d_keys_;
     view.pstart = (const uint32_t*)d_pstart_;
@@ -348,7 +378,7 @@ MergedLinks::MergedLinks(const std::vector<const Links*>& sets, const Graph& g) 
 }
 
 MergedLinks::~MergedLinks() {
-    rt::dfree(d_keys_); rt::dfree(d_pstart_); rt::dfree(d_off_); rt::dfree(d_junc_); rt::dfree(d_bases_);
+    rt::dfree(d_keys_); rt::dfree(d_pstart_); rt::dfree(d_off_); rt::dfree(d_junc_); rt::dfree(d_bases_); rt::dfree(d_rec_of_);
 }
 
 const HostLinksRecord* Links::get(const std::string& kmer_ascii) const {

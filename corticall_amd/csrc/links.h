@@ -18,8 +18,9 @@ struct JuncRec {
     uint32_t len;
     int32_t hash_asis;   // java.lang.String.hashCode of the junction string
     int32_t hash_comp;   // ... of its complement (LinkStore.add, LinkStore.java:25)
-    uint32_t is_fw;      // "the link goes forward when the querying k-mer is the canonical orientation":
-                         // (record k-mer string is canonical) == CortexJunctionsRecord.isForward()
+    uint32_t is_fw;      // bit 0: "the link goes forward when the querying k-mer is the canonical orientation":
+                         // (record k-mer string is canonical) == CortexJunctionsRecord.isForward();
+                         // bits 16..31: the first 8 junction bases (2 bits each), so that adding a link reads no bases
 };
 
 // one searchable link table on the device (the link sets of a traversal, merged by canonical k-mer)
@@ -31,6 +32,7 @@ struct LinksView {
     const uint32_t* off;      // [M+1]
     const JuncRec* junc;      // per key: set after set (order of addition), each in HashSet iteration order
     const uint8_t* bases;
+    const uint32_t* rec_of;   // [graph records] merged link record of a graph record, 0xFFFFFFFF = none
 };
 
 struct HostJunction {
@@ -65,6 +67,7 @@ public:
     uint32_t flag_mask = 0;
 private:
     void* d_keys_ = nullptr; void* d_pstart_ = nullptr; void* d_off_ = nullptr; void* d_junc_ = nullptr; void* d_bases_ = nullptr;
+    void* d_rec_of_ = nullptr;
 };
 
 // radix-indexed search over sorted key rows (shared by graph and links)

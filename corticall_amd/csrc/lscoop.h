@@ -40,17 +40,40 @@ LDBG_DEV void lsw_store_header(LinkStoreDev& s, const LsHdr& h) {
     s.n = h.n; s.java_cap = h.java_cap; s.nkeys = h.nkeys; s.next_seq = h.next_seq; s.age = h.age; s.n_new = h.n_new; s.overflow = h.overflow;
 }
 
-// LinkStore.add (:17-35) of merged link record m into the owner's store
-LDBG_DEV void coop_add(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, int64_t m, bool query_flipped, bool fwd) {
+// what an owner lane fetched for its add before the wavefront turns to it (all owners fetch at once)
+struct AddPre { uint32_t jlo, jhi; JuncRec r0, r1; };
+LDBG_DEV AddPre add_prefetch(const LinksView& Lk, int64_t m) {
+    AddPre p;
+    p.jlo = Lk.off[m]; p.jhi = Lk.off[m + 1];
+    p.r0 = Lk.junc[p.jlo];
+    p.r1 = Lk.junc[p.jlo + 1 < p.jhi ? p.jlo + 1 : p.jlo];
+    return p;
+}
+LDBG_DEV JuncRec bcast_junc(const JuncRec& r, int L) {
+    JuncRec o;
+    o.str_off = wave_bcast_u32(r.str_off, L); o.len = wave_bcast_u32(r.len, L);
+    o.hash_asis = (int32_t)wave_bcast_u32((uint32_t)r.hash_asis, L); o.hash_comp = (int32_t)wave_bcast_u32((uint32_t)r.hash_comp, L);
+    o.is_fw = wave_bcast_u32(r.is_fw, L);
+    return o;
+}
+LDBG_DEV AddPre bcast_addpre(const AddPre& p, int L) {
+    AddPre o;
+    o.jlo = wave_bcast_u32(p.jlo, L); o.jhi = wave_bcast_u32(p.jhi, L);
+    o.r0 = bcast_junc(p.r0, L); o.r1 = bcast_junc(p.r1, L);
+    return o;
+}
+
+// LinkStore.add (:17-35) of a merged link record (junction records [pre.jlo, pre.jhi)) into the owner's store
+LDBG_DEV void coop_add(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, const AddPre& pre, bool query_flipped, bool fwd) {
     const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
-    for (uint32_t j = Lk.off[m]; j < Lk.off[m + 1]; j++) {
-        const JuncRec jr = Lk.junc[j];
-        const bool lgf = (jr.is_fw != 0) != query_flipped;     // recordOrientationMatchesKmer == cjr.isForward() :24
+    for (uint32_t j = pre.jlo; j < pre.jhi; j++) {
+        const JuncRec jr = j == pre.jlo ? pre.r0 : (j == pre.jlo + 1 ? pre.r1 : Lk.junc[j]);
+        const bool lgf = ((jr.is_fw & 1u) != 0) != query_flipped;     // recordOrientationMatchesKmer == cjr.isForward() :24
         if (lgf != fwd) continue;
         LsElem x;
         x.str_off = jr.str_off; x.birth = h.age; x.hash = lgf ? jr.hash_asis : jr.hash_comp;
         x.len = (uint16_t)jr.len; x.pos = 0; x.comp = lgf ? 0 : 1; x.key_seq = 0;
-        ls_fill_nx(Lk, x);
+        ls_first_nx(jr, x);
         // the newest element filed under the same junction string, if any
         uint64_t found = 0;
         for (uint32_t base = 0; base < h.n; base += WS) {

@@ -21,6 +21,7 @@
 #ifndef LDBG_HOSTSIM
 #include <hip/hip_runtime.h>
 #define LDBG_KERNEL __global__
+#define LDBG_WAVE_KERNEL __global__ __launch_bounds__(64)   // launched one wavefront per workgroup: no register cap
 #define LDBG_DEV __device__ __forceinline__
 #define LDBG_HOSTDEV __host__ __device__ __forceinline__
 
@@ -105,6 +106,7 @@ LDBG_DEV int wave_count_below(unsigned long long ballot) { return __builtin_popc
 
 #else  // ------------------------------------------------------------------ LDBG_HOSTSIM (tests only)
 #define LDBG_KERNEL static
+#define LDBG_WAVE_KERNEL static
 #define LDBG_DEV inline
 #define LDBG_HOSTDEV inline
 #ifndef __forceinline__

@@ -23,7 +23,7 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, 
     int adj = 0;
     Node av = cv;
     if (e.cursor_on && st.cu.has) {                     // :379-407
-        av = cursor_step<W>(e, st.cu, ls, st.vt, fwd, &pre);
+        av = cursor_step<W, true>(e, st.cu, ls, st.vt, fwd, &pre);
         if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
         if (st.cu.has) { node_sync(cv, st.cu.nxt); node_sync(av, st.cu.nxt); }   // the `seen` mark may sit in a slot they hold
         const int cnt = node_count(av);                 // first unused copyIndex
@@ -70,7 +70,7 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, 
 }
 
 template <int W>
-LDBG_KERNEL void k_walk(WalkArgs a) {
+LDBG_WAVE_KERNEL void k_walk(WalkArgs a) {
     const int64_t slot = global_tid();
     if (slot >= a.n_slots) return;
 #ifndef LDBG_HOSTSIM
@@ -117,27 +117,39 @@ LDBG_KERNEL void k_walk(WalkArgs a) {
         wave_grow_tables(a, st, active);
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
         const bool cur_mode = active && st.status == ST_OK && a.e.cursor_on && st.cu.has;
-        int64_t m_cur = -1, m_nxt = -1;
-        if (cur_mode) {                                   // which merged link records this step adds (:548-597)
-            if (st.cu.first && (st.cu.cur.lflags & a.e.link_flag_mask))
-                m_cur = links_find<W>(a.e.links, a.e.g.k, graph_key<W>(a.e.g, st.cu.cur.idx));
-            if (st.cu.nxt.lflags & a.e.link_flag_mask)
-                m_nxt = links_find<W>(a.e.links, a.e.g.k, graph_key<W>(a.e.g, st.cu.nxt.idx));
-        }
+        // Two independent chains of dependent loads start here: (links) rec_of -> offsets -> junction records of the
+        // vertex about to be stepped onto, and (graph) its neighbour pointer -> the next row + its table slot.  They are
+        // issued stage by stage so that they overlap.
+        const uint32_t nmask = cur_mode ? (st.fwd ? st.cu.nxt.next_mask : st.cu.nxt.prev_mask) : 0u;
+        const bool one_child = cur_mode && popc4(nmask) == 1;
+        const bool flagged = cur_mode && (st.cu.nxt.lflags & a.e.link_flag_mask);
+        uint32_t m_cur = 0xFFFFFFFFu, m_nxt = 0xFFFFFFFFu, child_ent = 0;
+        if (flagged) m_nxt = a.e.links.rec_of[st.cu.nxt.idx];
+        if (one_child) child_ent = node_child_entry(a.e, st.cu.nxt, st.fwd, lowbit4(nmask));
+        if (cur_mode && st.cu.first && (st.cu.cur.lflags & a.e.link_flag_mask)) m_cur = a.e.links.rec_of[st.cu.cur.idx];
+        AddPre ap_cur, ap_nxt;
+        ap_cur.jlo = ap_cur.jhi = ap_nxt.jlo = ap_nxt.jhi = 0;
+        if (m_nxt != 0xFFFFFFFFu) { ap_nxt.jlo = a.e.links.off[m_nxt]; ap_nxt.jhi = a.e.links.off[m_nxt + 1]; }
         StepPre pre;
+        pre.has_child = one_child;
+        if (one_child) node_from_entry(a.e, st.vt, st.cu.nxt, child_ent, lowbit4(nmask), pre.child);
+        if (m_nxt != 0xFFFFFFFFu) {
+            ap_nxt.r0 = a.e.links.junc[ap_nxt.jlo];
+            ap_nxt.r1 = a.e.links.junc[ap_nxt.jlo + 1 < ap_nxt.jhi ? ap_nxt.jlo + 1 : ap_nxt.jlo];
+        }
+        if (m_cur != 0xFFFFFFFFu) ap_cur = add_prefetch(a.e.links, (int64_t)m_cur);
         pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0;
-        unsigned long long need = wave_ballot(m_cur >= 0 || m_nxt >= 0);
+        unsigned long long need = wave_ballot(m_cur != 0xFFFFFFFFu || m_nxt != 0xFFFFFFFFu);
         while (need) {
             const int L = __builtin_ctzll(need);
             need &= need - 1;
             LsHdr h = lsw_header(ls, L);
-            const int64_t mc = (int64_t)wave_bcast_u64((uint64_t)m_cur, L), mn = (int64_t)wave_bcast_u64((uint64_t)m_nxt, L);
-            const uint32_t flags = wave_bcast_u32((st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u), L);
-            if (mc >= 0) coop_add(a.e.links, lw, L, h, mc, (flags & 1u) != 0, (flags & 4u) != 0);
-            if (mn >= 0 && !h.overflow) coop_add(a.e.links, lw, L, h, mn, (flags & 2u) != 0, (flags & 4u) != 0);
+            const uint32_t flags = wave_bcast_u32((st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u) |
+                                                  (m_cur != 0xFFFFFFFFu ? 8u : 0u) | (m_nxt != 0xFFFFFFFFu ? 16u : 0u), L);
+            if (flags & 8u) coop_add(a.e.links, lw, L, h, bcast_addpre(ap_cur, L), (flags & 1u) != 0, (flags & 4u) != 0);
+            if ((flags & 16u) && !h.overflow) coop_add(a.e.links, lw, L, h, bcast_addpre(ap_nxt, L), (flags & 2u) != 0, (flags & 4u) != 0);
             if (wave_lane() == L) lsw_store_header(ls, h);
         }
-        const uint32_t nmask = cur_mode ? (st.fwd ? st.cu.nxt.next_mask : st.cu.nxt.prev_mask) : 0u;
         need = wave_ballot(cur_mode && popc4(nmask) > 1);
         while (need) {                                    // junction choices (:266-272)
             const int L = __builtin_ctzll(need);
