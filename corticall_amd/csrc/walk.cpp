@@ -125,14 +125,14 @@ LDBG_WAVE_KERNEL void k_walk(WalkArgs a) {
         const bool flagged = cur_mode && (st.cu.nxt.lflags & a.e.link_flag_mask);
         uint32_t m_cur = 0xFFFFFFFFu, m_nxt = 0xFFFFFFFFu, child_ent = 0;
         if (flagged) m_nxt = a.e.links.rec_of[st.cu.nxt.idx];
-        if (one_child) child_ent = node_child_entry(a.e, st.cu.nxt, st.fwd, lowbit4(nmask));
+        if (one_child) child_ent = st.cu.nxt.e1 ? st.cu.nxt.ent1 : node_child_entry(a.e, st.cu.nxt, st.fwd, lowbit4(nmask));
         if (cur_mode && st.cu.first && (st.cu.cur.lflags & a.e.link_flag_mask)) m_cur = a.e.links.rec_of[st.cu.cur.idx];
         AddPre ap_cur, ap_nxt;
         ap_cur.jlo = ap_cur.jhi = ap_nxt.jlo = ap_nxt.jhi = 0;
         if (m_nxt != 0xFFFFFFFFu) { ap_nxt.jlo = a.e.links.off[m_nxt]; ap_nxt.jhi = a.e.links.off[m_nxt + 1]; }
         StepPre pre;
         pre.has_child = one_child;
-        if (one_child) node_from_entry(a.e, st.vt, st.cu.nxt, child_ent, lowbit4(nmask), pre.child);
+        if (one_child) node_from_entry(a.e, st.vt, st.cu.nxt, child_ent, lowbit4(nmask), st.fwd, pre.child);
         if (m_nxt != 0xFFFFFFFFu) {
             ap_nxt.r0 = a.e.links.junc[ap_nxt.jlo];
             ap_nxt.r1 = a.e.links.junc[ap_nxt.jlo + 1 < ap_nxt.jhi ? ap_nxt.jlo + 1 : ap_nxt.jlo];
