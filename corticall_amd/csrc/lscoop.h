@@ -107,6 +107,40 @@ LDBG_DEV bool lsw_keeps(const LsElem& x, unsigned ch) { return !((uint32_t)x.pos
 LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, unsigned* choice) {
     if (h.n == 0) return false;
     const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
+    if (h.n <= WS && WS > 1) {
+        // the usual case — one element per lane: the element is read once and everything below happens in registers
+        const bool valid = lane < h.n;
+        LsElem x;
+        x.birth = 0; x.key_seq = 0; x.hash = 0; x.nx = 0; x.pos = 0; x.len = 0;
+        if (valid) x = lsw_get(v, L, lane);
+        const uint32_t minbirth0 = wave_bcast_u32(x.birth, 0);
+        const unsigned c = ls_cur(x);
+        const unsigned c0 = wave_bcast_u32(c, 0);
+        const bool old = valid && x.birth == minbirth0;
+        if (wave_ballot(old && c != c0) != 0ull) return false;
+        const uint32_t hh = (uint32_t)x.hash;
+        const uint64_t best1 = wave_min_u64(old ? (((uint64_t)((hh ^ (hh >> 16)) & (h.java_cap - 1)) << 32) | x.key_seq) : ~0ull);
+        const uint32_t seq1 = (uint32_t)best1;
+        const uint64_t last1 = wave_max_u64(valid && x.key_seq == seq1 ? (((uint64_t)(lane + 1) << 2) | c) : 0ull);
+        const unsigned ch1 = (unsigned)(last1 & 3ull);
+        const bool keep = valid && lsw_keeps(x, ch1);
+        unsigned long long db = wave_ballot(valid && !keep);
+        while (db) {
+            const int dl = __builtin_ctzll(db);
+            db &= db - 1;
+            const uint32_t ks = wave_bcast_u32(x.key_seq, dl);
+            const bool hit = valid && x.key_seq == ks && (int)lane != dl && ((int)lane < dl || keep);
+            if (wave_ballot(hit) == 0ull) h.nkeys--;
+        }
+        if (keep) ls_advance(Lk, x);
+        const unsigned long long kb = wave_ballot(keep);
+        if (keep) lsw_set(v, L, (uint32_t)wave_count_below(kb), x);
+        h.n_new = (uint32_t)__builtin_popcountll(wave_ballot(keep && x.birth == h.age));
+        h.n = (uint32_t)__builtin_popcountll(kb);
+        wave_fence();
+        *choice = ch1;
+        return true;
+    }
     const LsElem first = lsw_get(v, L, 0);
     const uint32_t minbirth = first.birth;          // oldest = largest age = smallest birth; births never decrease along the array
     const unsigned ch0 = ls_cur(first);
