@@ -76,6 +76,13 @@ LDBG_DEV void coop_add(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, co
         ls_first_nx(jr, x);
         // the newest element filed under the same junction string, if any
         uint64_t found = 0;
+        if (h.n <= WS && WS > 1) {                        // one element per lane: the highest matching lane
+            bool match = false;
+            uint32_t ks = 0;
+            if (lane < h.n) { const LsElem y = lsw_get(v, L, lane); match = ls_same_string(Lk, y, x); ks = y.key_seq; }
+            const unsigned long long mb = wave_ballot(match);
+            if (mb) found = (1ull << 32) | wave_bcast_u32(ks, 63 - __builtin_clzll(mb));
+        } else
         for (uint32_t base = 0; base < h.n; base += WS) {
             const uint32_t i = base + lane;
             uint64_t cand = 0;
@@ -118,11 +125,18 @@ LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHd
         const unsigned c0 = wave_bcast_u32(c, 0);
         const bool old = valid && x.birth == minbirth0;
         if (wave_ballot(old && c != c0) != 0ull) return false;
+        // first of the oldest links in HashMap iteration order: the oldest are few, walk their lanes
         const uint32_t hh = (uint32_t)x.hash;
-        const uint64_t best1 = wave_min_u64(old ? (((uint64_t)((hh ^ (hh >> 16)) & (h.java_cap - 1)) << 32) | x.key_seq) : ~0ull);
+        const uint64_t mine = ((uint64_t)((hh ^ (hh >> 16)) & (h.java_cap - 1)) << 32) | x.key_seq;
+        uint64_t best1 = ~0ull;
+        for (unsigned long long ob = wave_ballot(old); ob; ob &= ob - 1) {
+            const uint64_t o = wave_bcast_u64(mine, __builtin_ctzll(ob));
+            best1 = o < best1 ? o : best1;
+        }
         const uint32_t seq1 = (uint32_t)best1;
-        const uint64_t last1 = wave_max_u64(valid && x.key_seq == seq1 ? (((uint64_t)(lane + 1) << 2) | c) : 0ull);
-        const unsigned ch1 = (unsigned)(last1 & 3ull);
+        // the last element filed under that key = the highest lane holding it
+        const unsigned long long kbm = wave_ballot(valid && x.key_seq == seq1);
+        const unsigned ch1 = wave_bcast_u32(c, 63 - __builtin_clzll(kbm));
         const bool keep = valid && lsw_keeps(x, ch1);
         unsigned long long db = wave_ballot(valid && !keep);
         while (db) {
