@@ -105,6 +105,9 @@ LDBG_DEV void coop_add(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, co
         wave_fence();
         h.n++;
         h.n_new++;
+#ifdef LDBG_HOSTSIM
+        ls_debug().adds++; if (h.n > ls_debug().maxn) ls_debug().maxn = h.n;
+#endif
     }
 }
 

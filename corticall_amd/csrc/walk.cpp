@@ -14,7 +14,6 @@ namespace ldbg {
 template <int W>
 LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, const StepPre& pre) {
     const EngineView& e = a.e;
-    const int k = e.g.k;
     const bool fwd = st.fwd;
     if (st.status != ST_OK) return true;     // pool exhausted while regrowing the table
     st.iters++;
@@ -127,8 +126,7 @@ LDBG_WAVE_KERNEL void k_walk(WalkArgs a) {
         if (flagged) m_nxt = a.e.links.rec_of[st.cu.nxt.idx];
         if (one_child) child_ent = st.cu.nxt.e1 ? st.cu.nxt.ent1 : node_child_entry(a.e, st.cu.nxt, st.fwd, lowbit4(nmask));
         if (cur_mode && st.cu.first && (st.cu.cur.lflags & a.e.link_flag_mask)) m_cur = a.e.links.rec_of[st.cu.cur.idx];
-        AddPre ap_cur, ap_nxt;
-        ap_cur.jlo = ap_cur.jhi = ap_nxt.jlo = ap_nxt.jhi = 0;
+        AddPre ap_cur = AddPre(), ap_nxt = AddPre();
         if (m_nxt != 0xFFFFFFFFu) { ap_nxt.jlo = a.e.links.off[m_nxt]; ap_nxt.jhi = a.e.links.off[m_nxt + 1]; }
         StepPre pre;
         pre.has_child = one_child;

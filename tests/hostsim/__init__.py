@@ -14,7 +14,7 @@ SO = os.path.join(ROOT, "tests", "hostsim", "_build", "libldbg_hostsim.so")
 
 def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "corticall_amd", "csrc"), "hostsim", "-j8"],
-                          stdout=subprocess.DEVNULL)
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def load():

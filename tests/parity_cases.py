@@ -567,3 +567,18 @@ def test_ref_dfs_with_sinks(orc, lib, tmp):                       # TraversalEng
          .graph(cs.g).links(cs.links["test"]).make())
     g = e.dfs(hap[:5], hap[-5:])
     assert g.walk_contig(hap[:5], 0) == hap
+
+
+def case_big_link_stores(orc, lib, tmp):
+    """reads that thread a tandem repeat from every third position: hundreds of live links per walk — the link store
+    spills from LDS to HBM, overflows its first capacity (the host retries with a larger one) and the wave-cooperative
+    scans of the walk kernel run over several rounds"""
+    for seed in range(3):
+        rng = random.Random(50 + seed)
+        unit = rand_seq(rng, 9)
+        g1 = rand_seq(rng, 60) + unit * 6 + rand_seq(rng, 60) + unit * 3 + rand_seq(rng, 40)
+        reads = {"a": [g1[i:] for i in range(0, len(g1) - 30, 3)]}
+        cs = Case(orc, tmp, lib, [("a", [g1])], 5, link_samples=["a"], reads=reads, name="big%d" % seed)
+        seeds = cs.all_kmers()[:40]
+        compare_walks(cs, seeds, trav=[0], links=["a"], max_len=400)
+        compare_dfs(cs, seeds[:10], trav=[0], stopper="ExplorationStopper", links=["a"], max_len=200)
