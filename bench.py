@@ -88,9 +88,13 @@ def bench_c2(args, ca, rank, local_rank, world, dist):
     d = os.environ.get("LDBG_BENCH_DIR", "/tmp/ldbg_bench")
     os.makedirs(d, exist_ok=True)
     prefix = os.path.join(d, "c2_L%d_k%d" % (L, k))
+    if dist is not None and rank != 0:
+        dist.barrier()                  # rank 0 writes the files
     if not os.path.exists(prefix + ".ctx"):
         synth.generate(prefix, L, k, colours=1, with_links=False, seed=0xC0FFEE01, n_chrom=1, n_repeat_families=0, repeat_copies=0,
                        n_indels=0, n_dnm=0, n_tandem=0, n_seeds=100000, threads=min(16, os.cpu_count() or 1))
+    if dist is not None and rank == 0:
+        dist.barrier()
     present = np.fromfile(prefix + ".seeds", dtype=np.uint8).reshape(-1, k)
     rng = np.random.default_rng(0xC0FFEE02 + rank)
     n = args.lookups
@@ -279,7 +283,7 @@ def main():
     import numpy as np
     import torch
     dist = None
-    if world > 1 or args.sharded:
+    if world > 1 or args.sharded or os.environ.get("LDBG_FORCE_DIST"):      # LDBG_FORCE_DIST: rehearse the N > 1 code path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -294,7 +298,12 @@ def main():
     if args.workload == "c2":
         return bench_c2(args, ca, rank, local_rank, world, dist)
 
-    prefix, st = workload_files(args, 0)        # same graph on every rank
+    # same graph on every rank: rank 0 generates the files (once), the others wait for them
+    if dist is not None and rank != 0:
+        dist.barrier()
+    prefix, st = workload_files(args, 0)
+    if dist is not None and rank == 0:
+        dist.barrier()
     seeds = np.fromfile(prefix + ".seeds", dtype=np.uint8).reshape(-1, args.k)
     if args.use_seeds:
         seeds = seeds[np.random.default_rng(7).permutation(len(seeds))[:args.use_seeds]]

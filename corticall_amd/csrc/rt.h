@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #define LDBG_KERNEL __global__
 #define LDBG_WAVE_KERNEL __global__ __launch_bounds__(64)   // launched one wavefront per workgroup: no register cap
+#define LDBG_WAVE_KERNEL_N(n) __global__ __launch_bounds__(n)
 #define LDBG_DEV __device__ __forceinline__
 #define LDBG_HOSTDEV __host__ __device__ __forceinline__
 
@@ -85,7 +86,7 @@ LDBG_DEV unsigned atomic_or_u32(unsigned* p, unsigned v) { return atomicOr(p, v)
 LDBG_DEV unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
 LDBG_DEV unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { return atomicCAS(p, cmp, v); }
 // wavefront primitives (64 lanes on gfx950); kernels that use them are launched with 64-thread blocks
-LDBG_DEV int wave_size() { return 64; }
+LDBG_DEV int wave_size() { return (int)blockDim.x; }   // wave kernels run one (possibly partial) wavefront per workgroup
 LDBG_DEV int wave_lane() { return (int)(threadIdx.x & 63u); }
 LDBG_DEV unsigned long long wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
 LDBG_DEV uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
@@ -99,14 +100,15 @@ LDBG_DEV uint64_t wave_shfl_xor_u64(uint64_t v, int m) {
     return ((uint64_t)hi << 32) | lo;
 }
 // butterfly reductions: every lane receives the result
-LDBG_DEV uint64_t wave_min_u64(uint64_t v) { for (int m = 32; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o < v ? o : v; } return v; }
-LDBG_DEV uint64_t wave_max_u64(uint64_t v) { for (int m = 32; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o > v ? o : v; } return v; }
+LDBG_DEV uint64_t wave_min_u64(uint64_t v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o < v ? o : v; } return v; }
+LDBG_DEV uint64_t wave_max_u64(uint64_t v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o > v ? o : v; } return v; }
 LDBG_DEV int wave_count_below(unsigned long long ballot) { return __builtin_popcountll(ballot & ((1ull << wave_lane()) - 1ull)); }
 }  // namespace ldbg
 
 #else  // ------------------------------------------------------------------ LDBG_HOSTSIM (tests only)
 #define LDBG_KERNEL static
 #define LDBG_WAVE_KERNEL static
+#define LDBG_WAVE_KERNEL_N(n) static
 #define LDBG_DEV inline
 #define LDBG_HOSTDEV inline
 #ifndef __forceinline__

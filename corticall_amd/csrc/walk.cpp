@@ -68,8 +68,10 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, 
     return false;
 }
 
-template <int W>
-LDBG_WAVE_KERNEL void k_walk(WalkArgs a) {
+// BS = lanes per workgroup (a full or partial wavefront).  Fewer lanes per wavefront = fewer strands whose link-store
+// work the wavefront has to carry out one after the other, and more wavefronts per CU to hide each other's latency.
+template <int W, int BS>
+LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     const int64_t slot = global_tid();
     if (slot >= a.n_slots) return;
 #ifndef LDBG_HOSTSIM
@@ -77,9 +79,9 @@ LDBG_WAVE_KERNEL void k_walk(WalkArgs a) {
 #endif
     // link store: the first LDBG_LS_FAST elements of every lane live in LDS ([element][lane]), the rest in HBM
 #ifndef LDBG_HOSTSIM
-    __shared__ LsElem lds_store[LDBG_LS_FAST * 64];
-    LsElem* fast = lds_store + (threadIdx.x & 63u);
-    const uint32_t fast_stride = 64;
+    __shared__ LsElem lds_store[LDBG_LS_FAST * BS];
+    LsElem* fast = lds_store + threadIdx.x;
+    const uint32_t fast_stride = BS;
 #else
     static LsElem lds_store[LDBG_LS_FAST];
     LsElem* fast = lds_store;
@@ -481,9 +483,14 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     const bool want_times = getenv("LDBG_WG_TIMES") != nullptr;
     rt::Event e0, e1;
     e0.record(s);
-    const int block = 64;            // one wavefront per workgroup (the LDS link store is laid out [element][lane])
-    // every workgroup must be resident (lanes refill from the strand queue): 48 KB of LDS each -> 3 per CU
-    a.n_slots = std::min<int64_t>(a.n_slots, (int64_t)3 * 256 * 64);
+    // one (partial) wavefront per workgroup; every workgroup must be resident (lanes refill from the strand queue):
+    // LDBG_LS_FAST x block x 24 B of LDS each, at most 32 wavefronts per CU
+    // (measured at C3, profiles/r01_exp_block.log: 64 lanes 0.51 s, 32 lanes 0.60 s, 16 lanes 0.63 s per launch — smaller
+    // wavefronts finish the bulk sooner but the longest strands run slower with more wavefronts per CU)
+    int block = 64;
+    if (const char* ev = getenv("LDBG_WALK_BLOCK")) block = atoi(ev) == 16 ? 16 : (atoi(ev) == 32 ? 32 : 64);   // tuning knob
+    const int wg_per_cu = std::min<int>(32, (int)(160 * 1024 / (LDBG_LS_FAST * (size_t)block * sizeof(LsElem))));
+    a.n_slots = std::min<int64_t>(a.n_slots, (int64_t)wg_per_cu * 256 * block);
     a.n_slots = (a.n_slots / block) * block;
     if (a.n_slots < block) a.n_slots = block;
     const int grid = (int)((a.n_slots + block - 1) / block);
@@ -492,12 +499,17 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
         a.st_prof = (StepProf*)rt::dmalloc((size_t)ns * sizeof(StepProf)); rt::dmemset(a.st_prof, 0, (size_t)ns * sizeof(StepProf), s);
     }
+#define LDBG_WALK_CASE(WW) \
+    if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, a); \
+    else if (block == 64) LDBG_LAUNCH((k_walk<WW, 64>), grid, 64, s, a); \
+    else LDBG_LAUNCH((k_walk<WW, 32>), grid, 32, s, a)
     switch (W) {
-        case 1: LDBG_LAUNCH(k_walk<1>, grid, block, s, a); break;
-        case 2: LDBG_LAUNCH(k_walk<2>, grid, block, s, a); break;
-        case 3: LDBG_LAUNCH(k_walk<3>, grid, block, s, a); break;
-        default: LDBG_LAUNCH(k_walk<4>, grid, block, s, a); break;
+        case 1: LDBG_WALK_CASE(1); break;
+        case 2: LDBG_WALK_CASE(2); break;
+        case 3: LDBG_WALK_CASE(3); break;
+        default: LDBG_WALK_CASE(4); break;
     }
+#undef LDBG_WALK_CASE
     e1.record(s);
 
     // lengths + seed test
