@@ -6,6 +6,7 @@
 
 #include "cursor.h"
 #include "engine_host.h"
+#include "shard.h"
 
 using namespace ldbg;
 
@@ -22,6 +23,7 @@ struct ldbg_engine {
     explicit ldbg_engine(const ldbg_engine_config& c) : e(c) {}
 };
 struct ldbg_dfs_result { std::unique_ptr<DfsBatch> b; };
+struct ldbg_bsp_walker { BspWalker w; explicit ldbg_bsp_walker(const Engine& e) : w(e) {} };
 
 namespace {
 thread_local std::string g_err;
@@ -165,6 +167,27 @@ ldbg_status ldbg_shard_owner(int k, const uint64_t* packed, int64_t n, int world
         rt::dfree(dq); rt::dfree(d_o);
         rt::stream_destroy(s);
     });
+}
+ldbg_status ldbg_shard_nbr_queries(const ldbg_graph* g, int64_t first, int64_t n, uint64_t* d_words, uint8_t* d_flips) {
+    return guard([&] { rt::set_device(g->g.device); shard_nbr_queries(g->g, first, n, d_words, d_flips); });
+}
+ldbg_status ldbg_shard_set_nbr(ldbg_graph* g, int64_t first, int64_t n, const int32_t* d_owner, const int64_t* d_lidx, const uint8_t* d_flips) {
+    return guard([&] { rt::set_device(g->g.device); shard_set_nbr(g->g, first, n, d_owner, d_lidx, d_flips); });
+}
+ldbg_status ldbg_shard_row_bytes(const ldbg_graph* g, int* bytes) { return guard([&] { *bytes = shard_row_bytes(g->g); }); }
+ldbg_status ldbg_shard_rows(const ldbg_graph* g, const int64_t* d_lidx, int64_t n, uint8_t* d_rows) {
+    return guard([&] { rt::set_device(g->g.device); shard_rows(g->g, d_lidx, n, d_rows); });
+}
+ldbg_status ldbg_bsp_create(const ldbg_engine* e, ldbg_bsp_walker** out) { return guard([&] { *out = nullptr; *out = new ldbg_bsp_walker(e->e); }); }
+ldbg_status ldbg_bsp_destroy(ldbg_bsp_walker* w) { return guard([&] { delete w; }); }
+ldbg_status ldbg_bsp_start(ldbg_bsp_walker* w, int64_t n, const int32_t* d_owner, const int64_t* d_lidx, const uint8_t* d_flip, int32_t* d_ro, int64_t* d_rl) {
+    return guard([&] { w->w.start(n, d_owner, d_lidx, d_flip, d_ro, d_rl); });
+}
+ldbg_status ldbg_bsp_step(ldbg_bsp_walker* w, const uint8_t* d_have, const uint8_t* d_rows, int32_t* d_ro, int64_t* d_rl) {
+    return guard([&] { w->w.step(d_have, d_rows, d_ro, d_rl); });
+}
+ldbg_status ldbg_bsp_results(ldbg_bsp_walker* w, uint32_t* strand_n, uint32_t* status, uint32_t* iters, uint8_t* bases, int64_t stride) {
+    return guard([&] { w->w.results(strand_n, status, iters, bases, stride); });
 }
 ldbg_status ldbg_graph_find(const ldbg_graph* g, const uint64_t* packed, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {
     return guard([&] {

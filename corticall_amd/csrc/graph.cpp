@@ -350,7 +350,7 @@ void Graph::upload(const uint8_t* recs) {
 }
 
 Graph::~Graph() {
-    rt::dfree(d_keys_); rt::dfree(d_cov_); rt::dfree(d_edges_); rt::dfree(d_probe_); rt::dfree(d_pstart_);
+    rt::dfree(d_keys_); rt::dfree(d_cov_); rt::dfree(d_edges_); rt::dfree(d_probe_); rt::dfree(d_pstart_); rt::dfree(d_nbrg);
     rt::stream_destroy(stream);
 }
 

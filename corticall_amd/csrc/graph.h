@@ -99,6 +99,7 @@ public:
     // link sets bound to this graph get a flag bit in the probe rows (at most 8)
     mutable int next_link_slot = 0;
     uint8_t* probe_mutable() const { return (uint8_t*)d_probe_; }
+    void* d_nbrg = nullptr;   // shard of a partitioned table: global neighbour index [N][8] u64 (shard.cpp)
 
 private:
     void* d_keys_ = nullptr; void* d_cov_ = nullptr; void* d_edges_ = nullptr; void* d_probe_ = nullptr; void* d_pstart_ = nullptr;

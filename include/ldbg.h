@@ -112,6 +112,28 @@ ldbg_status ldbg_graph_find_dev(const ldbg_graph* g, const uint64_t* d_packed, i
 ldbg_status ldbg_shard_owner_dev(int k, const uint64_t* d_packed, int64_t n, int world, uint64_t* d_canon, int32_t* d_owner, void* stream);
 ldbg_status ldbg_shard_owner(int k, const uint64_t* packed, int64_t n, int world, int device, int32_t* owner);
 
+/* Walks over the partitioned table (corticall_amd/csrc/shard.cpp; ContigStopper, no links, odd k in round 1).
+ * A walk stays on the rank that holds its seed; per traversed k-mer it fetches ONE row from the owner of the vertex it
+ * steps onto: 8 global neighbour ids (owner, record, orientation — a routed findRecord memoised at load) | flags |
+ * C edge bytes.  All buffers are device buffers of the calling rank; calls return when the work is done. */
+ldbg_status ldbg_shard_nbr_queries(const ldbg_graph* shard, int64_t first, int64_t n, uint64_t* d_words /* [8n][W] */, uint8_t* d_flips /* [8n] */);
+ldbg_status ldbg_shard_set_nbr(ldbg_graph* shard, int64_t first, int64_t n, const int32_t* d_owner, const int64_t* d_local_idx, const uint8_t* d_flips);
+ldbg_status ldbg_shard_row_bytes(const ldbg_graph* shard, int* bytes);
+ldbg_status ldbg_shard_rows(const ldbg_graph* shard, const int64_t* d_local_idx, int64_t n, uint8_t* d_rows);
+typedef struct ldbg_bsp_walker ldbg_bsp_walker;
+struct ldbg_engine;
+ldbg_status ldbg_bsp_create(const struct ldbg_engine* engine_over_shard, ldbg_bsp_walker** out);
+ldbg_status ldbg_bsp_destroy(ldbg_bsp_walker* w);
+/* n seeds -> 2n strands (2i reverse, 2i+1 forward); req_owner[s] >= 0: strand s asks owner req_owner[s] for row req_local_idx[s] */
+ldbg_status ldbg_bsp_start(ldbg_bsp_walker* w, int64_t n_seeds, const int32_t* d_seed_owner, const int64_t* d_seed_local_idx,
+                           const uint8_t* d_seed_flip, int32_t* d_req_owner, int64_t* d_req_local_idx);
+/* have_row[s] != 0: the row strand s asked for is at d_rows + s * row_bytes; every such strand performs one iteration of the
+ * loop TraversalEngine.java:373-481 and files its next request */
+ldbg_status ldbg_bsp_step(ldbg_bsp_walker* w, const uint8_t* d_have_row, const uint8_t* d_rows, int32_t* d_req_owner, int64_t* d_req_local_idx);
+/* host outputs: vertices per strand, status (0 ok, 1 NullPointerException, 3 branch returned null, 8 table full, 11 quirk-Q6
+ * vertex: unsupported here), loop iterations, appended bases [strand][bases_stride] (entry 0 = the seed, unused) */
+ldbg_status ldbg_bsp_results(ldbg_bsp_walker* w, uint32_t* strand_n, uint32_t* status, uint32_t* iters, uint8_t* bases, int64_t bases_stride);
+
 /* ------------------------------------------------------------------ links: L3-L4
  * new CortexLinks(path) -> CortexLinksMap        J/utils/io/graph/links/CortexLinks.java:16-25,
  * CortexLinksIterable.java:49-226 (.ctp.gz text, JSON header v2/3/4).  Bound to a graph for k / device. */

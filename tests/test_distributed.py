@@ -144,3 +144,55 @@ def test_replicas_two_ranks(orc, tmp_path):
     arena, offs, _ = oe.walk_batch(km)
     assert expected == [arena.tobytes()[offs[i]:offs[i + 1]].decode() for i in range(len(seeds))]
     _spawn(_replica_worker, (cs.path, str(tmp_path / "rep.a.ctp.gz"), seeds, expected))
+
+
+def _sharded_walk_worker(rank, world, port, path, seeds, cfgs, expected):
+    dist = _init(rank, world, port)
+    try:
+        from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine, gather_strings, partition
+        from tests import hostsim
+        lib = hostsim.load()
+        sg = ShardedCortexGraph(path, lib=lib, chunk_records=700)
+        sg.build_neighbour_index(chunk_records=300)
+        first, cnt = partition(len(seeds), rank, world)
+        for ci, (trav, direction, op, max_len) in enumerate(cfgs):
+            e = ShardedTraversalEngine(sg, trav, direction=direction, op=op, max_branch_length=max_len)
+            mine = e.walk_batch(seeds[first:first + cnt])
+            got = gather_strings(mine)
+            for i, s in enumerate(seeds):
+                assert got[i] == expected[ci][0][i], (cfgs[ci], s, got[i], expected[ci][0][i])
+            import torch
+            t = torch.tensor([e.kmers_traversed])
+            dist.all_reduce(t)
+            assert int(t.item()) == expected[ci][1], (int(t.item()), expected[ci][1])
+            assert e.exchanges > 0
+            e.close()
+        sg.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("k", [21, 47])
+def test_sharded_walks_two_ranks(orc, tmp_path, k):
+    """ContigStopper walks over a table hash-sharded over two ranks (one row exchange per step) == the oracle's walks
+    on the whole graph: contigs and the number of k-mers traversed"""
+    from tests import parity_cases as pc
+    rng = random.Random(100 + k)
+    base = pc.genome_with_repeats(rng, 900, n_rep=5, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+    kid = pc.mutate(rng, base, snv=0.01, indel=0.003)
+    dad = pc.mutate(rng, base, snv=0.02, indel=0.003)
+    path = str(tmp_path / "sw.ctx")
+    orc.build_graph(path, [("kid", [kid]), ("mom", [base]), ("dad", [dad])], k)
+    og = orc.Graph(path, tuned=True)
+    kmers = [og.record_string(i).split()[0] for i in range(og.N)]
+    seeds = rng.sample(kmers, 60)
+    seeds = [s if rng.random() < 0.5 else orc.revcomp(s) for s in seeds] + [pc.rand_seq(rng, k), "N" * k, kid[:k], kid[-k:]]
+    cfgs = [([0], 0, 0, 75000), ([0], 1, 1, 75000), ([1], 2, 0, 75000), ([0, 2], 0, 0, 75000), ([0], 0, 0, 9)]
+    expected = []
+    for trav, direction, op, max_len in cfgs:
+        oe = orc.Engine(og, trav, op_and=(op == 1), direction=direction, max_length=max_len, stopper="ContigStopper")
+        it0 = oe.kmers_traversed()
+        contigs = [oe.walk(s)[0] for s in seeds]
+        expected.append((contigs, oe.kmers_traversed() - it0))
+    _spawn(_sharded_walk_worker, (path, seeds, cfgs, expected))
