@@ -160,6 +160,78 @@ def bench_c2(args, ca, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
+def bench_c5s(args, ca, prefix, seeds, rank, local_rank, world, dist):
+    """configs[4]'s path at a size that fits this image: the same 3-colour k=47 table HASH-SHARDED over the ranks,
+    ContigStopper walks without link annotations (links are not routed yet), one row exchange per traversed k-mer
+    (corticall_amd/distributed.py::ShardedTraversalEngine)."""
+    import numpy as np
+    import torch
+    from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine
+    t0 = time.time()
+    sg = ShardedCortexGraph(prefix + ".ctx", device=local_rank)
+    sg.build_neighbour_index()
+    t_load = time.time() - t0
+    eng = ShardedTraversalEngine(sg, [0], max_branch_length=args.max_len)
+    mine = [s.tobytes().decode() for s in seeds[:args.sharded_seeds]]
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.walk_batch(mine)
+    ca.profile_reset()
+    eng.exchanges = 0
+    sync()
+    t1 = time.time()
+    traversed = 0
+    for _ in range(args.steps):
+        contigs = eng.walk_batch(mine)
+        traversed += eng.kmers_traversed
+    sync()
+    dt = time.time() - t1
+    step_ms, launches = ca.profile_get("bsp_step")
+    t = torch.tensor([float(traversed), float(len(mine) * args.steps)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t)
+    m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        N, W, C = sg.getNumRecords(), sg.W, sg.C
+        b_find = math.ceil(math.log2(N)) * 8 * W + 5 * C
+        out = {
+            "metric": "k-mers traversed/sec (whole node) + contigs/sec, k=47 3-color LdBG", "value": t[0].item() / m[0].item(),
+            "unit": "k-mers traversed/s", "contigs_per_s": t[1].item() / m[0].item(), "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": m[0].item() / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[4]'s path on the %.1f Mb 3-colour k=%d table hash-sharded over %d rank(s): ContigStopper walks "
+                                   "WITHOUT links from %d seeds per GPU, one row exchange (2 all-to-alls) per traversed k-mer"
+                                   % (args.genome_len / 1e6, args.k, world, len(mine)),
+                       "records": N, "row_bytes": sg.row_bytes, "exchanges_per_step": eng.exchanges // max(1, args.steps),
+                       "kmers_traversed_per_step": traversed // max(1, args.steps), "load_seconds_incl_neighbour_index": round(t_load, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_bsp_step", "achieved": (traversed / max(1, launches)) * b_find / (max(1e-9, step_ms / max(1, launches)) * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "algorithmic_bytes_per_kmer": b_find,
+                         "avg_launch_ms": step_ms / max(1, launches), "launches": launches,
+                         "note": "the exchanges, not this kernel, bound the sharded path: see ms_per_step / exchanges_per_step"},
+        }
+        out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+        if not args.no_cpu_baseline:
+            from oracle import pyoracle as orc
+            og = orc.Graph(prefix + ".ctx", use_cache=True, tuned=False)
+            oe = orc.Engine(og, [0], stopper="ContigStopper", max_length=args.max_len)
+            t2 = time.time()
+            i = mism = 0
+            while i < len(mine) and time.time() - t2 < args.cpu_seconds:
+                mism += 0 if oe.walk(mine[i])[0] == contigs[i] else 1
+                i += 1
+            dtc = time.time() - t2
+            out["cpu_baseline"] = {"value": oe.kmers_traversed() / dtc, "unit": "k-mers traversed/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d seeds (%d k-mers traversed in %.1f s), oracle in faithful mode" % (i, oe.kmers_traversed(), dtc)}
+            out["parity"] = "%d/%d sampled contigs bit-exact vs oracle" % (i - mism, i)
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist, sync, t_load):
     """configs[3]: dfs with DestinationStopper (the gap-closing configuration of Call.java:759-779) from every seed
     towards the child k-mer 200-2000 bp downstream on the seed's own link-guided contig."""
@@ -270,7 +342,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lookups", type=int, default=100000, help="c2: lookups per step (configs[1] says 100k)")
     ap.add_argument("--sharded", action="store_true", help="c2: hash-shard the table over the ranks and route lookups with all-to-all")
-    ap.add_argument("--workload", choices=["c3", "c4", "c2"], default="c3",
+    ap.add_argument("--sharded-seeds", type=int, default=2048, help="c5s: seeds per GPU and step")
+    ap.add_argument("--workload", choices=["c3", "c4", "c2", "c5s"], default="c3",
                     help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
     ap.add_argument("--use-seeds", type=int, default=0, help="experiment: walk only the first N seeds")
     ap.add_argument("--no-links", action="store_true", help="experiment: walk without the link annotations")
@@ -283,7 +356,7 @@ def main():
     import numpy as np
     import torch
     dist = None
-    if world > 1 or args.sharded or os.environ.get("LDBG_FORCE_DIST"):      # LDBG_FORCE_DIST: rehearse the N > 1 code path on one GPU
+    if world > 1 or args.sharded or args.workload == "c5s" or os.environ.get("LDBG_FORCE_DIST"):      # LDBG_FORCE_DIST: rehearse the N > 1 code path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -310,6 +383,9 @@ def main():
     if world > 1:                               # weak scaling: each rank walks its own seeds
         rng = np.random.default_rng(1000 + rank)
         seeds = seeds[rng.permutation(len(seeds))]
+
+    if args.workload == "c5s":
+        return bench_c5s(args, ca, prefix, seeds, rank, local_rank, world, dist)
 
     t_load = time.time()
     g = CortexGraph(prefix + ".ctx", device=local_rank)

@@ -120,6 +120,10 @@ class ShardedCortexGraph:
     def getNumColors(self): return self.C
 
     def _ptr(self, t):
+        """device pointer of a tensor the library is about to read or write.  The library works on its own HIP stream and
+        returns when its work is done; torch's stream is drained first so that the buffer is ready."""
+        if t.is_cuda:
+            self._torch.cuda.current_stream(t.device).synchronize()
         return C.c_void_p(t.data_ptr())
 
     def find_batch(self, kmers):

@@ -89,3 +89,39 @@ def test_sharded_find_one_rank_rccl(orc, lib, tmp_path):
         sg.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_walks_one_rank_rccl(orc, lib, tmp_path):
+    """the bulk-synchronous walker over a sharded table with device buffers and RCCL collectives (one rank here; two
+    ranks on gloo in tests/test_distributed.py)"""
+    import os
+    import random
+    import torch.distributed as dist
+    from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29519")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        rng = random.Random(8)
+        k = 47
+        base = pc.genome_with_repeats(rng, 2500, n_rep=6, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+        kid = pc.mutate(rng, base, snv=0.01, indel=0.003)
+        p = str(tmp_path / "sw.ctx")
+        orc.build_graph(p, [("kid", [kid]), ("mom", [base])], k)
+        og = orc.Graph(p, tuned=True)
+        sg = ShardedCortexGraph(p, lib=lib)
+        kmers = [og.record_string(i).split()[0] for i in range(og.N)]
+        seeds = rng.sample(kmers, 200)
+        seeds = [s if rng.random() < 0.5 else orc.revcomp(s) for s in seeds] + [pc.rand_seq(rng, k), "N" * k]
+        for trav, direction, op in (([0], 0, 0), ([1], 1, 1), ([0, 1], 2, 0)):
+            oe = orc.Engine(og, trav, op_and=(op == 1), direction=direction, stopper="ContigStopper")
+            it0 = oe.kmers_traversed()
+            exp = [oe.walk(s)[0] for s in seeds]
+            e = ShardedTraversalEngine(sg, trav, direction=direction, op=op)
+            got = e.walk_batch(seeds)
+            assert got == exp
+            assert e.kmers_traversed == oe.kmers_traversed() - it0
+            e.close()
+        sg.close()
+    finally:
+        dist.destroy_process_group()
