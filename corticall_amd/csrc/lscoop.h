@@ -5,8 +5,8 @@
 // with 64 strands per wavefront some lane is at a junction in most iterations.  Here the WHOLE wavefront carries out one
 // lane's (the owner's) operation: lane h handles elements h, h+64, ...; agreement, minimum and "last of the key" are
 // ballots and butterfly reductions; expiry is a ballot-prefix compaction.  The semantics are those of the one-lane
-// versions in engine.h (ls_add / ls_next_choice), which the cursor and dfs kernels keep using; both are held to the
-// oracle by the same parity cases.
+// versions in engine.h (ls_add / ls_next_choice), which the cursor and dfs kernels keep using; both go through the same
+// parity cases (tests/parity_cases.py).
 #pragma once
 #include "engine.h"
 
