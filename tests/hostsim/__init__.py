@@ -17,7 +17,9 @@ def build():
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
-def load():
+def load(rebuild=True):
+    """rebuild=False: workers spawned by a test that has already built the library (two makes at once would race)"""
     from corticall_amd import NativeLib
-    build()
+    if rebuild:
+        build()
     return NativeLib(SO)

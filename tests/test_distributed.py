@@ -34,7 +34,7 @@ def _sharded_worker(rank, world, port, paths):
         from corticall_amd.distributed import ShardedCortexGraph
         from oracle import pyoracle as orc
         from tests import hostsim
-        lib = hostsim.load()
+        lib = hostsim.load(rebuild=False)
         for path in paths:
             og = orc.Graph(path, tuned=True)
             sg = ShardedCortexGraph(path, lib=lib, chunk_records=1000)
@@ -75,7 +75,7 @@ def _replica_worker(rank, world, port, ctx, ctp, seeds, expected):
         from corticall_amd import BOTH, OR, ContigStopper, CortexGraph, CortexLinks, TraversalEngineFactory
         from corticall_amd.distributed import gather_strings, partition
         from tests import hostsim
-        lib = hostsim.load()
+        lib = hostsim.load(rebuild=False)
         g = CortexGraph(ctx, lib=lib)
         e = (TraversalEngineFactory(lib=lib).traversalColors(0).traversalDirection(BOTH).combinationOperator(OR)
              .stoppingRule(ContigStopper).graph(g).links(CortexLinks(ctp, g)).maxBranchLength(300).make())
@@ -89,6 +89,8 @@ def _replica_worker(rank, world, port, ctx, ctp, seeds, expected):
 
 def _spawn(fn, args, world=2):
     import torch.multiprocessing as mp
+    from tests import hostsim
+    hostsim.build()          # once, here: the workers only load it
     mp.spawn(fn, args=(world, _free_port()) + tuple(args), nprocs=world, join=True)
 
 
@@ -151,7 +153,7 @@ def _sharded_walk_worker(rank, world, port, path, seeds, cfgs, expected):
     try:
         from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine, gather_strings, partition
         from tests import hostsim
-        lib = hostsim.load()
+        lib = hostsim.load(rebuild=False)
         sg = ShardedCortexGraph(path, lib=lib, chunk_records=700)
         sg.build_neighbour_index(chunk_records=300)
         first, cnt = partition(len(seeds), rank, world)
