@@ -24,6 +24,7 @@
 #include <thread>
 #include <unordered_set>
 
+#include "lscoop.h"
 #include "stoppers.h"
 #include "strand.h"
 
@@ -215,7 +216,7 @@ LDBG_DEV bool end_branch(const DfsArgs& a, DfsLane<W>& L, bool success) {
 
 // one micro-step; returns true when the strand has ended
 template <int W>
-LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t slot) {
+LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t slot, const StepPre& pre) {
     StrandState& st = L.st;
     const EngineView& e = a.w.e;
     const bool fwd = st.fwd;
@@ -283,7 +284,7 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
     uint32_t avs_mask = 0;
     Node av = cv;
     if (e.cursor_on && st.cu.has) {                     // :379-407
-        av = cursor_step<W>(e, st.cu, ls, st.vt, fwd);
+        av = cursor_step<W, true>(e, st.cu, ls, st.vt, fwd, &pre);   // its link-store part was done by the wavefront (lscoop.h)
         if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
         if (st.cu.has) { node_sync(cv, st.cu.nxt); node_sync(av, st.cu.nxt); }   // the `seen` mark may sit in a slot they hold
         const int cnt = node_count(av);                 // first copyIndex not in visited
@@ -388,6 +389,9 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
     ls.el = a.w.ls + (size_t)slot * a.w.ecap;
     ls.cap = a.w.ecap + LDBG_LS_FAST;
     ls_clear(ls);
+    LsWave lw;
+    lw.fast = fast - wave_lane(); lw.stride = fast_stride; lw.fast_cap = LDBG_LS_FAST;
+    lw.el = a.w.ls + (size_t)(slot - wave_lane()) * a.w.ecap; lw.ecap = a.w.ecap;
     DfsLane<W> L;
     L.st.vt.tab = nullptr; L.st.vt.mask = 0; L.st.vt.used = 0; L.st.status = ST_OK;
     L.phase = PH_ITER;
@@ -408,7 +412,10 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
             }
         }
         wave_grow_tables(a.w, L.st, active);
-        if (active && dfs_step<W>(a, L, ls, slot)) { strand_finish(a.w, L.st); active = false; }
+        const bool cur_mode = active && L.st.status == ST_OK && L.phase == PH_ITER && a.w.e.cursor_on && L.st.cu.has;
+        StepPre pre;
+        coop_step_prepare<W>(a.w.e, L.st, ls, lw, cur_mode, pre);
+        if (active && dfs_step<W>(a, L, ls, slot, pre)) { strand_finish(a.w, L.st); active = false; }
     }
 }
 
@@ -729,7 +736,6 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     DfsArgs a;
     memset(&a, 0, sizeof(a));
     a.w.e = view;
-    a.w.e.dbg = 0;
     a.w.seeds = d_seeds;
     a.w.n_strands = ns;
     a.w.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);

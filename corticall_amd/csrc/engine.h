@@ -20,7 +20,6 @@ struct EngineView {
     int stopper, max_len, connect_all, strict_flip;
     int cursor_on;        // !ec.getLinks().isEmpty(): dfs drives the cursor (TraversalEngine.java:363, 379) even
                           // when none of the configured link sets belongs to a traversal sample
-    uint32_t dbg;         // timing experiments only (LDBG_DEBUG_SKIP): results are wrong when non-zero
     uint32_t link_flag_mask;   // probe-row link-flag bits of the link sets merged into `links`
     LinksView links;      // the traversal's link sets merged into one table (links.h)
 };

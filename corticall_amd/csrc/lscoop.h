@@ -9,6 +9,7 @@
 // parity cases (tests/parity_cases.py).
 #pragma once
 #include "engine.h"
+#include "strand.h"
 
 namespace ldbg {
 
@@ -240,6 +241,53 @@ LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHd
     h.n_new = n_new;
     *choice = ch;
     return true;
+}
+
+// The link-store part of one cursor step (TraversalEngine.java:241-276) for every lane of the wavefront that is in cursor
+// mode: per-lane prefetch, cooperative adds, cooperative junction choices.  `pre` then carries the results into
+// cursor_step<W, true>.  Every lane of the wavefront must call this (cur_mode false where it does not apply).
+template <int W>
+LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreDev& ls, const LsWave& lw, bool cur_mode, StepPre& pre) {
+    // Two independent chains of dependent loads start here: (links) rec_of -> offsets -> junction records of the
+    // vertex about to be stepped onto, and (graph) its neighbour pointer -> the next row + its table slot.  They are
+    // issued stage by stage so that they overlap.
+    const uint32_t nmask = cur_mode ? (st.fwd ? st.cu.nxt.next_mask : st.cu.nxt.prev_mask) : 0u;
+    const bool one_child = cur_mode && popc4(nmask) == 1;
+    const bool flagged = cur_mode && (st.cu.nxt.lflags & e.link_flag_mask);
+    uint32_t m_cur = 0xFFFFFFFFu, m_nxt = 0xFFFFFFFFu, child_ent = 0;
+    if (flagged) m_nxt = e.links.rec_of[st.cu.nxt.idx];
+    if (one_child) child_ent = st.cu.nxt.e1 ? st.cu.nxt.ent1 : node_child_entry(e, st.cu.nxt, st.fwd, lowbit4(nmask));
+    if (cur_mode && st.cu.first && (st.cu.cur.lflags & e.link_flag_mask)) m_cur = e.links.rec_of[st.cu.cur.idx];
+    AddPre ap_cur = AddPre(), ap_nxt = AddPre();
+    if (m_nxt != 0xFFFFFFFFu) { ap_nxt.jlo = e.links.off[m_nxt]; ap_nxt.jhi = e.links.off[m_nxt + 1]; }
+    pre.has_child = one_child;
+    if (one_child) node_from_entry(e, st.vt, st.cu.nxt, child_ent, lowbit4(nmask), st.fwd, pre.child);
+    if (m_nxt != 0xFFFFFFFFu) {
+        ap_nxt.r0 = e.links.junc[ap_nxt.jlo];
+        ap_nxt.r1 = e.links.junc[ap_nxt.jlo + 1 < ap_nxt.jhi ? ap_nxt.jlo + 1 : ap_nxt.jlo];
+    }
+    if (m_cur != 0xFFFFFFFFu) ap_cur = add_prefetch(e.links, (int64_t)m_cur);
+    pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0;
+    unsigned long long need = wave_ballot(m_cur != 0xFFFFFFFFu || m_nxt != 0xFFFFFFFFu);
+    while (need) {
+        const int L = __builtin_ctzll(need);
+        need &= need - 1;
+        LsHdr h = lsw_header(ls, L);
+        const uint32_t flags = wave_bcast_u32((st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u) |
+                                              (m_cur != 0xFFFFFFFFu ? 8u : 0u) | (m_nxt != 0xFFFFFFFFu ? 16u : 0u), L);
+        if (flags & 8u) coop_add(e.links, lw, L, h, bcast_addpre(ap_cur, L), (flags & 1u) != 0, (flags & 4u) != 0);
+        if ((flags & 16u) && !h.overflow) coop_add(e.links, lw, L, h, bcast_addpre(ap_nxt, L), (flags & 2u) != 0, (flags & 4u) != 0);
+        if (wave_lane() == L) lsw_store_header(ls, h);
+    }
+    need = wave_ballot(cur_mode && popc4(nmask) > 1);
+    while (need) {                                    // junction choices (:266-272)
+        const int L = __builtin_ctzll(need);
+        need &= need - 1;
+        LsHdr h = lsw_header(ls, L);
+        unsigned ch = 0;
+        const bool ok = coop_next_choice(e.links, lw, L, h, &ch);
+        if (wave_lane() == L) { lsw_store_header(ls, h); pre.choice_done = true; pre.choice_ok = ok; pre.ch = ch; }
+    }
 }
 
 }  // namespace ldbg

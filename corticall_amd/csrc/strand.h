@@ -66,7 +66,7 @@ LDBG_DEV bool path_append(const WalkArgs& a, int64_t s, PathWriter& pw, uint64_t
             pw.nblk = bi + 1;
         }
     }
-    if (!(a.e.dbg & 1u)) pw.cur[off] = entry;
+    pw.cur[off] = entry;
     pw.n++;
     return true;
 }

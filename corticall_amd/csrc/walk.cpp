@@ -118,47 +118,8 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
         wave_grow_tables(a, st, active);
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
         const bool cur_mode = active && st.status == ST_OK && a.e.cursor_on && st.cu.has;
-        // Two independent chains of dependent loads start here: (links) rec_of -> offsets -> junction records of the
-        // vertex about to be stepped onto, and (graph) its neighbour pointer -> the next row + its table slot.  They are
-        // issued stage by stage so that they overlap.
-        const uint32_t nmask = cur_mode ? (st.fwd ? st.cu.nxt.next_mask : st.cu.nxt.prev_mask) : 0u;
-        const bool one_child = cur_mode && popc4(nmask) == 1;
-        const bool flagged = cur_mode && (st.cu.nxt.lflags & a.e.link_flag_mask);
-        uint32_t m_cur = 0xFFFFFFFFu, m_nxt = 0xFFFFFFFFu, child_ent = 0;
-        if (flagged) m_nxt = a.e.links.rec_of[st.cu.nxt.idx];
-        if (one_child) child_ent = st.cu.nxt.e1 ? st.cu.nxt.ent1 : node_child_entry(a.e, st.cu.nxt, st.fwd, lowbit4(nmask));
-        if (cur_mode && st.cu.first && (st.cu.cur.lflags & a.e.link_flag_mask)) m_cur = a.e.links.rec_of[st.cu.cur.idx];
-        AddPre ap_cur = AddPre(), ap_nxt = AddPre();
-        if (m_nxt != 0xFFFFFFFFu) { ap_nxt.jlo = a.e.links.off[m_nxt]; ap_nxt.jhi = a.e.links.off[m_nxt + 1]; }
         StepPre pre;
-        pre.has_child = one_child;
-        if (one_child) node_from_entry(a.e, st.vt, st.cu.nxt, child_ent, lowbit4(nmask), st.fwd, pre.child);
-        if (m_nxt != 0xFFFFFFFFu) {
-            ap_nxt.r0 = a.e.links.junc[ap_nxt.jlo];
-            ap_nxt.r1 = a.e.links.junc[ap_nxt.jlo + 1 < ap_nxt.jhi ? ap_nxt.jlo + 1 : ap_nxt.jlo];
-        }
-        if (m_cur != 0xFFFFFFFFu) ap_cur = add_prefetch(a.e.links, (int64_t)m_cur);
-        pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0;
-        unsigned long long need = wave_ballot(m_cur != 0xFFFFFFFFu || m_nxt != 0xFFFFFFFFu);
-        while (need) {
-            const int L = __builtin_ctzll(need);
-            need &= need - 1;
-            LsHdr h = lsw_header(ls, L);
-            const uint32_t flags = wave_bcast_u32((st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u) |
-                                                  (m_cur != 0xFFFFFFFFu ? 8u : 0u) | (m_nxt != 0xFFFFFFFFu ? 16u : 0u), L);
-            if (flags & 8u) coop_add(a.e.links, lw, L, h, bcast_addpre(ap_cur, L), (flags & 1u) != 0, (flags & 4u) != 0);
-            if ((flags & 16u) && !h.overflow) coop_add(a.e.links, lw, L, h, bcast_addpre(ap_nxt, L), (flags & 2u) != 0, (flags & 4u) != 0);
-            if (wave_lane() == L) lsw_store_header(ls, h);
-        }
-        need = wave_ballot(cur_mode && popc4(nmask) > 1);
-        while (need) {                                    // junction choices (:266-272)
-            const int L = __builtin_ctzll(need);
-            need &= need - 1;
-            LsHdr h = lsw_header(ls, L);
-            unsigned ch = 0;
-            const bool ok = coop_next_choice(a.e.links, lw, L, h, &ch);
-            if (wave_lane() == L) { lsw_store_header(ls, h); pre.choice_done = true; pre.choice_ok = ok; pre.ch = ch; }
-        }
+        coop_step_prepare<W>(a.e, st, ls, lw, cur_mode, pre);
         if (active && strand_step<W>(a, st, ls, pre)) { strand_finish(a, st); active = false; }
     }
 #ifndef LDBG_HOSTSIM
@@ -346,7 +307,6 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.link_flag_mask = merged_->flag_mask;
     // ec.getLinks().isEmpty() (not "my links") decides whether dfs uses the cursor (:363, :379)
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
-    view.dbg = 0;
 }
 
 Engine::~Engine() { clear_batch(); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); }
@@ -453,8 +413,6 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
 
     WalkArgs a;
     a.e = view;
-    a.e.dbg = 0;
-    if (const char* ev = getenv("LDBG_DEBUG_SKIP")) a.e.dbg = (uint32_t)atoi(ev);   // timing experiments only
     a.seeds = (const uint64_t*)out.d_seed_words;
     a.n_strands = ns;
     a.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
