@@ -343,6 +343,8 @@ ldbg_status ldbg_dfs_result_sizes(const ldbg_dfs_result* r, int64_t i, int* is_n
 ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result* r, int64_t i, uint64_t* kmer_words, int64_t* rec, int32_t* copy_index, int32_t* index,
                                 int32_t* edge_src, int32_t* edge_dst, int32_t* edge_color) {
     return guard([&] {
+        dfs_at(r, i);
+        if (kmer_words) r->b->materialize();
         const DfsGraphHost& g = dfs_at(r, i);
         if (kmer_words && !g.words.empty()) memcpy(kmer_words, g.words.data(), g.words.size() * 8);
         for (size_t v = 0; v < g.verts.size(); v++) {

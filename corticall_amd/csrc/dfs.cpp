@@ -19,6 +19,7 @@
 //    (vertex/edge insertion order, Graphs.addGraph merges, index relabelling, OR/AND combination, :75-99) are
 //    replayed on the host from that log (assemble_* below).
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <unordered_map>
 #include <thread>
@@ -668,7 +669,7 @@ DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, c
         if (!ascii_to_words(sinks + i * k, k, &sink_words[i * W], W)) { for (int w = 0; w < W; w++) sink_words[i * W + w] = ~0ull; }
 
     std::unique_ptr<DfsBatch> out(new DfsBatch);
-    out->k = k; out->W = W; out->C = graph->hdr.C;
+    out->k = k; out->W = W; out->C = graph->hdr.C; out->graph = graph;
     out->results.resize((size_t)n);
     out->traversed = 0;
     std::vector<std::pair<int64_t, int64_t>> todo{{0, n}};
@@ -808,6 +809,10 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         }
     }
     for (int64_t i = 0; i < ns; i++) out.traversed += iters[i];
+    const bool want_times = getenv("LDBG_DFS_TIMES") != nullptr;     // diagnostics: host phases of the call
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_phase = now();
 
     // dense logs -> host
     std::vector<int64_t> strand_off((size_t)ns + 1, 0);
@@ -823,6 +828,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         rt::stream_sync(s);
     }
 
+    if (want_times) { fprintf(stderr, "[ldbg] dfs host: log compaction + download %.1f ms (%lld entries)\n", ms_since(t_phase), (long long)total); t_phase = now(); }
     // replay the JGraphT container semantics (dfs(source, sinks) :64-106); seeds are independent -> host threads
     const int color = cfg.traversal_colors[0];
     const bool op_and = cfg.combination_operator == LDBG_OP_AND;
@@ -890,13 +896,15 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         for (auto& th : pool) th.join();
         for (auto& er : thread_err) if (!er.empty()) throw StatusError(LDBG_ERR_HIP, er);
     }
-    // slots were numbered per thread: make them global
-    std::vector<uint64_t> gather_keys;
+    if (want_times) { fprintf(stderr, "[ldbg] dfs host: graph assembly %.1f ms on %d threads\n", ms_since(t_phase), n_threads); t_phase = now(); }
+    // slots were numbered per thread (and per chunk): make them global.  The k-mers and coverages of the vertices are
+    // gathered when a result is first read (DfsBatch::materialize): the graphs themselves — record numbers, orientations,
+    // copy indices, edges — are complete here.
     {
-        std::vector<int64_t> base((size_t)n_threads + 1, 0);
+        std::vector<int64_t> base((size_t)n_threads + 1, (int64_t)out.gather_keys.size());
         for (int t = 0; t < n_threads; t++) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)thread_keys[(size_t)t].size();
-        gather_keys.reserve((size_t)base[(size_t)n_threads]);
-        for (int t = 0; t < n_threads; t++) gather_keys.insert(gather_keys.end(), thread_keys[(size_t)t].begin(), thread_keys[(size_t)t].end());
+        out.gather_keys.reserve((size_t)base[(size_t)n_threads]);
+        for (int t = 0; t < n_threads; t++) out.gather_keys.insert(out.gather_keys.end(), thread_keys[(size_t)t].begin(), thread_keys[(size_t)t].end());
         const int64_t per = (n + n_threads - 1) / n_threads;
         for (int64_t i = 0; i < n; i++) {
             const int64_t off = base[(size_t)std::min<int64_t>(n_threads - 1, i / per)];
@@ -904,14 +912,23 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             for (auto& o : out.results[(size_t)(first + i)].verts) if (o.rec >= 0) o.slot += off;
         }
     }
-    // k-mers and coverages of the vertices, gathered from the probe rows in one launch
+    if (want_times) fprintf(stderr, "[ldbg] dfs host: slot renumbering %.1f ms\n", ms_since(t_phase));
+    return true;
+}
+
+// k-mers and coverages of every vertex of the batch, gathered from the probe rows in one launch
+void DfsBatch::materialize() {
+    if (materialized) return;
+    materialized = true;
+    rt::set_device(graph->device);
+    rt::stream_t s = graph->stream;
     const int64_t ng = (int64_t)gather_keys.size();
     std::vector<uint64_t> gw((size_t)std::max<int64_t>(1, ng) * W);
     std::vector<uint32_t> gc((size_t)std::max<int64_t>(1, ng) * C);
     if (ng > 0) {
-        uint64_t* d_keys = (uint64_t*)tmp.get((size_t)ng * 8);
-        uint64_t* d_w = (uint64_t*)tmp.get((size_t)ng * W * 8);
-        uint32_t* d_c = (uint32_t*)tmp.get((size_t)ng * C * 4);
+        uint64_t* d_keys = (uint64_t*)rt::dmalloc((size_t)ng * 8);
+        uint64_t* d_w = (uint64_t*)rt::dmalloc((size_t)ng * W * 8);
+        uint32_t* d_c = (uint32_t*)rt::dmalloc((size_t)ng * C * 4);
         rt::h2d(d_keys, gather_keys.data(), (size_t)ng * 8, s);
         const int g = grid_of(ng, 256, 4096);
         switch (W) {
@@ -923,27 +940,38 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         rt::d2h(gw.data(), d_w, (size_t)ng * W * 8, s);
         rt::d2h(gc.data(), d_c, (size_t)ng * C * 4, s);
         rt::stream_sync(s);
+        rt::dfree(d_keys); rt::dfree(d_w); rt::dfree(d_c);
     }
-    for (int64_t i = 0; i < n; i++) {
-        DfsGraphHost& r = out.results[(size_t)(first + i)];
-        r.words.resize(r.verts.size() * (size_t)W);
-        r.cov.assign(r.verts.size() * (size_t)C, 0);
-        for (size_t v = 0; v < r.verts.size(); v++) {
-            const DfsVertex& o = r.verts[v];
-            if (o.rec >= 0) {
-                for (int w = 0; w < W; w++) r.words[v * W + w] = gw[(size_t)o.slot * W + w];
-                for (int c = 0; c < C; c++) r.cov[v * C + c] = gc[(size_t)o.slot * C + c];
-            } else {
-                const auto& nk = r.null_kmers[(size_t)(-o.slot - 1)];
-                for (int w = 0; w < W; w++) r.words[v * W + w] = nk[w];
+    std::vector<uint64_t>().swap(gather_keys);
+    const int64_t n = (int64_t)results.size();
+    const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)16, n / 64 + 1}));
+    auto fill = [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            DfsGraphHost& r = results[(size_t)i];
+            r.words.resize(r.verts.size() * (size_t)W);
+            r.cov.assign(r.verts.size() * (size_t)C, 0);
+            for (size_t v = 0; v < r.verts.size(); v++) {
+                const DfsVertex& o = r.verts[v];
+                if (o.rec >= 0) {
+                    for (int w = 0; w < W; w++) r.words[v * W + w] = gw[(size_t)o.slot * W + w];
+                    for (int c = 0; c < C; c++) r.cov[v * C + c] = gc[(size_t)o.slot * C + c];
+                } else {
+                    const auto& nk = r.null_kmers[(size_t)(-o.slot - 1)];
+                    for (int w = 0; w < W; w++) r.words[v * W + w] = nk[w];
+                }
             }
         }
-    }
-    return true;
+    };
+    std::vector<std::thread> pool;
+    const int64_t per = (n + n_threads - 1) / n_threads;
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(fill, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
+    fill(0, std::min<int64_t>(n, per));
+    for (auto& th : pool) th.join();
 }
 
 // TraversalUtils.toWalk(g, seed, colour) + toContig (TraversalUtils.java:367-488) over an assembled result
-std::string DfsBatch::walk_contig(int64_t i, const char* seed, int color) const {
+std::string DfsBatch::walk_contig(int64_t i, const char* seed, int color) {
+    materialize();
     const DfsGraphHost& r = results.at((size_t)i);
     if (r.is_null) return std::string();
     if (color < 0 || color >= C) throw StatusError(LDBG_ERR_ARG, "colour out of range");

@@ -37,7 +37,12 @@ struct DfsBatch {
     int k = 0, W = 0, C = 0;
     int64_t traversed = 0;
     std::vector<DfsGraphHost> results;
-    std::string walk_contig(int64_t i, const char* seed, int color) const;
+    // the k-mer words and coverages of the vertices are gathered from the device on first use (the graph must still be open)
+    const Graph* graph = nullptr;
+    std::vector<uint64_t> gather_keys;
+    bool materialized = false;
+    void materialize();
+    std::string walk_contig(int64_t i, const char* seed, int color);
 };
 
 class Engine {

@@ -207,7 +207,10 @@ ldbg_status ldbg_engine_walk_vertices(ldbg_engine* e, int64_t walk, int64_t capa
  * sources n × k ASCII; sinks as CSR over ASCII k-mers (sink_offsets[n+1] counts k-mers; may be NULL). */
 ldbg_status ldbg_engine_dfs_batch(ldbg_engine* e, const char* sources, int64_t n,
                                   const char* sinks, const int64_t* sink_offsets, ldbg_dfs_result** out);
-/* result i: is_null = dfs returned null; vertices in insertion order; edges (src,dst index into vertices, colour) */
+/* result i: is_null = dfs returned null; vertices in insertion order; edges (src,dst index into vertices, colour).
+ * The graphs (record numbers, copy indices, indices, edges) are complete when dfs_batch returns; the k-mer words of the
+ * vertices are gathered from the device the first time they are asked for (kmer_words != NULL, or _walk), so the graph
+ * handle must still be open then. */
 ldbg_status ldbg_dfs_result_sizes(const ldbg_dfs_result* r, int64_t i, int* is_null, int64_t* n_vertices, int64_t* n_edges);
 ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result* r, int64_t i,
                                 uint64_t* kmer_words, int64_t* rec, int32_t* copy_index, int32_t* index,
