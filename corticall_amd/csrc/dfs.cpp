@@ -906,11 +906,16 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         out.gather_keys.reserve((size_t)base[(size_t)n_threads]);
         for (int t = 0; t < n_threads; t++) out.gather_keys.insert(out.gather_keys.end(), thread_keys[(size_t)t].begin(), thread_keys[(size_t)t].end());
         const int64_t per = (n + n_threads - 1) / n_threads;
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t off = base[(size_t)std::min<int64_t>(n_threads - 1, i / per)];
-            if (off == 0) continue;
-            for (auto& o : out.results[(size_t)(first + i)].verts) if (o.rec >= 0) o.slot += off;
-        }
+        auto shift = [&](int t) {
+            const int64_t off = base[(size_t)t];
+            if (off == 0) return;
+            for (int64_t i = std::min<int64_t>(n, t * per); i < std::min<int64_t>(n, (t + 1) * per); i++)
+                for (auto& o : out.results[(size_t)(first + i)].verts) if (o.rec >= 0) o.slot += off;
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; t++) pool.emplace_back(shift, t);
+        shift(0);
+        for (auto& th : pool) th.join();
     }
     if (want_times) fprintf(stderr, "[ldbg] dfs host: slot renumbering %.1f ms\n", ms_since(t_phase));
     return true;
