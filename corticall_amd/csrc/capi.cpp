@@ -306,6 +306,10 @@ ldbg_status ldbg_engine_walk_vertices(ldbg_engine* e, int64_t walk, int64_t capa
     return guard([&] { e->e.walk_vertices(walk, capacity, len, words, rec, copy, index); });
 }
 
+ldbg_status ldbg_engine_walk_roi_hits(ldbg_engine* e, int64_t* offsets, uint32_t* hits, int64_t capacity, uint8_t* has_null) {
+    return guard([&] { e->e.walk_roi_hits(offsets, hits, capacity, has_null); });
+}
+
 ldbg_status ldbg_engine_dfs_batch(ldbg_engine* e, const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets, ldbg_dfs_result** out) {
     return guard([&] {
         *out = nullptr;

@@ -59,6 +59,7 @@ public:
     void walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len);
     void walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index);
     void clear_batch();
+    void walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, uint8_t* has_null);
     // dfs(source, sinks...) for n sources; sinks as CSR over ASCII k-mers (sink_offsets may be nullptr)
     DfsBatch* dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets);
     int dfs_max_depth = 64;
@@ -79,6 +80,7 @@ private:
     int max_blocks_ = 0;
     void* d_frames_ = nullptr; size_t d_frames_bytes_ = 0;
     void* d_roi_bits_ = nullptr;
+    void* d_roi_of_ = nullptr;
     int64_t dfs_traversed_ = 0;
     std::unique_ptr<MergedLinks> merged_;
     void build_roi_bits();

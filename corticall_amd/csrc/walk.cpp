@@ -259,6 +259,51 @@ LDBG_KERNEL void k_walk_vertices(GraphView g, const uint64_t* dense, int64_t ro,
     }
 }
 
+// ---- which ROI records the vertices of each walk are (Partition.markUsedRois, J/commands/discover/call/Partition.java:238-257)
+// roi_of[record] = number of that record's k-mer in the ROI graph (0xFFFFFFFF: not a ROI k-mer).  One wavefront per walk;
+// fill == 0: count hits (and note walks whose graph holds a vertex without a record); fill == 1: write them.
+struct RoiHitArgs {
+    const uint32_t* roi_of;
+    int64_t n;
+    const uint64_t* dense; const int64_t* strand_off; const int64_t* walk_len;
+    unsigned long long* count;     // [n]
+    const int64_t* out_off;        // [n + 1] (fill pass)
+    uint32_t* out;
+    uint8_t* has_null;             // [n]
+    int fill;
+};
+LDBG_KERNEL void k_roi_hits(RoiHitArgs a) {
+    const int64_t wave = global_tid() >> 6, lane = global_tid() & 63, nwaves = (global_nthreads() + 63) >> 6;
+    for (int64_t i = wave; i < a.n; i += nwaves) {
+        const int64_t ro = a.strand_off[2 * i], nr = a.strand_off[2 * i + 1] - ro;
+        const int64_t fo = a.strand_off[2 * i + 1], nf = a.strand_off[2 * i + 2] - fo;
+        const bool in_walk = a.walk_len[i] > 0;
+        bool null_seen = false;
+        for (int64_t p = lane; p < nr + nf; p += 64) {
+            const bool fwd_part = p >= nr;
+            const uint64_t e = a.dense[fwd_part ? fo + (p - nr) : ro + p];
+            const int64_t idx = path_idx(e);
+            if (idx < 0) { null_seen = true; continue; }
+            if (fwd_part && p == nr && nr > 0) continue;       // the seed is entry 0 of both strands
+            if (!in_walk) continue;
+            const uint32_t r = a.roi_of[idx];
+            if (r == 0xFFFFFFFFu) continue;
+            const unsigned long long slot = atomic_add_u64(&a.count[i], 1ull);
+            if (a.fill) a.out[a.out_off[i] + (int64_t)slot] = r;
+        }
+        if (!a.fill && null_seen) a.has_null[i] = 1;
+    }
+}
+template <int W>
+LDBG_KERNEL void k_roi_of(GraphView g, GraphView rois, uint32_t* roi_of) {
+    for (int64_t i = global_tid(); i < rois.N; i += global_nthreads()) {
+        GraphView exact = g;
+        exact.java_tiny = 0;
+        const int64_t idx = graph_find_canonical<W>(exact, graph_key<W>(rois, i));
+        if (idx >= 0) roi_of[idx] = (uint32_t)i;
+    }
+}
+
 // ------------------------------------------------------------------ host
 static uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)p; }
 static int grid_for(int64_t n, int block, int max_blocks) {
@@ -309,7 +354,72 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
 }
 
-Engine::~Engine() { clear_batch(); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); }
+Engine::~Engine() { clear_batch(); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
+
+// ROI hits of the walks of the last batch: offsets[n+1] into hits (ROI record numbers, order within a walk arbitrary),
+// has_null[i] = the dfs graph of seed i holds a vertex without a record
+void Engine::walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, uint8_t* has_null) {
+    if (!rois) throw StatusError(LDBG_ERR_ARG, "walk_roi_hits: the engine has no ROI graph");
+    rt::set_device(graph->device);
+    rt::stream_t s = graph->stream;
+    const int W = graph->hdr.W;
+    if (!d_roi_of_) {
+        if (rois->hdr.k != graph->hdr.k) throw StatusError(LDBG_ERR_ARG, "the ROI graph must have the k-mer size of the traversed graph");
+        const size_t nrec = (size_t)std::max<int64_t>(1, graph->view.N);
+        d_roi_of_ = rt::dmalloc(nrec * 4);
+        rt::dmemset(d_roi_of_, 0xFF, nrec * 4, s);
+        if (rois->view.N > 0) {
+            const int grid = grid_for(rois->view.N, 256, 4096);
+            switch (W) {
+                case 1: LDBG_LAUNCH(k_roi_of<1>, grid, 256, s, graph->view, rois->view, (uint32_t*)d_roi_of_); break;
+                case 2: LDBG_LAUNCH(k_roi_of<2>, grid, 256, s, graph->view, rois->view, (uint32_t*)d_roi_of_); break;
+                case 3: LDBG_LAUNCH(k_roi_of<3>, grid, 256, s, graph->view, rois->view, (uint32_t*)d_roi_of_); break;
+                default: LDBG_LAUNCH(k_roi_of<4>, grid, 256, s, graph->view, rois->view, (uint32_t*)d_roi_of_); break;
+            }
+        }
+    }
+    // pass 1: counts
+    std::vector<std::vector<unsigned long long>> counts(chunks.size());
+    int64_t total = 0;
+    offsets[0] = 0;
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        WalkChunk& c = chunks[ci];
+        RoiHitArgs a;
+        a.roi_of = (const uint32_t*)d_roi_of_; a.n = c.n; a.dense = (const uint64_t*)c.d_path;
+        int64_t* d_soff = (int64_t*)rt::dmalloc((size_t)(2 * c.n + 1) * 8);
+        int64_t* d_wl = (int64_t*)rt::dmalloc((size_t)std::max<int64_t>(1, c.n) * 8);
+        unsigned long long* d_cnt = (unsigned long long*)rt::dmalloc((size_t)std::max<int64_t>(1, c.n) * 8);
+        uint8_t* d_null = (uint8_t*)rt::dmalloc((size_t)std::max<int64_t>(1, c.n));
+        rt::h2d(d_soff, c.strand_off.data(), (size_t)(2 * c.n + 1) * 8, s);
+        rt::h2d(d_wl, c.walk_len.data(), (size_t)c.n * 8, s);
+        rt::dmemset(d_cnt, 0, (size_t)std::max<int64_t>(1, c.n) * 8, s);
+        rt::dmemset(d_null, 0, (size_t)std::max<int64_t>(1, c.n), s);
+        a.strand_off = d_soff; a.walk_len = d_wl; a.count = d_cnt; a.out_off = nullptr; a.out = nullptr; a.has_null = d_null; a.fill = 0;
+        const int grid = grid_for(c.n * 64, 256, 4096);
+        LDBG_LAUNCH(k_roi_hits, grid, 256, s, a);
+        counts[ci].resize((size_t)c.n);
+        rt::d2h(counts[ci].data(), d_cnt, (size_t)c.n * 8, s);
+        rt::d2h(has_null + c.first, d_null, (size_t)c.n, s);
+        rt::stream_sync(s);
+        std::vector<int64_t> off((size_t)c.n + 1, 0);
+        for (int64_t i = 0; i < c.n; i++) { off[i + 1] = off[i] + (int64_t)counts[ci][i]; offsets[c.first + i + 1] = total + off[i + 1]; }
+        const int64_t chunk_total = off[c.n];
+        if (total + chunk_total <= capacity && chunk_total > 0) {          // pass 2: fill
+            int64_t* d_off = (int64_t*)rt::dmalloc((size_t)(c.n + 1) * 8);
+            uint32_t* d_out = (uint32_t*)rt::dmalloc((size_t)chunk_total * 4);
+            rt::h2d(d_off, off.data(), (size_t)(c.n + 1) * 8, s);
+            rt::dmemset(d_cnt, 0, (size_t)c.n * 8, s);
+            a.out_off = d_off; a.out = d_out; a.fill = 1;
+            LDBG_LAUNCH(k_roi_hits, grid, 256, s, a);
+            rt::d2h(hits + total, d_out, (size_t)chunk_total * 4, s);
+            rt::stream_sync(s);
+            rt::dfree(d_off); rt::dfree(d_out);
+        }
+        total += chunk_total;
+        rt::dfree(d_soff); rt::dfree(d_wl); rt::dfree(d_cnt); rt::dfree(d_null);
+    }
+    if (total > capacity) throw StatusError(LDBG_ERR_CAPACITY, "hit buffer too small: need " + std::to_string(total));
+}
 
 void Engine::launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks) {
     LDBG_LAUNCH(k_compact_paths, grid_for(n_strands * 64, 256, 4096), 256, graph->stream, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,

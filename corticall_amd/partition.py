@@ -1,0 +1,106 @@
+"""Partition — the reference's seed loop over the novel k-mers (J/commands/discover/call/Partition.java:57-219, without the
+optional k-mer / variant tables and with linkNovels = false, i.e. ContigStopper): every ROI k-mer that no earlier contig
+has claimed is walked, the ROI k-mers on the walk are marked with it (a longer walk takes a k-mer over), and the distinct
+contigs are written as FASTA.
+
+The walks do not depend on the marking, so all ROI k-mers are walked in ONE device batch; the order-dependent bookkeeping
+(`used` in ROI order, longest walk wins, reverse-complement de-duplication, TreeSet output order) is replayed on the host
+from the walk lengths and the per-walk ROI hits the device reports (ldbg_engine_walk_roi_hits)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from .traversal import BOTH, OR, ContigStopper, TraversalEngineFactory
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _revcomp(s):
+    return s.encode().translate(_COMP)[::-1].decode()
+
+
+def unpack_kmers(words, k):
+    """packed words u64[n, W] -> ASCII u8[n, k]"""
+    w = np.ascontiguousarray(words, dtype=np.uint64).reshape(len(words), -1)
+    W = w.shape[1]
+    out = np.empty((w.shape[0], k), dtype=np.uint8)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(k):
+        bit = 2 * (k - 1 - i)
+        out[:, i] = alpha[((w[:, W - 1 - (bit >> 6)] >> np.uint64(bit & 63)) & np.uint64(3)).astype(np.int64)]
+    return out
+
+
+class Partition:
+    def __init__(self, graph, rois, links=()):
+        self.GRAPH, self.ROIS, self.LINKS = graph, rois, list(links)
+
+    def execute(self):
+        """-> the FASTA text the reference prints"""
+        g, rois = self.GRAPH, self.ROIS
+        k = g.getKmerSize()
+        color = g.getColorForSampleName(rois.getSampleName(0))        # getTraversalColor :266-268
+        f = (TraversalEngineFactory(lib=g._lib).traversalColors(color).traversalDirection(BOTH).combinationOperator(OR)
+             .graph(g).rois(rois).stoppingRule(ContigStopper))
+        if self.LINKS:
+            f.links(*self.LINKS)
+        e = f.make()
+        n = rois.getNumRecords()
+        if n == 0:
+            return ""
+        words, _, _ = rois.records(0, n)
+        seeds = unpack_kmers(words, k)                                  # loadRois: TreeMap order = the ROI graph's order
+        arena, offs, wl = e.walk_batch_arrays(seeds)
+        idx, _, _ = g.find_batch(seeds, with_payload=False)
+        hit_off = np.zeros(n + 1, dtype=np.int64)
+        has_null = np.zeros(n, dtype=np.uint8)
+        hits = np.zeros(1, dtype=np.uint32)
+        st = e._d.ldbg_engine_walk_roi_hits(e._h, hit_off.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p), C.c_int64(0),
+                                            has_null.ctypes.data_as(C.c_void_p))
+        if st not in (0, 7):
+            e._lib.check(st)
+        hits = np.zeros(max(1, int(hit_off[n])), dtype=np.uint32)
+        e._lib.check(e._d.ldbg_engine_walk_roi_hits(e._h, hit_off.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p),
+                                                    C.c_int64(len(hits)), has_null.ctypes.data_as(C.c_void_p)))
+        raw = arena.tobytes()
+        seed_str = seeds.tobytes().decode()
+
+        def contig_of(i):
+            return raw[offs[i]:offs[i + 1]].decode() if wl[i] > 0 else seed_str[i * k:(i + 1) * k]
+
+        # the loop :98-184 — order matters: a k-mer claimed by an earlier walk is not walked itself
+        used = [None] * n
+        wlen = [int(x) if x > 0 else 1 for x in wl]
+        for i in range(n):
+            if used[i] is not None:
+                continue
+            if has_null[i] or (wl[i] == 0 and idx[i] < 0):
+                # countNovels / markUsedRois call TreeMap.containsKey(v.getCanonicalKmer()) with null for a vertex without a record
+                raise _native.JavaNullPointerException("Partition: a vertex without a record reached used.containsKey (seed %s)"
+                                                       % seed_str[i * k:(i + 1) * k])
+            mine = hits[hit_off[i]:hit_off[i + 1]] if wl[i] > 0 else (i,)
+            for r in mine:                                              # markUsedRois :238-257
+                r = int(r)
+                if used[r] is None or wlen[i] > wlen[used[r]]:
+                    used[r] = i
+        contigs = set()                                                 # :186-198
+        for i in range(n):
+            if used[i] is not None:
+                fw = contig_of(used[i])
+                if fw not in contigs and _revcomp(fw) not in contigs:
+                    contigs.add(fw)
+        out = []
+        for num, part in enumerate(sorted(contigs)):                    # TreeSet<String> order :200-214
+            km = np.frombuffer(part.encode(), dtype=np.uint8)
+            windows = np.lib.stride_tricks.sliding_window_view(km, k) if len(km) >= k else np.zeros((0, k), dtype=np.uint8)
+            if n > 2:
+                ridx, _, _ = rois.find_batch(np.ascontiguousarray(windows), with_payload=False)
+                num_novels = int((ridx >= 0).sum())
+            else:           # findRecord never finds anything in a graph of <= 2 records (Q1); the reference uses a map here
+                keys = {seed_str[j * k:(j + 1) * k] for j in range(n)}
+                num_novels = sum(1 for wdw in windows if min(wdw.tobytes().decode(), _revcomp(wdw.tobytes().decode())) in keys)
+            out.append(">partition%d len=%d numNovels=%d" % (num, len(part) - k + 1, num_novels))
+            out.append(part)
+        e.close()
+        return "\n".join(out) + ("\n" if out else "")

@@ -203,6 +203,13 @@ ldbg_status ldbg_engine_walk_batch_fetch(ldbg_engine* e, char* contig_arena, int
 ldbg_status ldbg_engine_walk_vertices(ldbg_engine* e, int64_t walk, int64_t capacity, int64_t* len,
                                       uint64_t* kmer_words, int64_t* rec, int32_t* copy_index, int32_t* index);
 
+/* Which ROI k-mers the walks of the last batch pass through (the engine must have been made with a ROI graph):
+ * what Partition.markUsedRois needs (J/commands/discover/call/Partition.java:238-257).  offsets[n+1] into hits (numbers
+ * of ROI records; order within a walk is arbitrary; empty walks have none); has_null[i] != 0: the dfs graph of seed i
+ * holds a vertex without a record (the reference's bookkeeping throws NullPointerException on those).  If hits is too
+ * small, LDBG_ERR_CAPACITY is returned and offsets[n] holds the required number. */
+ldbg_status ldbg_engine_walk_roi_hits(ldbg_engine* e, int64_t* offsets, uint32_t* hits, int64_t capacity, uint8_t* has_null);
+
 /* dfs(source, sinks...) for n sources                               TraversalEngine.java:64-106, 356-482
  * sources n × k ASCII; sinks as CSR over ASCII k-mers (sink_offsets[n+1] counts k-mers; may be NULL). */
 ldbg_status ldbg_engine_dfs_batch(ldbg_engine* e, const char* sources, int64_t n,

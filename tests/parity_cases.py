@@ -582,3 +582,63 @@ def case_big_link_stores(orc, lib, tmp):
         seeds = cs.all_kmers()[:40]
         compare_walks(cs, seeds, trav=[0], links=["a"], max_len=400)
         compare_dfs(cs, seeds[:10], trav=[0], stopper="ExplorationStopper", links=["a"], max_len=200)
+
+
+# ------------------------------------------------------------------ Partition (the seed loop around the walks)
+def partition_reference(orc, og, oroi, olinks, k):
+    """J/commands/discover/call/Partition.java:57-219 restated over the oracle engine, one seed at a time"""
+    color = og.color_for_sample_name(oroi.sample_name(0))
+    oe = orc.Engine(og, [color], links=olinks, rois=oroi, stopper="ContigStopper")
+    keys = [oroi.record_string(i).split()[0] for i in range(oroi.N)]
+    used = {ck: None for ck in keys}
+    for ck in keys:
+        if used[ck] is not None:
+            continue
+        contig, _ = oe.walk(ck)
+        w = [contig[j:j + k] for j in range(len(contig) - k + 1)] if contig else [ck]
+        canon = []
+        for sk in w:
+            assert og.find(sk)[0] >= 0, "vertex without a record: the reference throws here"
+            canon.append(orc.canonical(sk))
+        for c in canon:
+            if c in used and (used[c] is None or len(w) > len(used[c][0])):
+                used[c] = (w, contig if contig else ck)
+    contigs = set()
+    for ck in keys:
+        if used[ck] is not None:
+            fw = used[ck][1]
+            if fw not in contigs and orc.revcomp(fw) not in contigs:
+                contigs.add(fw)
+    out = []
+    for num, part in enumerate(sorted(contigs)):
+        nn = sum(1 for j in range(len(part) - k + 1) if orc.canonical(part[j:j + k]) in used)
+        out += [">partition%d len=%d numNovels=%d" % (num, len(part) - k + 1, nn), part]
+    return "\n".join(out) + ("\n" if out else "")
+
+
+def case_partition(orc, lib, tmp, k, seed, with_links):
+    from corticall_amd.partition import Partition
+    rng = random.Random(7000 + seed * 31 + k)
+    base = genome_with_repeats(rng, 1500, n_rep=5, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+    kid = list(base)
+    for _ in range(6):                                   # de novo mutations: child-only k-mers around them
+        p = rng.randrange(k, len(kid) - k)
+        kid[p] = rng.choice([b for b in "ACGT" if b != kid[p]])
+    kid = "".join(kid)
+    dad = mutate(rng, base, snv=0.01, indel=0.002)
+    reads = {"kid": [kid[i:i + 4 * k] for i in range(0, len(kid) - 4 * k, k)] + [kid[-4 * k:]]} if with_links else None
+    cs = Case(orc, tmp, lib, [("kid", [kid]), ("mom", [base]), ("dad", [dad])], k, link_samples=(["kid"] if with_links else []), reads=reads,
+              name="part%d_%d_%d" % (k, seed, int(with_links)))
+    parents = set()
+    for h in (base, dad):
+        parents |= {orc.canonical(h[i:i + k]) for i in range(len(h) - k + 1)}
+    novel = [kid[i:i + k] for i in range(len(kid) - k + 1) if orc.canonical(kid[i:i + k]) not in parents]
+    assert len(novel) > 3
+    roi_path = str(tmp / "roi.ctx")
+    orc.build_graph(roi_path, [("kid", novel)], k)
+    oroi, roi = orc.Graph(roi_path, tuned=True), CortexGraph(roi_path, lib=lib)
+    exp = partition_reference(orc, cs.og, oroi, [cs.olinks["kid"]] if with_links else [], k)
+    got = Partition(cs.g, roi, [cs.links["kid"]] if with_links else []).execute()
+    assert got == exp, (got, exp)
+    assert exp.count(">partition") >= 1
+    roi.close(); oroi.close()
