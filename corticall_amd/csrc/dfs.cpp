@@ -461,6 +461,17 @@ LDBG_KERNEL void k_gather_vertices(GraphView g, const uint64_t* keys, int64_t n,
     }
 }
 
+// edges, flags and neighbour index of a list of vertices (addSecondaryColors needs them for every vertex of a result)
+LDBG_KERNEL void k_gather_rows(GraphView g, const uint64_t* keys, int64_t n, uint8_t* edges, uint8_t* flags, uint32_t* nbr) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        const int64_t idx = (int64_t)(keys[i] >> 1) - 1;
+        const uint8_t* row = graph_row(g, idx);
+        for (int c = 0; c < g.C; c++) edges[i * g.C + c] = row[g.edges_off + c];
+        flags[i] = row[g.flags_off];
+        for (int q = 0; q < 8; q++) nbr[i * 8 + q] = graph_nbr(g, idx, q);
+    }
+}
+
 // ------------------------------------------------------------------ host: graph assembly from the event logs
 namespace {
 
@@ -513,6 +524,7 @@ struct HGraph {
         edges.push_back({s, t, color});
         if (indexed) { dir.insert(dir_key(s, t)); und.insert(und_key(s, t, color)); }
     }
+    bool contains_edge(int s, int t) { ensure_index(); return dir.count(dir_key(s, t)) != 0; }
     void add_edge(int s, int t, int color) {            // Graph.addEdge: refused when an equal CortexEdge is present
         ensure_index();
         if (!und.insert(und_key(s, t, color)).second) return;
@@ -656,7 +668,6 @@ void Engine::build_roi_bits() {
 
 DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets) {
     if (cfg.connect_all_neighbors) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: connectAllNeighbors is not supported on the device path");
-    if (cfg.n_secondary > 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: secondary colours are not supported on the device path");
     rt::set_device(graph->device);
     build_roi_bits();
     const int k = graph->hdr.k, W = graph->hdr.W;
@@ -916,6 +927,111 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         for (int t = 1; t < n_threads; t++) pool.emplace_back(shift, t);
         shift(0);
         for (auto& th : pool) th.join();
+    }
+    // ---- TraversalEngine.addSecondaryColors (:108-145): for every secondary colour that is not a traversal colour, the edges
+    // of that colour at every vertex of the combined graph, to neighbours looked up with findRecord (here: the neighbour index)
+    std::vector<int> sec_cols;
+    for (int c = 0; c < graph->hdr.C; c++) {
+        bool sec = false, trav = false;
+        for (int j = 0; j < cfg.n_secondary; j++) sec |= cfg.secondary_colors[j] == c;
+        for (int j = 0; j < cfg.n_traversal; j++) trav |= cfg.traversal_colors[j] == c;
+        if (sec && !trav) sec_cols.push_back(c);
+    }
+    if (!sec_cols.empty()) {
+        const int64_t base0 = (int64_t)out.gather_keys.size() - [&] { int64_t t = 0; for (auto& v : thread_keys) t += (int64_t)v.size(); return t; }();
+        const int64_t ngk = (int64_t)out.gather_keys.size() - base0;        // this chunk's keys
+        std::vector<uint8_t> redges((size_t)std::max<int64_t>(1, ngk) * C), rflags((size_t)std::max<int64_t>(1, ngk));
+        std::vector<uint32_t> rnbr((size_t)std::max<int64_t>(1, ngk) * 8);
+        if (ngk > 0) {
+            uint64_t* d_keys = (uint64_t*)tmp.get((size_t)ngk * 8);
+            uint8_t* d_e = (uint8_t*)tmp.get((size_t)ngk * C);
+            uint8_t* d_f = (uint8_t*)tmp.get((size_t)ngk);
+            uint32_t* d_n = (uint32_t*)tmp.get((size_t)ngk * 32);
+            rt::h2d(d_keys, out.gather_keys.data() + base0, (size_t)ngk * 8, s);
+            LDBG_LAUNCH(k_gather_rows, grid_of(ngk, 256, 4096), 256, s, graph->view, (const uint64_t*)d_keys, ngk, d_e, d_f, d_n);
+            rt::d2h(redges.data(), d_e, (size_t)ngk * C, s);
+            rt::d2h(rflags.data(), d_f, (size_t)ngk, s);
+            rt::d2h(rnbr.data(), d_n, (size_t)ngk * 32, s);
+            rt::stream_sync(s);
+        }
+        if (graph->hdr.k % 2 == 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: secondary colours with an even k-mer size are not supported");
+        std::vector<uint64_t> extra_keys;                   // vertices the secondary colours add (single thread: only visualisers ask for this)
+        for (int64_t i = 0; i < n; i++) {
+            DfsGraphHost& r = out.results[(size_t)(first + i)];
+            if (r.is_null) continue;
+            HGraph M;
+            std::vector<int64_t> slot_of;                   // gather slot per vertex of M
+            auto key_of = [&](const DfsVertex& o) { VKey kv; kv.id = ((uint64_t)(o.rec + 1) << 1) | o.flip; kv.copy = o.copy; kv.index = o.index; return kv; };
+            for (auto& o : r.verts) {
+                if (o.rec < 0) throw StatusError(LDBG_ERR_NULLPOINTER, "addSecondaryColors: findRecord of a vertex returned null (seed " + std::to_string(first + i) + ")");
+                M.add_vertex_new(key_of(o)); slot_of.push_back(o.slot);
+            }
+            for (auto& ed : r.edges) M.add_edge_new(ed.src, ed.dst, ed.color);
+            const size_t nv0 = r.verts.size();
+            for (int c : sec_cols) {
+                HGraph g2;
+                std::vector<int64_t> g2_slot;
+                auto g2_add = [&](const VKey& kv, int64_t slot) {
+                    const size_t before = g2.verts.size();
+                    const int id = g2.add_vertex(kv);
+                    if (g2.verts.size() > before) g2_slot.push_back(slot);
+                    return id;
+                };
+                for (size_t v = 0; v < nv0; v++) {
+                    const DfsVertex& o = r.verts[v];
+                    const int64_t sl = o.slot - base0;
+                    const bool fj = cfg.strict_java_flip && (rflags[(size_t)sl] & LDBG_ROW_HASH_COLLISION) ? false : o.flip != 0;
+                    const uint32_t eb = redges[(size_t)sl * C + c], lo = eb & 0xf, hi = eb >> 4;
+                    const int vi = g2_add(key_of(o), o.slot);
+                    auto neighbour = [&](bool fwd, unsigned b) {
+                        const uint32_t ent = rnbr[(size_t)sl * 8 + nbr_slot(fj, fwd, b)];
+                        if ((ent & 0x7FFFFFFFu) == 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "addSecondaryColors: a neighbour without a record is not supported yet");
+                        VKey kv;
+                        const bool nflip = (((ent >> 31) & 1u) != 0) != fj;
+                        kv.id = ((uint64_t)(ent & 0x7FFFFFFFu) << 1) | (nflip ? 1ull : 0ull);
+                        kv.copy = 0; kv.index = 0;
+                        return kv;
+                    };
+                    // in-edges (:121-129): record orientation -> bits 3-i of the high nibble, base i; flipped -> complemented out-edges
+                    for (unsigned q = 0; q < 4; q++) {
+                        const bool have = !fj ? ((hi >> (3 - q)) & 1u) != 0 : ((lo >> q) & 1u) != 0;
+                        if (!have) continue;
+                        const unsigned b = !fj ? q : 3u - q;
+                        const VKey pk = neighbour(false, b);
+                        const int pi = g2_add(pk, -1);
+                        if (!g2.contains_edge(pi, vi)) g2.add_edge(pi, vi, c);
+                    }
+                    for (unsigned q = 0; q < 4; q++) {       // out-edges (:131-139)
+                        const bool have = !fj ? ((lo >> q) & 1u) != 0 : ((hi >> (3 - q)) & 1u) != 0;
+                        if (!have) continue;
+                        const unsigned b = !fj ? q : 3u - q;
+                        const VKey nk = neighbour(true, b);
+                        const int ni = g2_add(nk, -1);
+                        if (!g2.contains_edge(vi, ni)) g2.add_edge(vi, ni, c);
+                    }
+                }
+                // Graphs.addGraph(m, g2)
+                std::vector<int> map(g2.verts.size());
+                for (size_t j = 0; j < g2.verts.size(); j++) {
+                    const size_t before = M.verts.size();
+                    map[j] = M.add_vertex(g2.verts[j]);
+                    if (M.verts.size() > before) {
+                        int64_t sl = g2_slot[j];
+                        if (sl < 0) { sl = (int64_t)out.gather_keys.size() + (int64_t)extra_keys.size(); extra_keys.push_back(g2.verts[j].id); }
+                        slot_of.push_back(sl);
+                    }
+                }
+                for (auto& ed : g2.edges) M.add_edge(map[ed.src], map[ed.dst], ed.color);
+            }
+            r.verts.resize(M.verts.size());
+            for (size_t v = nv0; v < M.verts.size(); v++) {
+                DfsVertex& o = r.verts[v];
+                const VKey& kv = M.verts[v];
+                o.rec = (int64_t)(kv.id >> 1) - 1; o.flip = (uint8_t)(kv.id & 1ull); o.copy = kv.copy; o.index = kv.index; o.slot = slot_of[v];
+            }
+            r.edges = std::move(M.edges);
+        }
+        out.gather_keys.insert(out.gather_keys.end(), extra_keys.begin(), extra_keys.end());
     }
     if (want_times) fprintf(stderr, "[ldbg] dfs host: slot renumbering %.1f ms\n", ms_since(t_phase));
     return true;

@@ -405,10 +405,10 @@ def case_hash_collision(orc, lib, tmp):
 
 
 # ------------------------------------------------------------------ dfs with stopping rules vs oracle
-def dfs_engines(case, trav, stopper, links=(), rois=None, join=(), recruit=(), op=OR, direction=BOTH, max_len=75000):
+def dfs_engines(case, trav, stopper, links=(), rois=None, join=(), recruit=(), secondary=(), op=OR, direction=BOTH, max_len=75000):
     """rois: (oracle graph, product graph) or None"""
     oe = case.orc.Engine(case.og, trav, links=[case.olinks[s] for s in links], rois=rois[0] if rois else None,
-                         joining_colors=join, recruitment_colors=recruit, op_and=(op == AND), direction=direction,
+                         joining_colors=join, recruitment_colors=recruit, secondary_colors=secondary, op_and=(op == AND), direction=direction,
                          max_length=max_len, stopper=stopper)
     f = (TraversalEngineFactory(lib=case.lib).traversalColors(*trav).graph(case.g).combinationOperator(op)
          .traversalDirection(direction).maxBranchLength(max_len).stoppingRule(stopper))
@@ -416,6 +416,8 @@ def dfs_engines(case, trav, stopper, links=(), rois=None, join=(), recruit=(), o
         f.joiningColors(*join)
     if recruit:
         f.recruitmentColors(*recruit)
+    if secondary:
+        f.secondaryColors(*secondary)
     if rois:
         f.rois(rois[1])
     if links:
@@ -535,6 +537,9 @@ def case_dfs_rules(orc, lib, tmp, k, seed, with_links):
     compare_dfs(cs, seeds, trav=[0], stopper="NovelPartitionStopper", links=L, max_len=ML)              # no ROI graph: the reference throws
     compare_dfs(cs, seeds, trav=[0], stopper="BubbleOpeningStopper", links=L, max_len=ML, join=[1])     # no ROI graph: NullPointerException
     compare_dfs(cs, seeds, trav=[0], stopper="ContigStopper", links=L, max_len=ML)
+    if k % 2:       # addSecondaryColors (the visualiser's configuration): the other colours' edges at every vertex
+        compare_dfs(cs, seeds, trav=[0], stopper="ExplorationStopper", links=L, max_len=ML, secondary=[1, 2])
+        compare_dfs(cs, seeds, trav=[0, 2], stopper="ContigStopper", links=L, max_len=ML, secondary=[0, 1], op=AND)
     for g in rois:
         g.close()
 
