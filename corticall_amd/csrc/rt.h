@@ -131,7 +131,11 @@ inline void h2d(void* d, const void* h, size_t n, stream_t) { if (n) memcpy(d, h
 inline void d2h(void* h, const void* d, size_t n, stream_t) { if (n) memcpy(h, d, n); }
 inline void d2d(void* d, const void* s, size_t n, stream_t) { if (n) memmove(d, s, n); }
 inline void dmemset(void* d, int v, size_t n, stream_t) { if (n) memset(d, v, n); }
-inline void mem_info(size_t* free_b, size_t* total_b) { *free_b = (size_t)2 << 30; *total_b = (size_t)2 << 30; }
+inline void mem_info(size_t* free_b, size_t* total_b) {      // LDBG_HOSTSIM_MEM_MB: pretend to be a small device (tests of the batch-splitting paths)
+    size_t mb = 2048;
+    if (const char* ev = getenv("LDBG_HOSTSIM_MEM_MB")) mb = (size_t)atoll(ev);
+    *free_b = mb << 20; *total_b = mb << 20;
+}
 struct Event {
     void record(stream_t) {}
     static float elapsed_ms(Event&, Event&) { return 0.0f; }
