@@ -73,7 +73,6 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
     ls.age = st.ls_age; ls.n_new = st.ls_n_new;
     ls.overflow = false;
     Cursor cu;
-    cu.prof = nullptr;
     cu.cur = st.cur; cu.first = st.first != 0; cu.status = ST_OK; cu.epoch = 1;
     cu.has = fwd ? st.has_next != 0 : st.has_prev != 0;
     if (!cu.has) { st.status = ST_NULLPTR; return; }   // target vanished after the re-seek: NPE in the reference

@@ -354,7 +354,7 @@ LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64
     st.fwd = (s & 1) != 0;
     st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false; st.quirk = false;
     st.pw.cur = nullptr; st.pw.n = 0; st.pw.nblk = 0;
-    st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true; st.cu.epoch = 0; st.cu.prof = nullptr;
+    st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true; st.cu.epoch = 0;
     ls_clear(ls);
     L.depth = 0;
     L.sink_lo = a.sink_off ? a.sink_off[s >> 1] : 0;

@@ -440,14 +440,7 @@ LDBG_HOSTDEV bool ls_next_choice(const LinksView& L, LinkStoreDev& s, unsigned* 
 }
 
 // ---- cursor (TraversalEngine.seek / next / previous, TraversalEngine.java:241-339, 518-597)
-struct StepProf { unsigned long long t_links, t_child, t_choice, n_links, n_choice; };
-#if !defined(LDBG_HOSTSIM)
-#define LDBG_NOW() __builtin_amdgcn_s_memrealtime()
-#else
-#define LDBG_NOW() 0ull
-#endif
 struct Cursor {
-    StepProf* prof;     // diagnostics only (nullptr in normal runs)
     Node cur;
     Node nxt;           // the vertex hasNext()/hasPrevious() refers to, looked up one step ahead
     bool has;
@@ -498,7 +491,6 @@ struct StepPre {
 // LinkStore code is then not even compiled into the kernel.
 template <int W, bool PRE = false>
 LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd, const StepPre* pre = nullptr) {
-    unsigned long long p0 = cu.prof ? LDBG_NOW() : 0ull;
     const bool links_done = PRE;
     if (cu.first) {
         cu.first = false;                              // seek(cur) recomputes the same state; then
@@ -506,7 +498,6 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
     }
     if constexpr (!PRE) cursor_add_links<W>(e, s, cu.nxt, fwd);         // updateLinkStore :570-597
     (void)links_done;
-    if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_links += p1 - p0; cu.prof->n_links += (cu.nxt.lflags & e.link_flag_mask) ? 1 : 0; p0 = p1; }
     Node t = cu.nxt;
     cu.cur = t;
     if (t.npe) cu.status = ST_NULLPTR;
@@ -518,7 +509,6 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
         if (PRE && pre->has_child) x = pre->child;
         else node_child_located(e, vt, t, fwd, lowbit4(m), x);
         const uint64_t ex = x.idx >= 0 ? x.vent : 0ull;
-        if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_child += p1 - p0; p0 = p1; }
         if (!vt_seen_e(ex, cu.epoch) || s.n > 0) {      // :262
             if (x.idx >= 0 && !vt_seen_e(ex, cu.epoch)) {                // seen.add(nextKmer)
                 node_store(vt, x, vt_with_seen(ex, cu.epoch));
@@ -537,7 +527,6 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
             if (mb >= 0) { node_child_located(e, vt, t, fwd, (unsigned)mb, cu.nxt); has = true; }
         }
         ls_increment_ages(s);                           // :271
-        if (cu.prof) { unsigned long long p1 = LDBG_NOW(); cu.prof->t_choice += p1 - p0; cu.prof->n_choice++; p0 = p1; }
     }
     cu.has = has;
 #ifdef LDBG_HOSTSIM

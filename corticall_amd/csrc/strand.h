@@ -38,7 +38,6 @@ struct WalkArgs {
     uint32_t ecap;
     unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
-    StepProf* st_prof;              // diagnostics: [n_strands] time split of the cursor step
 };
 #define LDBG_VT_INITIAL 4096u
 #ifndef LDBG_LS_FAST
@@ -123,7 +122,6 @@ LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls,
     st.status = ST_OK; st.iters = 0; st.gV = 0; st.branch_null = false; st.quirk = false;
     st.pw.cur = nullptr; st.pw.n = 0; st.pw.nblk = 0;
     st.cu.has = false; st.cu.status = ST_OK; st.cu.first = true; st.cu.epoch = 1;
-    st.cu.prof = a.st_prof ? a.st_prof + s : nullptr;
     ls_clear(ls);
     if (!vt_alloc(a, st.vt, a.vcap_init < a.vcap_max ? a.vcap_init : a.vcap_max)) { st.status = ST_POOL_FULL; return false; }
     const uint64_t* sw = a.seeds + (s >> 1) * W;

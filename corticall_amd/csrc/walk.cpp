@@ -547,7 +547,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     if (const char* ev = getenv("LDBG_VT_INITIAL")) a.vcap_init = std::max<uint32_t>(64u, next_pow2((uint64_t)atoll(ev)));   // tuning knob
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
 
-    a.wg_times = nullptr; a.st_times = nullptr; a.st_prof = nullptr;
+    a.wg_times = nullptr; a.st_times = nullptr;
     const bool want_times = getenv("LDBG_WG_TIMES") != nullptr;
     rt::Event e0, e1;
     e0.record(s);
@@ -565,7 +565,6 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     if (want_times) {
         a.wg_times = (unsigned long long*)rt::dmalloc((size_t)grid * 16); rt::dmemset(a.wg_times, 0, (size_t)grid * 16, s);
         a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
-        a.st_prof = (StepProf*)rt::dmalloc((size_t)ns * sizeof(StepProf)); rt::dmemset(a.st_prof, 0, (size_t)ns * sizeof(StepProf), s);
     }
 #define LDBG_WALK_CASE(WW) \
     if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, a); \
@@ -621,15 +620,6 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         std::vector<int64_t> order(ns);
         for (int64_t i = 0; i < ns; i++) order[i] = i;
         std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return tt[2 * x + 1] - tt[2 * x] > tt[2 * y + 1] - tt[2 * y]; });
-        std::vector<StepProf> pr(ns);
-        rt::d2h(pr.data(), a.st_prof, (size_t)ns * sizeof(StepProf), s);
-        rt::stream_sync(s);
-        rt::dfree(a.st_prof);
-        for (int r = 0; r < 3 && r < ns; r++) {
-            int64_t i = order[r];
-            fprintf(stderr, "[ldbg] prof strand %lld: links %.1f ms (%llu flagged), child+locate %.1f ms, junction choice %.1f ms (%llu)\n", (long long)i,
-                    pr[i].t_links / 1e5, pr[i].n_links, pr[i].t_child / 1e5, pr[i].t_choice / 1e5, pr[i].n_choice);
-        }
         for (int r = 0; r < 12 && r < ns; r++) {
             int64_t i = order[r];
             double ms = (tt[2 * i + 1] - tt[2 * i]) / 1e5;
