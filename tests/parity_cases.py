@@ -647,3 +647,71 @@ def case_partition(orc, lib, tmp, k, seed, with_links):
     assert got == exp, (got, exp)
     assert exp.count(">partition") >= 1
     roi.close(); oroi.close()
+
+
+# ------------------------------------------------------------------ link file formats (L4): .ctp.gz versions 2, 3 and 4
+def _write_ctp(path, version, k, records, two_colours=False):
+    """records: [(kmer, [(F|R, num_kmers, junctions, [cov per colour])...])] as McCortex / IndexLinks would write them"""
+    import gzip
+    import json
+    ncol = 2 if two_colours else 1
+    cols = [{"colour": c, "sample": "s%d" % c, "total_sequence": 1000 + c, "cleaned_tips": bool(c)} for c in range(ncol)]
+    nlinks = sum(len(js) for _, js in records)
+    if version == 2:
+        hdr = {"format_version" if two_colours else "formatVersion": 2, "ncols": ncol, "kmer_size": k, "num_kmers_in_graph": 77,
+               "num_kmers_with_paths": len(records), "num_paths": nlinks, "path_bytes": 99, "colours": cols}
+    else:
+        hdr = {"file_format": "ctp", "formatVersion": version,
+               "graph": {"num_colours": ncol, "kmer_size": k, "num_kmers_in_graph": 77, "colours": cols},
+               "paths": {"num_kmers_with_paths": len(records), "num_paths": nlinks, "path_bytes": 99}}
+    text = json.dumps(hdr, indent=2).replace("{\n", "{\n", 1)
+    lines = ["{"] + text.split("\n")[1:-1] + ["}", "", "# comment line", "# kmer num_links", ""]
+    for kmer, js in records:
+        lines.append("%s %d" % (kmer, len(js)))
+        for orient, nk, junc, cov in js:
+            covs = ",".join(str(c) for c in cov)
+            if version == 4:
+                lines.append("%s %d %s %s" % (orient, len(junc), covs, junc))
+            else:
+                lines.append("%s %d %d %s %s" % (orient, nk, len(junc), covs, junc))
+    with gzip.open(path, "wt") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def case_link_formats(orc, lib, tmp):
+    """the three header dialects (CortexLinksIterable.java:69-123) and record layouts (:172-226): header fields, record
+    lookup in either orientation, junction records in the reference's HashSet order — product vs oracle, then a walk"""
+    rng = random.Random(77)
+    k = 7
+    g1 = rand_seq(rng, 140)
+    cs = Case(orc, tmp, lib, [("s0", [g1]), ("s1", [mutate(rng, g1, snv=0.03)])], k, name="lf")
+    kmers = cs.all_kmers()
+    for version in (2, 3, 4):
+        for two in (False, True):
+            recs = []
+            for km in rng.sample(kmers, 12):
+                js = []
+                for _ in range(rng.randint(1, 4)):
+                    junc = rand_seq(rng, rng.randint(1, 9))
+                    js.append((rng.choice("FR"), rng.randint(2, 30), junc, [rng.randint(1, 9) for _ in range(2 if two else 1)]))
+                recs.append((km if rng.random() < 0.5 else orc.revcomp(km), js))
+            recs.sort(key=lambda r: orc.canonical(r[0]))
+            p = str(tmp / ("v%d_%d.ctp.gz" % (version, int(two))))
+            _write_ctp(p, version, k, recs, two)
+            ol, l = orc.Links(p), CortexLinks(p, cs.g)
+            assert (l.version, l.numColors, l.kmerSize, l.numKmersInGraph, l.numKmersWithLinks, l.numLinks) == (version, 2 if two else 1, k, 77, len(recs), sum(len(j) for _, j in recs))
+            assert l.getSampleNameForColor(0) == "s0"
+            exp = dict(ol.records())
+            for km, js in recs:
+                cov_of = {(o, j): c for o, _, j, c in js}
+                for q in (km, orc.revcomp(km)):
+                    found, got = l.get(q)
+                    assert found
+                    # junction records in the reference's HashSet iteration order, with their coverages
+                    assert [(x[0], x[3]) for x in got] == [(j[0] == "F", j[1]) for j in exp[km]], (version, km, got, exp[km])
+                    for x in got:
+                        assert x[1] == len(x[3]) and x[2] == cov_of[("F" if x[0] else "R", x[3])]
+            assert not l.containsKey("A" * k) or "A" * k in {orc.canonical(r[0]) for r in recs}
+            # and the links drive a walk identically
+            cs.olinks["s0"], cs.links["s0"] = ol, l
+            compare_walks(cs, kmers[:25], trav=[0], links=["s0"], max_len=60)
