@@ -97,7 +97,7 @@ public:
     void find_dev(const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const;
     int color_for_sample_name(const std::string& name) const;
     // link sets bound to this graph get a flag bit in the probe rows (at most 8)
-    mutable int next_link_slot = 0;
+    mutable uint32_t link_slots = 0;                 // bits of the flag byte in use
     uint8_t* probe_mutable() const { return (uint8_t*)d_probe_; }
     void* d_nbrg = nullptr;   // shard of a partitioned table: global neighbour index [N][8] u64 (shard.cpp)
 

@@ -143,13 +143,16 @@ std::vector<std::string> split_fields(const std::string& s, bool commas) {
 
 // sets bit `slot` of the link-flags byte of every graph record that has a link record in this set
 template <int W>
-LDBG_KERNEL void k_set_link_flags(GraphView g, uint8_t* probe, const uint64_t* keys, int64_t M, int slot) {
+LDBG_KERNEL void k_set_link_flags(GraphView g, uint8_t* probe, const uint64_t* keys, int64_t M, int slot, int clear = 0) {
     for (int64_t i = global_tid(); i < M; i += global_nthreads()) {
         Kmer<W> q;
 #pragma unroll
         for (int w = 0; w < W; w++) q.w[w] = keys[i * W + w];
         int64_t idx = graph_find_canonical<W>(g, q);
-        if (idx >= 0) probe[(size_t)idx * (size_t)g.stride + g.flags_off] |= (uint8_t)(1u << slot);
+        if (idx >= 0) {
+            uint8_t* f = probe + (size_t)idx * (size_t)g.stride + g.flags_off;
+            *f = clear ? (uint8_t)(*f & ~(1u << slot)) : (uint8_t)(*f | (1u << slot));
+        }
     }
 }
 
@@ -169,6 +172,9 @@ LDBG_KERNEL void k_link_rec_of(GraphView g, const uint64_t* keys, int64_t M, uin
 }
 
 Links::Links(const std::string& path, const Graph& g) : device(g.device) {
+    // CortexLinks.initialize (CortexLinks.java:16-25): an ".idx" file next to the links file selects the random-access back-end
+    // (BGZF is a series of gzip members, so the whole file is read the same way; the index itself is not needed in HBM)
+    const bool indexed = [&] { FILE* f = fopen((path + ".idx").c_str(), "rb"); if (f) fclose(f); return f != nullptr; }();
     std::string text = gunzip_file(path);
     // header = lines from "{" to "}" (CortexLinksIterable.java:58-67)
     size_t pos = 0;
@@ -240,10 +246,21 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
             int off = version == 4 ? 2 : 3;
             if ((int)f.size() < off + num_colors + 1) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record");
             j.is_fw = f[0] == "F";
-            j.num_kmers = version == 4 ? -1 : atoi(f[1].c_str());
-            j.num_junctions = version == 4 ? atoi(f[1].c_str()) : atoi(f[2].c_str());
-            for (int c = 0; c < num_colors; c++) j.cov.push_back(atoi(f[off + c].c_str()));
-            j.junctions = f[off + num_colors];
+            if (indexed && version != 4) throw StatusError(LDBG_ERR_CORTEXJDK, "indexed link files are version 4 (IndexLinks.java:62-135)");
+            if (indexed) {
+                // CortexLinksRandomAccess reads records through CortexLinksRecord(byte[]) (CortexLinksRecord.java:17-43):
+                // "orientation x coverages junctions", numKmers := x, numJunctions := junctions.length() — quirk Q11: another
+                // hashCode, hence another HashSet order of the junction records than the un-indexed back-end
+                j.num_kmers = atoi(f[1].c_str());
+                for (int c = 0; c < num_colors; c++) j.cov.push_back(atoi(f[2 + c].c_str()));
+                j.junctions = f[2 + num_colors];
+                j.num_junctions = (int)j.junctions.size();
+            } else {
+                j.num_kmers = version == 4 ? -1 : atoi(f[1].c_str());
+                j.num_junctions = version == 4 ? atoi(f[1].c_str()) : atoi(f[2].c_str());
+                for (int c = 0; c < num_colors; c++) j.cov.push_back(atoi(f[off + c].c_str()));
+                j.junctions = f[off + num_colors];
+            }
             bool dup = false;
             for (auto& o : rec.juncs) dup |= junction_eq(o, j);
             if (!dup) rec.juncs.push_back(j);
@@ -269,8 +286,19 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
         record_is_canonical.push_back(w == kv.first ? 1 : 0);
     }
     // claim a flag bit in the graph's probe rows and set it on every record that has links here
-    if (g.next_link_slot >= 6) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than 6 link sets bound to one graph");
-    slot = g.next_link_slot++;
+    int free_slot = -1;
+    for (int b = 0; b < 6 && free_slot < 0; b++) if (!((g.link_slots >> b) & 1u)) free_slot = b;
+    if (free_slot < 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than 6 link sets bound to one graph at the same time");
+    slot = free_slot;
+    g.link_slots |= 1u << slot;
+    graph_ = &g;
+    mark_records(false);
+}
+
+// set (or, when the link set is closed, clear) this set's bit on the records it has links for
+void Links::mark_records(bool clear) {
+    const Graph& g = *graph_;
+    const int W = g.hdr.W;
     const int64_t M = (int64_t)records.size();
     if (M > 0) {
         rt::set_device(device);
@@ -280,14 +308,22 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
         void* d_keys = rt::dmalloc(keys.size() * 8);
         rt::h2d(d_keys, keys.data(), keys.size() * 8, g.stream);
         const int grid = (int)std::min<int64_t>((M + 255) / 256, 2048);
+        const int cl = clear ? 1 : 0;
         switch (W) {
-            case 1: LDBG_LAUNCH(k_set_link_flags<1>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot); break;
-            case 2: LDBG_LAUNCH(k_set_link_flags<2>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot); break;
-            case 3: LDBG_LAUNCH(k_set_link_flags<3>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot); break;
-            default: LDBG_LAUNCH(k_set_link_flags<4>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot); break;
+            case 1: LDBG_LAUNCH(k_set_link_flags<1>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot, cl); break;
+            case 2: LDBG_LAUNCH(k_set_link_flags<2>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot, cl); break;
+            case 3: LDBG_LAUNCH(k_set_link_flags<3>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot, cl); break;
+            default: LDBG_LAUNCH(k_set_link_flags<4>, grid, 256, g.stream, g.view, g.probe_mutable(), (const uint64_t*)d_keys, M, slot, cl); break;
         }
         rt::stream_sync(g.stream);
         rt::dfree(d_keys);
+    }
+}
+
+Links::~Links() {
+    if (graph_ && slot >= 0) {
+        try { mark_records(true); } catch (...) {}
+        graph_->link_slots &= ~(1u << slot);
     }
 }
 

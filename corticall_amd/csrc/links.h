@@ -47,6 +47,7 @@ struct HostLinksRecord {
 class Links {
 public:
     Links(const std::string& path, const Graph& g);
+    ~Links();                                        // gives the flag bit back (the graph must still be open)
     int version = 0, num_colors = 0, k = 0;
     int64_t num_kmers_in_graph = 0, num_kmers_with_links = 0, num_links = 0, link_bytes = 0;
     std::vector<std::string> sample_names;
@@ -56,6 +57,9 @@ public:
     int device = 0;
     int slot = -1;                                   // bit of the probe rows' link-flags byte
     const HostLinksRecord* get(const std::string& kmer_ascii) const;   // containsKey / get
+private:
+    const Graph* graph_ = nullptr;
+    void mark_records(bool clear);
 };
 
 // the link sets a traversal may use, merged into one device table

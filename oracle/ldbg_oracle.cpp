@@ -593,6 +593,8 @@ static std::vector<std::string> split_ws(const std::string& s, const char* extra
 }
 
 CortexLinks::CortexLinks(const std::string& path) {
+    // CortexLinks.initialize :16-25: an ".idx" file next to the links file selects the random-access back-end
+    const bool indexed = [&] { FILE* f = fopen((path + ".idx").c_str(), "rb"); if (f) fclose(f); return f != nullptr; }();
     std::string text = read_gz_all(path);
     std::vector<std::string> lines;
     { std::string l; std::istringstream is(text); while (std::getline(is, l)) lines.push_back(l); }
@@ -632,11 +634,21 @@ CortexLinks::CortexLinks(const std::string& path) {
             auto f = split_ws(lines[li++], ",");
             JunctionsRecord j;
             j.is_fw = f[0] == "F";
+            if (indexed) {
+                // CortexLinksRandomAccess -> CortexLinksRecord(byte[]) :17-43: "orientation x coverages junctions" with
+                // numKmers := x and numJunctions := junctions.length() (quirk Q11: another hashCode, another set order)
+                if (version != 4) throw CortexJDKException("indexed link files are version 4 (IndexLinks.java:62-135)");
+                j.num_kmers = std::stoi(f[1]);
+                for (int c = 0; c < num_colors; c++) j.coverages.push_back(std::stoi(f[2 + c]));
+                j.junctions = f[2 + num_colors];
+                j.num_junctions = (int)j.junctions.size();
+            } else {
             j.num_kmers = version == 4 ? -1 : std::stoi(f[1]);
             j.num_junctions = version == 4 ? std::stoi(f[1]) : std::stoi(f[2]);
             int off = version == 4 ? 2 : 3;
             for (int c = 0; c < num_colors; c++) j.coverages.push_back(std::stoi(f[off + c]));
             j.junctions = f[off + num_colors];
+            }
             if (std::find(rec.cjs_insertion.begin(), rec.cjs_insertion.end(), j) == rec.cjs_insertion.end())
                 rec.cjs_insertion.push_back(j);
         }

@@ -715,3 +715,18 @@ def case_link_formats(orc, lib, tmp):
             # and the links drive a walk identically
             cs.olinks["s0"], cs.links["s0"] = ol, l
             compare_walks(cs, kmers[:25], trav=[0], links=["s0"], max_len=60)
+            if version == 4:
+                # the same file with an index next to it: CortexLinks picks the random-access back-end, whose records hash
+                # differently (quirk Q11) -> possibly another order of the junction records, same content
+                open(p + ".idx", "wb").write(b"LNKIDX")
+                oli, li = orc.Links(p), CortexLinks(p, cs.g)
+                expi = dict(oli.records())
+                for km, js in recs:
+                    found, got = li.get(km)
+                    assert found and [(x[0], x[3]) for x in got] == [(j[0] == "F", j[1]) for j in expi[km]]
+                    assert sorted((x[0], x[3]) for x in got) == sorted((j[0] == "F", j[1]) for j in exp[km])
+                cs.olinks["s0"], cs.links["s0"] = oli, li
+                compare_walks(cs, kmers[:25], trav=[0], links=["s0"], max_len=60)
+                os.remove(p + ".idx")
+                li.close()
+            l.close()           # gives the graph's flag bit back: more than 6 link sets pass through this graph
