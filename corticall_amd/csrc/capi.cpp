@@ -11,6 +11,7 @@
 using namespace ldbg;
 
 namespace ldbg {
+int64_t sort_ctx_file(const std::string& in_path, const std::string& out_path, int device);
 void profile_reset_all();
 bool profile_get(const char* family, double* ms, int64_t* n);
 }  // namespace ldbg
@@ -65,6 +66,10 @@ ldbg_status ldbg_kmer_decode(const uint64_t* words, int k, char* ascii_out) {
         words_to_ascii(words, k, (k + 31) / 32, ascii_out);
         ascii_out[k] = 0;
     });
+}
+
+ldbg_status ldbg_sort_ctx(const char* in_path, const char* out_path, int device, int64_t* num_records) {
+    return guard([&] { const int64_t n = sort_ctx_file(in_path, out_path, device); if (num_records) *num_records = n; });
 }
 
 // ---- graph

@@ -104,3 +104,16 @@ class Partition:
             out.append(part)
         e.close()
         return "\n".join(out) + ("\n" if out else "")
+
+
+class Sort:
+    """J/commands/utils/Sort.java:20-49 — the records of a Cortex graph in k-mer order (device radix sort, ldbg_sort_ctx)"""
+
+    def __init__(self, cortex_graph_path, out_path, device=0, lib=None):
+        self.path, self.out, self.device = str(cortex_graph_path), str(out_path), device
+        self._lib = lib or _native.default_lib()
+
+    def execute(self):
+        n = C.c_int64()
+        self._lib.check(self._lib.dll.ldbg_sort_ctx(self.path.encode(), self.out.encode(), int(self.device), C.byref(n)))
+        return n.value

@@ -56,6 +56,11 @@ ldbg_status ldbg_device_count(int* count);
 ldbg_status ldbg_kmer_encode(const char* ascii, int k, uint64_t* words_out);
 ldbg_status ldbg_kmer_decode(const uint64_t* words, int k, char* ascii_out /* k bytes + NUL */);
 
+/* Sort (J/commands/utils/Sort.java:20-49): writes the records of in_path in k-mer order (CortexRecord.compareTo :210-212,
+ * stable like Arrays.sort) under the unchanged header — produces the sorted table ldbg_graph_open requires.  The order is
+ * computed by a radix sort on the device. */
+ldbg_status ldbg_sort_ctx(const char* in_path, const char* out_path, int device, int64_t* num_records);
+
 /* ------------------------------------------------------------------ graph: G1-G3
  * new CortexGraph(path)              J/utils/io/graph/cortex/CortexGraph.java:40-48, 66-168
  * The file is parsed on the host, streamed to the device, verified strictly ascending

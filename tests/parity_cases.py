@@ -730,3 +730,36 @@ def case_link_formats(orc, lib, tmp):
                 os.remove(p + ".idx")
                 li.close()
             l.close()           # gives the graph's flag bit back: more than 6 link sets pass through this graph
+
+
+def case_sort(orc, lib, tmp):
+    """Sort.java:20-49: Arrays.sort with CortexRecord.compareTo (k-mer strings) is a stable merge sort — shuffled files, with
+    duplicate k-mers kept in input order, must come back byte for byte as Python's stable sort on the k-mer strings gives"""
+    from corticall_amd.distributed import ctx_header
+    from corticall_amd.partition import Sort, unpack_kmers
+    rng = random.Random(31)
+    for k, ncol, n_bp in ((5, 1, 60), (31, 2, 3000), (47, 3, 5000), (65, 1, 2000)):
+        src = str(tmp / ("sorted%d.ctx" % k))
+        orc.build_graph(src, [("s%d" % c, [rand_seq(rng, n_bp)]) for c in range(ncol)], k)
+        raw = np.fromfile(src, dtype=np.uint8)
+        h = ctx_header(raw)
+        rec = 8 * h["W"] + 5 * h["C"]
+        body = raw[h["data_offset"]:].reshape(-1, rec)
+        dup = body[rng.sample(range(len(body)), min(7, len(body)))].copy()
+        dup[:, -1] ^= 0x5A                                   # same k-mers, different payload: stability is visible
+        shuffled = np.concatenate([body, dup])[np.random.default_rng(k).permutation(len(body) + len(dup))]
+        unsorted = str(tmp / ("unsorted%d.ctx" % k))
+        np.concatenate([raw[:h["data_offset"]], shuffled.reshape(-1)]).tofile(unsorted)
+        out = str(tmp / ("resorted%d.ctx" % k))
+        assert Sort(unsorted, out, lib=lib).execute() == len(shuffled)
+        words = np.ascontiguousarray(shuffled[:, :8 * h["W"]]).view("<u8").reshape(-1, h["W"])
+        kmers = [x.tobytes().decode() for x in unpack_kmers(words, k)]
+        order = sorted(range(len(kmers)), key=lambda i: kmers[i])          # stable, like Arrays.sort on objects
+        expected = np.concatenate([raw[:h["data_offset"]], shuffled[order].reshape(-1)])
+        assert (np.fromfile(out, dtype=np.uint8) == expected).all()
+        if k != 5:      # and without the duplicates the result loads as a graph again
+            clean = str(tmp / ("clean%d.ctx" % k))
+            np.concatenate([raw[:h["data_offset"]], body[np.random.default_rng(1).permutation(len(body))].reshape(-1)]).tofile(clean)
+            Sort(clean, out, lib=lib).execute()
+            assert (np.fromfile(out, dtype=np.uint8) == raw).all()
+            CortexGraph(out, lib=lib).close()

@@ -43,6 +43,9 @@ def test_long_walks(orc, lib, tmp_path): pc.case_long_walks(orc, lib, tmp_path)
 def test_link_formats(orc, lib, tmp_path): pc.case_link_formats(orc, lib, tmp_path)
 
 
+def test_sort(orc, lib, tmp_path): pc.case_sort(orc, lib, tmp_path)
+
+
 def test_big_link_stores(orc, lib, tmp_path): pc.case_big_link_stores(orc, lib, tmp_path)
 
 
