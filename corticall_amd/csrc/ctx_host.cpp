@@ -83,4 +83,26 @@ CtxHeader parse_ctx_header(const uint8_t* p, size_t avail, int64_t file_size, co
     return h;
 }
 
+std::vector<uint8_t> serialize_ctx_header(const CtxHeader& h) {
+    std::vector<uint8_t> o;
+    auto put = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; o.insert(o.end(), b, b + n); };
+    auto u32 = [&](uint32_t v) { put(&v, 4); };
+    put("CORTEX", 6);
+    u32((uint32_t)h.version); u32((uint32_t)h.k); u32((uint32_t)h.W); u32((uint32_t)h.C);
+    for (auto& c : h.colors) u32(c.mean_read_length);
+    for (auto& c : h.colors) { uint64_t v = c.total_sequence; put(&v, 8); }          // putLong, little-endian buffer
+    for (auto& c : h.colors) { u32((uint32_t)c.sample_name.size()); put(c.sample_name.data(), c.sample_name.size()); }
+    static const uint8_t error_rate[16] = {0, 0xd8, 0xa3, 0x70, 0x3d, 0x0a, 0xd7, 0xa3, 0xf8, 0x3f, 0, 0, 0, 0, 0, 0};   // :72-80
+    for (size_t i = 0; i < h.colors.size(); i++) put(error_rate, 16);
+    for (auto& c : h.colors) {
+        const uint8_t flags[4] = {(uint8_t)(c.tip_clipping ? 1 : 0), (uint8_t)(c.low_covg_supernodes_removed ? 1 : 0),
+                                  (uint8_t)(c.low_covg_kmers_removed ? 1 : 0), (uint8_t)(c.cleaned_against_graph ? 1 : 0)};
+        put(flags, 4);
+        u32(c.low_cov_supernodes_threshold); u32(c.low_cov_kmer_threshold);
+        u32((uint32_t)c.cleaned_against_graph_name.size()); put(c.cleaned_against_graph_name.data(), c.cleaned_against_graph_name.size());
+    }
+    put("CORTEX", 6);
+    return o;
+}
+
 }  // namespace ldbg

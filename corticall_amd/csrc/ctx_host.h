@@ -35,4 +35,9 @@ struct CtxHeader {
 // `what` names the file in error messages.  Throws StatusError(LDBG_ERR_CORTEXJDK, ...).
 CtxHeader parse_ctx_header(const uint8_t* p, size_t avail, int64_t file_size, const std::string& what);
 
+// The header as CortexGraphWriter.initialize writes it (J/utils/io/graph/cortex/CortexGraphWriter.java:40-113): the parsed
+// values, not the input bytes — total_sequence goes out as the byte-swapped value the reader produced (Q16), the error
+// rate as the writer's constant, names as trimmed by the reader.
+std::vector<uint8_t> serialize_ctx_header(const CtxHeader& h);
+
 }  // namespace ldbg

@@ -13,6 +13,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <functional>
+#include <memory>
 #include <numeric>
 #include <vector>
 
@@ -71,79 +73,165 @@ LDBG_KERNEL void k_radix_scatter(const uint64_t* word, const uint32_t* perm_in, 
     }
 }
 
-// in_path -> out_path; returns the number of records
-int64_t sort_ctx_file(const std::string& in_path, const std::string& out_path, int device) {
-    if (rt::device_count() <= device) throw StatusError(LDBG_ERR_HIP, "no HIP device " + std::to_string(device) + " available (libldbg has no CPU fallback)");
-    int fd = open(in_path.c_str(), O_RDONLY);
-    if (fd < 0) throw StatusError(LDBG_ERR_CORTEXJDK, "Cortex graph file '" + in_path + "' cannot be opened");
-    struct stat sb;
-    fstat(fd, &sb);
-    const size_t size = (size_t)sb.st_size;
-    const uint8_t* base = size ? (const uint8_t*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
-    close(fd);
-    if (size && base == MAP_FAILED) throw StatusError(LDBG_ERR_CORTEXJDK, "cannot map '" + in_path + "'");
-    struct Unmap { const uint8_t* p; size_t n; ~Unmap() { if (p && n) munmap((void*)p, n); } } unmap{base, size};
-    const CtxHeader h = parse_ctx_header(base, size, (int64_t)size, in_path);
-    const int64_t n = h.num_records;
-    const int W = h.W;
-    const size_t rec = (size_t)h.record_size;
+// stable permutation that sorts n keys of W words (word 0 most significant, `used_bits_word0` significant bits in word 0);
+// fill(w, col) writes word w of every key into col[n]
+static std::vector<uint32_t> radix_sort_permutation(int64_t n, int W, int used_bits_word0, int device,
+                                                    const std::function<void(int, uint64_t*)>& fill) {
     if (n >= (1ll << 32)) throw StatusError(LDBG_ERR_UNSUPPORTED, "Sort: more than 2^32 records");
     std::vector<uint32_t> perm((size_t)n);
     std::iota(perm.begin(), perm.end(), 0u);
-    if (n > 1) {
-        rt::set_device(device);
-        rt::stream_t s = rt::stream_create();
-        const uint8_t* recs = base + h.data_offset;
-        uint64_t* d_word = (uint64_t*)rt::dmalloc((size_t)n * 8);
-        uint32_t* d_a = (uint32_t*)rt::dmalloc((size_t)n * 4);
-        uint32_t* d_b = (uint32_t*)rt::dmalloc((size_t)n * 4);
-        uint32_t* d_counts = (uint32_t*)rt::dmalloc((size_t)16 * SORT_THREADS * 4);
-        uint32_t* d_tot = (uint32_t*)rt::dmalloc(64);
-        rt::h2d(d_a, perm.data(), (size_t)n * 4, s);
-        const int64_t chunk = (n + SORT_THREADS - 1) / SORT_THREADS;
-        std::vector<uint64_t> col((size_t)n);
-        rt::Event e0, e1;
-        double dev_ms = 0;
-        for (int w = W - 1; w >= 0; w--) {                  // least significant word first
-            for (int64_t i = 0; i < n; i++) memcpy(&col[(size_t)i], recs + (size_t)i * rec + (size_t)w * 8, 8);
-            rt::h2d(d_word, col.data(), (size_t)n * 8, s);
-            const int bits = w == 0 ? 2 * h.k - 64 * (W - 1) : 64;     // the used bits of this word
-            e0.record(s);
-            for (int shift = 0; shift < bits; shift += 4) {
-                LDBG_LAUNCH(k_radix_count, SORT_THREADS / 256, 256, s, (const uint64_t*)d_word, (const uint32_t*)d_a, n, shift, chunk, d_counts);
-                LDBG_LAUNCH(k_radix_scan, 1, 64, s, d_counts, d_tot);
-                uint32_t tot[16];
-                rt::d2h(tot, d_tot, 64, s);
-                rt::stream_sync(s);
-                bool uniform = false;
-                for (int d = 0; d < 16; d++) uniform |= (int64_t)tot[d] == n;
-                if (uniform) continue;
-                LDBG_LAUNCH(k_radix_scatter, SORT_THREADS / 256, 256, s, (const uint64_t*)d_word, (const uint32_t*)d_a, d_b, n, shift, chunk, (const uint32_t*)d_counts);
-                std::swap(d_a, d_b);
-            }
-            e1.record(s);
-            dev_ms += rt::Event::elapsed_ms(e0, e1);
+    if (n <= 1) return perm;
+    rt::set_device(device);
+    rt::stream_t s = rt::stream_create();
+    uint64_t* d_word = (uint64_t*)rt::dmalloc((size_t)n * 8);
+    uint32_t* d_a = (uint32_t*)rt::dmalloc((size_t)n * 4);
+    uint32_t* d_b = (uint32_t*)rt::dmalloc((size_t)n * 4);
+    uint32_t* d_counts = (uint32_t*)rt::dmalloc((size_t)16 * SORT_THREADS * 4);
+    uint32_t* d_tot = (uint32_t*)rt::dmalloc(64);
+    rt::h2d(d_a, perm.data(), (size_t)n * 4, s);
+    const int64_t chunk = (n + SORT_THREADS - 1) / SORT_THREADS;
+    std::vector<uint64_t> col((size_t)n);
+    rt::Event e0, e1;
+    double dev_ms = 0;
+    for (int w = W - 1; w >= 0; w--) {                  // least significant word first
+        fill(w, col.data());
+        rt::h2d(d_word, col.data(), (size_t)n * 8, s);
+        const int bits = w == 0 ? used_bits_word0 : 64;
+        e0.record(s);
+        for (int shift = 0; shift < bits; shift += 4) {
+            LDBG_LAUNCH(k_radix_count, SORT_THREADS / 256, 256, s, (const uint64_t*)d_word, (const uint32_t*)d_a, n, shift, chunk, d_counts);
+            LDBG_LAUNCH(k_radix_scan, 1, 64, s, d_counts, d_tot);
+            uint32_t tot[16];
+            rt::d2h(tot, d_tot, 64, s);
+            rt::stream_sync(s);
+            bool uniform = false;
+            for (int d = 0; d < 16; d++) uniform |= (int64_t)tot[d] == n;
+            if (uniform) continue;
+            LDBG_LAUNCH(k_radix_scatter, SORT_THREADS / 256, 256, s, (const uint64_t*)d_word, (const uint32_t*)d_a, d_b, n, shift, chunk, (const uint32_t*)d_counts);
+            std::swap(d_a, d_b);
         }
-        profile_add("sort", dev_ms);
-        rt::d2h(perm.data(), d_a, (size_t)n * 4, s);
-        rt::stream_sync(s);
-        rt::dfree(d_word); rt::dfree(d_a); rt::dfree(d_b); rt::dfree(d_counts); rt::dfree(d_tot);
-        rt::stream_destroy(s);
+        e1.record(s);
+        dev_ms += rt::Event::elapsed_ms(e0, e1);
     }
-    // CortexGraphWriter: the header as it was, then the records in their new order
+    profile_add("sort", dev_ms);
+    rt::d2h(perm.data(), d_a, (size_t)n * 4, s);
+    rt::stream_sync(s);
+    rt::dfree(d_word); rt::dfree(d_a); rt::dfree(d_b); rt::dfree(d_counts); rt::dfree(d_tot);
+    rt::stream_destroy(s);
+    return perm;
+}
+
+struct MappedCtx {
+    const uint8_t* base = nullptr;
+    size_t size = 0;
+    CtxHeader h;
+    explicit MappedCtx(const std::string& path) {
+        int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw StatusError(LDBG_ERR_CORTEXJDK, "Cortex graph file '" + path + "' cannot be opened");
+        struct stat sb;
+        fstat(fd, &sb);
+        size = (size_t)sb.st_size;
+        base = size ? (const uint8_t*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+        close(fd);
+        if (size && base == MAP_FAILED) { base = nullptr; throw StatusError(LDBG_ERR_CORTEXJDK, "cannot map '" + path + "'"); }
+        h = parse_ctx_header(base, size, (int64_t)size, path);
+    }
+    ~MappedCtx() { if (base && size) munmap((void*)base, size); }
+    MappedCtx(const MappedCtx&) = delete;
+    const uint8_t* record(int64_t i) const { return base + h.data_offset + (size_t)i * (size_t)h.record_size; }
+};
+
+static void write_all(FILE* f, const std::vector<uint8_t>& b, bool& ok) { if (ok && !b.empty()) ok = fwrite(b.data(), 1, b.size(), f) == b.size(); }
+
+// Sort: in_path -> out_path; returns the number of records
+int64_t sort_ctx_file(const std::string& in_path, const std::string& out_path, int device) {
+    if (rt::device_count() <= device) throw StatusError(LDBG_ERR_HIP, "no HIP device " + std::to_string(device) + " available (libldbg has no CPU fallback)");
+    MappedCtx in(in_path);
+    const CtxHeader& h = in.h;
+    const int64_t n = h.num_records;
+    const size_t rec = (size_t)h.record_size;
+    const std::vector<uint32_t> perm = radix_sort_permutation(n, h.W, 2 * h.k - 64 * (h.W - 1), device, [&](int w, uint64_t* col) {
+        for (int64_t i = 0; i < n; i++) memcpy(&col[i], in.record(i) + (size_t)w * 8, 8);
+    });
+    // CortexGraphWriter: the header re-serialised from its parsed values (not a byte copy), then the records in their new order
     FILE* f = fopen(out_path.c_str(), "wb");
     if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "cannot write '" + out_path + "'");
-    bool ok = fwrite(base, 1, (size_t)h.data_offset, f) == (size_t)h.data_offset;
+    bool ok = true;
+    write_all(f, serialize_ctx_header(h), ok);
     std::vector<uint8_t> buf;
     buf.reserve((size_t)(1 << 16) * rec);
     for (int64_t i = 0; i < n && ok; i++) {
-        const uint8_t* r = base + h.data_offset + (size_t)perm[(size_t)i] * rec;
+        const uint8_t* r = in.record(perm[(size_t)i]);
         buf.insert(buf.end(), r, r + rec);
-        if (buf.size() >= (size_t)(1 << 16) * rec || i + 1 == n) { ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size(); buf.clear(); }
+        if (buf.size() >= (size_t)(1 << 16) * rec || i + 1 == n) { write_all(f, buf, ok); buf.clear(); }
     }
     ok = fclose(f) == 0 && ok;
     if (!ok) throw StatusError(LDBG_ERR_CORTEXJDK, "error while writing '" + out_path + "'");
     return n;
+}
+
+// Join (J/commands/utils/Join.java:16-60 over CortexCollection, J/utils/io/graph/cortex/CortexCollection.java:34-58, 218-293):
+// the union of the k-mers of several sorted graphs, each graph's colours side by side (a k-mer missing from a graph has
+// coverage 0 and no edges there).  The reference merges the files' iterators head by head; here the keys of all files are
+// concatenated and go through the same stable device sort (ties stay in file order), then equal neighbours are folded.
+int64_t join_ctx_files(const std::vector<std::string>& paths, const std::string& out_path, int device) {
+    if (rt::device_count() <= device) throw StatusError(LDBG_ERR_HIP, "no HIP device " + std::to_string(device) + " available (libldbg has no CPU fallback)");
+    if (paths.empty()) throw StatusError(LDBG_ERR_ARG, "Join: no graphs");
+    std::vector<std::unique_ptr<MappedCtx>> in;
+    for (auto& p : paths) in.emplace_back(new MappedCtx(p));
+    CtxHeader out_h;
+    out_h.version = 6; out_h.k = in[0]->h.k; out_h.W = in[0]->h.W; out_h.C = 0;
+    std::vector<int64_t> first_rec{0};
+    std::vector<int> first_col;
+    for (size_t g = 0; g < in.size(); g++) {
+        const CtxHeader& h = in[g]->h;
+        if (h.k != out_h.k)
+            throw StatusError(LDBG_ERR_CORTEXJDK, "Graph kmer sizes are not equal.  Expected k=" + std::to_string(out_h.k) + ", but found k=" +
+                                                      std::to_string(h.k) + " in graph " + paths[g]);
+        first_col.push_back(out_h.C);
+        out_h.C += h.C;
+        out_h.colors.insert(out_h.colors.end(), h.colors.begin(), h.colors.end());
+        first_rec.push_back(first_rec.back() + h.num_records);
+    }
+    const int64_t n = first_rec.back();
+    const int W = out_h.W, C = out_h.C;
+    auto locate = [&](int64_t i, size_t* g) { size_t x = 0; while (i >= first_rec[x + 1]) x++; *g = x; return i - first_rec[x]; };
+    const std::vector<uint32_t> perm = radix_sort_permutation(n, W, 2 * out_h.k - 64 * (W - 1), device, [&](int w, uint64_t* col) {
+        for (size_t g = 0; g < in.size(); g++)
+            for (int64_t i = 0; i < in[g]->h.num_records; i++) memcpy(&col[first_rec[g] + i], in[g]->record(i) + (size_t)w * 8, 8);
+    });
+    FILE* f = fopen(out_path.c_str(), "wb");
+    if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "cannot write '" + out_path + "'");
+    bool ok = true;
+    write_all(f, serialize_ctx_header(out_h), ok);
+    const size_t rec = (size_t)(8 * W + 5 * C);
+    std::vector<uint8_t> buf, cur(rec);
+    int64_t n_out = 0;
+    for (int64_t i = 0; i < n && ok;) {
+        size_t g;
+        int64_t li = locate((int64_t)perm[(size_t)i], &g);
+        const uint8_t* key = in[g]->record(li);
+        std::fill(cur.begin(), cur.end(), 0);
+        memcpy(cur.data(), key, (size_t)8 * W);
+        int64_t j = i;
+        for (; j < n; j++) {                               // every file's record of this k-mer (CortexCollection.next :241-283)
+            size_t g2;
+            const int64_t l2 = locate((int64_t)perm[(size_t)j], &g2);
+            const uint8_t* r = in[g2]->record(l2);
+            if (memcmp(r, key, (size_t)8 * W) != 0) break;
+            const int Cg = in[g2]->h.C;
+            memcpy(cur.data() + 8 * W + 4 * first_col[g2], r + 8 * W, (size_t)4 * Cg);
+            memcpy(cur.data() + 8 * W + 4 * C + first_col[g2], r + 8 * W + 4 * Cg, (size_t)Cg);
+        }
+        buf.insert(buf.end(), cur.begin(), cur.end());
+        n_out++;
+        i = j;
+        if (buf.size() >= ((size_t)1 << 16) * rec) { write_all(f, buf, ok); buf.clear(); }
+    }
+    write_all(f, buf, ok);
+    ok = fclose(f) == 0 && ok;
+    if (!ok) throw StatusError(LDBG_ERR_CORTEXJDK, "error while writing '" + out_path + "'");
+    return n_out;
 }
 
 }  // namespace ldbg

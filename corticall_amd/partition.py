@@ -117,3 +117,17 @@ class Sort:
         n = C.c_int64()
         self._lib.check(self._lib.dll.ldbg_sort_ctx(self.path.encode(), self.out.encode(), int(self.device), C.byref(n)))
         return n.value
+
+
+class Join:
+    """J/commands/utils/Join.java:16-60 — several sorted graphs as one, colours side by side (ldbg_join_ctx)"""
+
+    def __init__(self, graph_paths, out_path, device=0, lib=None):
+        self.paths, self.out, self.device = [str(p) for p in graph_paths], str(out_path), device
+        self._lib = lib or _native.default_lib()
+
+    def execute(self):
+        n = C.c_int64()
+        arr = (C.c_char_p * len(self.paths))(*[p.encode() for p in self.paths])
+        self._lib.check(self._lib.dll.ldbg_join_ctx(arr, len(self.paths), self.out.encode(), int(self.device), C.byref(n)))
+        return n.value

@@ -60,6 +60,9 @@ ldbg_status ldbg_kmer_decode(const uint64_t* words, int k, char* ascii_out /* k 
  * stable like Arrays.sort) under the unchanged header — produces the sorted table ldbg_graph_open requires.  The order is
  * computed by a radix sort on the device. */
 ldbg_status ldbg_sort_ctx(const char* in_path, const char* out_path, int device, int64_t* num_records);
+/* Join (J/commands/utils/Join.java:16-60; CortexCollection.java:34-58, 218-293): the union of the k-mers of several sorted
+ * graphs with every graph's colours side by side, written as one graph.  num_records = k-mers written. */
+ldbg_status ldbg_join_ctx(const char* const* in_paths, int n_paths, const char* out_path, int device, int64_t* num_records);
 
 /* ------------------------------------------------------------------ graph: G1-G3
  * new CortexGraph(path)              J/utils/io/graph/cortex/CortexGraph.java:40-48, 66-168

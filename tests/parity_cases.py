@@ -763,3 +763,122 @@ def case_sort(orc, lib, tmp):
             Sort(clean, out, lib=lib).execute()
             assert (np.fromfile(out, dtype=np.uint8) == raw).all()
             CortexGraph(out, lib=lib).close()
+
+
+def java_read_header(raw):
+    """CortexGraph.loadCortexGraph (:66-168): the values the reader keeps — total_sequence read big-endian (quirk Q16),
+    names cut at their first NUL, the error rate skipped -> (k, W, [colour dicts])"""
+    import struct
+    ver, k, W, C = struct.unpack_from("<IIII", raw, 6)
+    p = 22
+    mrl = struct.unpack_from("<%dI" % C, raw, p); p += 4 * C
+    tot = struct.unpack_from(">%dQ" % C, raw, p); p += 8 * C
+    names = []
+    for _ in range(C):
+        (ln,) = struct.unpack_from("<I", raw, p); p += 4
+        names.append(bytes(raw[p:p + ln]).split(b"\0")[0]); p += ln
+    p += 16 * C
+    cols = []
+    for c in range(C):
+        fl = bytes(raw[p:p + 4]); t1, t2, ln = struct.unpack_from("<III", raw, p + 4); p += 16
+        cols.append(dict(mrl=mrl[c], tot=tot[c], name=names[c], flags=bytes(1 if b else 0 for b in fl), t1=t1, t2=t2,
+                         cleaned=bytes(raw[p:p + ln]).split(b"\0")[0])); p += ln
+    return k, W, cols
+
+
+def java_write_header(k, W, cols):
+    """CortexGraphWriter.initialize (:40-113)"""
+    import struct
+    C = len(cols)
+    o = b"CORTEX" + struct.pack("<IIII", 6, k, W, C) + struct.pack("<%dI" % C, *[c["mrl"] for c in cols])
+    o += struct.pack("<%dQ" % C, *[c["tot"] for c in cols])
+    for c in cols:
+        o += struct.pack("<I", len(c["name"])) + c["name"]
+    o += bytes([0, 0xd8, 0xa3, 0x70, 0x3d, 0x0a, 0xd7, 0xa3, 0xf8, 0x3f, 0, 0, 0, 0, 0, 0]) * C
+    for c in cols:
+        o += c["flags"] + struct.pack("<III", c["t1"], c["t2"], len(c["cleaned"])) + c["cleaned"]
+    return o + b"CORTEX"
+
+
+def java_rewritten_header(raw):
+    """what the reference's reader + writer pair makes of a header: values, not bytes"""
+    return java_write_header(*java_read_header(raw))
+
+
+def case_sort_rewrites_header(orc, lib, tmp):
+    """a McCortex-like header (total_sequence set, another error rate, a name padded with NULs) comes out of Sort the way the
+    reference's reader + writer pair would leave it"""
+    import struct
+    from corticall_amd.distributed import ctx_header
+    from corticall_amd.partition import Sort
+    rng = random.Random(41)
+    src = str(tmp / "plain.ctx")
+    orc.build_graph(src, [("a", [rand_seq(rng, 400)]), ("b", [rand_seq(rng, 300)])], 21)
+    raw = np.fromfile(src, dtype=np.uint8)
+    h = ctx_header(raw)
+    body = raw[h["data_offset"]:]
+    hdr = (b"CORTEX" + struct.pack("<IIII", 6, 21, 1, 2) + struct.pack("<II", 100, 76) + struct.pack("<QQ", 123456789, 2 ** 40 + 7)
+           + struct.pack("<I", 6) + b"mom\0\0\0" + struct.pack("<I", 3) + b"kid" + bytes(range(1, 33))
+           + bytes([1, 0, 2, 0]) + struct.pack("<III", 5, 0, 7) + b"ref.ctx" + bytes([0, 1, 0, 0]) + struct.pack("<III", 0, 3, 0) + b"CORTEX")
+    rec = 8 + 10
+    recs = body.reshape(-1, rec)
+    shuffled = recs[np.random.default_rng(3).permutation(len(recs))]
+    unsorted = str(tmp / "mccortex_like.ctx")
+    np.concatenate([np.frombuffer(hdr, dtype=np.uint8), shuffled.reshape(-1)]).tofile(unsorted)
+    out = str(tmp / "mccortex_like.sorted.ctx")
+    assert Sort(unsorted, out, lib=lib).execute() == len(recs)
+    got = np.fromfile(out, dtype=np.uint8).tobytes()
+    exp_hdr = java_rewritten_header(np.frombuffer(hdr, dtype=np.uint8))
+    assert got[:len(exp_hdr)] == exp_hdr and got[len(exp_hdr):] == body.tobytes()
+    assert exp_hdr != hdr                                                   # the rewrite is visible (Q16, error rate, names)
+    g = CortexGraph(out, lib=lib)
+    assert g.getSampleName(0) == "mom" and g.getNumRecords() == len(recs)
+    g.close()
+
+
+def case_join(orc, lib, tmp):
+    """Join.java:16-60 over CortexCollection (:34-58 colours side by side, :218-293 head-by-head merge of the sorted files):
+    the union of the k-mers, zero coverage / no edges where a file lacks the k-mer — byte for byte"""
+    from corticall_amd.distributed import ctx_header
+    from corticall_amd.partition import Join
+    rng = random.Random(58)
+    for k in (21, 47):
+        base = rand_seq(rng, 1200)
+        paths, parsed = [], []
+        for gi, ncol in enumerate((1, 2, 1)):
+            haps = [("s%d_%d" % (gi, c), [mutate(rng, base[rng.randint(0, 200):rng.randint(600, 1200)], snv=0.02)]) for c in range(ncol)]
+            p = str(tmp / ("j%d_%d.ctx" % (k, gi)))
+            orc.build_graph(p, haps, k)
+            raw = np.fromfile(p, dtype=np.uint8)
+            h = ctx_header(raw)
+            rec = 8 * h["W"] + 5 * h["C"]
+            parsed.append((raw, h, raw[h["data_offset"]:].reshape(-1, rec)))
+            paths.append(p)
+        W = parsed[0][1]["W"]
+        Ctot = sum(h["C"] for _, h, _ in parsed)
+        cols, merged, off = [], {}, 0
+        for raw, h, recs in parsed:
+            cols += java_read_header(raw)[2]
+            for r in recs:
+                key = r[:8 * W].tobytes()
+                cov, edges = merged.setdefault(key, (bytearray(4 * Ctot), bytearray(Ctot)))
+                cov[4 * off:4 * (off + h["C"])] = r[8 * W:8 * W + 4 * h["C"]].tobytes()
+                edges[off:off + h["C"]] = r[8 * W + 4 * h["C"]:].tobytes()
+            off += h["C"]
+        def kmer_order(key):          # file order = k-mer order: words most significant first
+            return tuple(int.from_bytes(key[8 * w:8 * w + 8], "little") for w in range(W))
+        body = b"".join(key + bytes(merged[key][0]) + bytes(merged[key][1]) for key in sorted(merged, key=kmer_order))
+        expected = java_write_header(k, W, cols) + body
+        out = str(tmp / ("joined%d.ctx" % k))
+        assert Join(paths, out, lib=lib).execute() == len(merged)
+        assert np.fromfile(out, dtype=np.uint8).tobytes() == expected
+        g = CortexGraph(out, lib=lib)
+        assert g.getNumColors() == Ctot and g.getNumRecords() == len(merged) and g.getSampleName(1) == "s1_0"
+        g.close()
+    other = str(tmp / "otherk.ctx")
+    orc.build_graph(other, [("x", [rand_seq(rng, 100)])], 31)
+    try:
+        Join([paths[0], other], str(tmp / "bad.ctx"), lib=lib).execute()
+        assert False
+    except ca.CortexJDKException as ex:
+        assert "Graph kmer sizes are not equal" in str(ex)

@@ -44,6 +44,8 @@ def test_link_formats(orc, lib, tmp_path): pc.case_link_formats(orc, lib, tmp_pa
 
 
 def test_sort(orc, lib, tmp_path): pc.case_sort(orc, lib, tmp_path)
+def test_sort_rewrites_header(orc, lib, tmp_path): pc.case_sort_rewrites_header(orc, lib, tmp_path)
+def test_join(orc, lib, tmp_path): pc.case_join(orc, lib, tmp_path)
 
 
 def test_big_link_stores(orc, lib, tmp_path): pc.case_big_link_stores(orc, lib, tmp_path)
