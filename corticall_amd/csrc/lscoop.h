@@ -258,7 +258,7 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
     if (flagged) m_nxt = e.links.rec_of[st.cu.nxt.idx];
     if (one_child) child_ent = st.cu.nxt.e1 ? st.cu.nxt.ent1 : node_child_entry(e, st.cu.nxt, st.fwd, lowbit4(nmask));
     if (cur_mode && st.cu.first && (st.cu.cur.lflags & e.link_flag_mask)) m_cur = e.links.rec_of[st.cu.cur.idx];
-    AddPre ap_cur = AddPre(), ap_nxt = AddPre();
+    AddPre ap_cur, ap_nxt;      // read only by the lanes that filled them (the flags below say which)
     if (m_nxt != 0xFFFFFFFFu) { ap_nxt.jlo = e.links.off[m_nxt]; ap_nxt.jhi = e.links.off[m_nxt + 1]; }
     pre.has_child = one_child;
     if (one_child) node_from_entry(e, st.vt, st.cu.nxt, child_ent, lowbit4(nmask), st.fwd, pre.child);
