@@ -89,7 +89,9 @@ LDBG_DEV unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long 
 LDBG_DEV int wave_size() { return (int)blockDim.x; }   // wave kernels run one (possibly partial) wavefront per workgroup
 LDBG_DEV int wave_lane() { return (int)(threadIdx.x & 63u); }
 LDBG_DEV unsigned long long wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
-LDBG_DEV uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+// broadcast from a lane every lane agrees on (src is wave-uniform at every call site: it comes from a ballot): v_readlane,
+// not a cross-lane shuffle through the LDS crossbar
+LDBG_DEV uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
 LDBG_DEV uint64_t wave_bcast_u64(uint64_t v, int src) {
     uint32_t lo = wave_bcast_u32((uint32_t)v, src), hi = wave_bcast_u32((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
