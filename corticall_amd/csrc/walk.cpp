@@ -98,9 +98,11 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     StrandState st;
     st.vt.tab = nullptr; st.vt.mask = 0; st.vt.used = 0; st.status = ST_OK;
     bool active = false, exhausted = false;
+    unsigned long long wave_iterations = 0;
     // all lanes of a wavefront stay in the loop until every one of them has run out of strands: the table
     // regrowth below is a wave-wide operation
     while (wave_ballot(active || !exhausted) != 0ull) {
+        wave_iterations++;
         if (!active && !exhausted) {
             const int64_t fi = (int64_t)atomic_add_u64(a.next_strand, 1ull);
             if (fi >= a.n_strands) exhausted = true;
@@ -124,6 +126,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     }
 #ifndef LDBG_HOSTSIM
     if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) atomic_add_u64(a.vnext + 1, wave_iterations);     // diagnostics: loop iterations of all wavefronts
 #endif
 }
 
@@ -627,7 +630,8 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
                     (i & 1) ? "fwd" : "rev", ms, iters[i], iters[i] ? ms * 1e3 / iters[i] : 0.0, (long long)(i & 63), out.status[i]);
         }
         double tot_ms = 0; for (int64_t i = 0; i < ns; i++) tot_ms += (tt[2 * i + 1] - tt[2 * i]) / 1e5;
-        fprintf(stderr, "[ldbg] sum of strand durations %.1f s over %lld strands\n", tot_ms / 1e3, (long long)ns);
+        fprintf(stderr, "[ldbg] sum of strand durations %.1f s over %lld strands; %llu wavefront loop iterations in %d wavefronts\n", tot_ms / 1e3, (long long)ns,
+                ctr[3], grid);
         rt::dfree(a.st_times);
     }
     vpool_dirty_ = ctr[2];
