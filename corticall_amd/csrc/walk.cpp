@@ -68,6 +68,59 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, 
     return false;
 }
 
+// ---- the lean step.  Nearly all iterations of a link-guided walk are the same case: the cursor has a next vertex, that
+// vertex has one successor with a record, no link annotations, no junction, no quirk, nothing ends or allocates.  The
+// general step (coop_step_prepare + cursor_step + strand_step) spends ~1000 instructions per iteration on its generality
+// (PMC: profiles/r01_walk_instructions.log) and a walk cannot go faster than its own instruction stream; this is the
+// same sequence of table reads and writes with the decisions taken out.  Any lane for which lean_ok() is false takes
+// the general step in the same iteration.
+LDBG_DEV bool lean_ok(const WalkArgs& a, const StrandState& st) {
+    const Cursor& cu = st.cu;
+    const Node& cv = st.cv;
+    const Node& t = cu.nxt;
+    if (!(st.status == ST_OK && a.e.cursor_on && cu.has && !cu.first)) return false;
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    return st.gV >= 2 && st.gV <= (uint32_t)a.e.max_len                            // not the first step, not at the maxLength cut
+        && cv.idx >= 0 && t.idx >= 0 && !t.npe && cv.flip == cv.fj && t.flip == t.fj   // records present, no quirk-Q6 vertex
+        && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u                                     // exactly one successor, and it has a record
+        && !(t.lflags & a.e.link_flag_mask)                                         // no links to add
+        && cv.vslot != t.vslot                                                      // not standing on the vertex it looks at
+        && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767                       // cv not visited before, copies in range
+        && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u                                  // room in the current path block
+        && (a.e.g.k & 1);                                                           // odd k: no palindromic k-mers
+}
+template <int W>
+LDBG_DEV void lean_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) {
+    const EngineView& e = a.e;
+    const bool fwd = st.fwd;
+    st.iters++;
+    Node& cv = st.cv;
+    Node av = st.cu.nxt;                               // next()/previous(): step onto it (TraversalEngine.java:241-279)
+    st.cu.cur = av;
+    Node x;                                            // its only successor, one step ahead
+    node_from_entry(e, st.vt, av, av.ent1, lowbit4(fwd ? av.next_mask : av.prev_mask), fwd, x);
+    bool has = false;
+    const bool seen = vt_seen_e(x.vent, st.cu.epoch);
+    if (!seen || ls.n > 0) {                           // :262
+        if (!seen) { node_store(st.vt, x, vt_with_seen(x.vent, st.cu.epoch)); node_sync(st.cu.cur, x); }
+        st.cu.nxt = x;
+        has = true;
+    }
+    st.cu.has = has;
+    if (ls_num_new(ls) > 0) ls_increment_ages(ls);     // :274-276 (Q12)
+    if (has) { node_sync(cv, st.cu.nxt); node_sync(av, st.cu.nxt); }
+    const int cnt = node_count(av);                    // first unused copyIndex :383-389
+    av.copy = fwd ? cnt : -cnt;
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    node_store(st.vt, cv, vt_with_count(cv.vent, acopy + 1));      // visited.add(cv) :425
+    node_sync(av, cv); node_sync(st.cu.cur, cv);
+    if (has) node_sync(st.cu.nxt, cv);
+    st.pw.cur[st.pw.n & (LDBG_PATH_BLOCK - 1)] = pack_vertex(av);   // connectVertex(g, cv, {av}) :432-440
+    st.pw.n++;
+    st.gV++;
+    cv = av;
+}
+
 // BS = lanes per workgroup (a full or partial wavefront).  Fewer lanes per wavefront = fewer strands whose link-store
 // work the wavefront has to carry out one after the other, and more wavefronts per CU to hide each other's latency.
 template <int W, int BS>
@@ -118,11 +171,14 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             }
         }
         wave_grow_tables(a, st, active);
+        const bool lean = active && lean_ok(a, st);
+        if (lean) lean_step<W>(a, st, ls);
+        if (wave_ballot(active && !lean) == 0ull) continue;          // the whole wavefront took the lean step
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
-        const bool cur_mode = active && st.status == ST_OK && a.e.cursor_on && st.cu.has;
+        const bool cur_mode = active && !lean && st.status == ST_OK && a.e.cursor_on && st.cu.has;
         StepPre pre;
         coop_step_prepare<W>(a.e, st, ls, lw, cur_mode, pre);
-        if (active && strand_step<W>(a, st, ls, pre)) { strand_finish(a, st); active = false; }
+        if (active && !lean && strand_step<W>(a, st, ls, pre)) { strand_finish(a, st); active = false; }
     }
 #ifndef LDBG_HOSTSIM
     if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
