@@ -751,7 +751,8 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     a.w.seeds = d_seeds;
     a.w.n_strands = ns;
     a.w.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
-    a.w.n_slots = std::min<int64_t>(a.w.n_slots, (int64_t)3 * 256 * 64);
+    // every workgroup resident: LDBG_LS_FAST x 64 x 24 B of LDS each; 194 VGPRs per lane leave 2 wavefronts per SIMD = 8 per CU
+    a.w.n_slots = std::min<int64_t>(a.w.n_slots, (int64_t)std::min<size_t>(8, 160 * 1024 / (LDBG_LS_FAST * 64 * sizeof(LsElem))) * 256 * 64);
     a.w.n_slots = std::max<int64_t>(64, (a.w.n_slots / 64) * 64);
     {
         auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };

@@ -41,7 +41,9 @@ struct WalkArgs {
 };
 #define LDBG_VT_INITIAL 4096u
 #ifndef LDBG_LS_FAST
-#define LDBG_LS_FAST 32u          // link-store elements per lane kept in LDS (48 KB per 64-lane workgroup)
+#define LDBG_LS_FAST 16u          // link-store elements per lane kept in LDS: 24 KB per 64-lane workgroup, so that six workgroups
+                                  // fit a CU and every strand of a 50,000-seed batch has a lane (profiles/r01_exp_ls_fast.log:
+                                  // 8/12/16 elements 0.356 s per launch, 24 elements 0.41 s, 32 elements 0.44 s)
 #endif
 
 LDBG_DEV uint64_t pack_vertex(const Node& v) { return path_pack(v.idx, v.flip != 0, v.base, v.copy, v.flip && !v.fj); }

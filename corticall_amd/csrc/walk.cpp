@@ -616,7 +616,9 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     // wavefronts finish the bulk sooner but the longest strands run slower with more wavefronts per CU)
     int block = 64;
     if (const char* ev = getenv("LDBG_WALK_BLOCK")) block = atoi(ev) == 16 ? 16 : (atoi(ev) == 32 ? 32 : 64);   // tuning knob
-    const int wg_per_cu = std::min<int>(32, (int)(160 * 1024 / (LDBG_LS_FAST * (size_t)block * sizeof(LsElem))));
+    // residency: LDS per workgroup, and 152 VGPRs per lane leave 3 wavefronts per SIMD = 12 per CU
+    int wg_per_cu = std::min<int>(12, (int)(160 * 1024 / (LDBG_LS_FAST * (size_t)block * sizeof(LsElem))));
+    if (const char* ev = getenv("LDBG_WG_PER_CU")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(ev)));   // tuning knob
     a.n_slots = std::min<int64_t>(a.n_slots, (int64_t)wg_per_cu * 256 * block);
     a.n_slots = (a.n_slots / block) * block;
     if (a.n_slots < block) a.n_slots = block;
