@@ -84,15 +84,13 @@ LDBG_DEV void coop_add(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, co
             const unsigned long long mb = wave_ballot(match);
             if (mb) found = (1ull << 32) | wave_bcast_u32(ks, 63 - __builtin_clzll(mb));
         } else
-        for (uint32_t base = 0; base < h.n; base += WS) {
+        for (uint32_t base = 0; base < h.n; base += WS) {           // several elements per lane: later rounds hold newer elements
             const uint32_t i = base + lane;
-            uint64_t cand = 0;
-            if (i < h.n) {
-                const LsElem y = lsw_get(v, L, i);
-                if (ls_same_string(Lk, y, x)) cand = ((uint64_t)(i + 1) << 32) | y.key_seq;
-            }
-            const uint64_t r = wave_max_u64(cand);
-            found = r > found ? r : found;
+            bool match = false;
+            uint32_t ks = 0;
+            if (i < h.n) { const LsElem y = lsw_get(v, L, i); match = ls_same_string(Lk, y, x); ks = y.key_seq; }
+            const unsigned long long mb = wave_ballot(match);
+            if (mb) found = (1ull << 32) | wave_bcast_u32(ks, 63 - __builtin_clzll(mb));
         }
         if (found) x.key_seq = (uint32_t)found;
         else {
@@ -169,17 +167,19 @@ LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHd
     for (uint32_t base = 0; base < h.n; base += WS) {
         const uint32_t i = base + lane;
         bool old = false, differs = false;
-        uint64_t cand = ~0ull;
+        uint64_t mine = ~0ull;
         if (i < h.n) {
             const LsElem x = lsw_get(v, L, i);
             old = x.birth == minbirth;
             differs = old && ls_cur(x) != ch0;
             const uint32_t hh = (uint32_t)x.hash;
-            if (old) cand = ((uint64_t)((hh ^ (hh >> 16)) & (h.java_cap - 1)) << 32) | x.key_seq;
+            mine = ((uint64_t)((hh ^ (hh >> 16)) & (h.java_cap - 1)) << 32) | x.key_seq;
         }
         if (wave_ballot(differs) != 0ull) disagree = true;
-        const uint64_t r = wave_min_u64(cand);
-        best = r < best ? r : best;
+        for (unsigned long long ob = wave_ballot(old); ob; ob &= ob - 1) {      // the oldest links are few: walk their lanes
+            const uint64_t o = wave_bcast_u64(mine, __builtin_ctzll(ob));
+            best = o < best ? o : best;
+        }
         if (wave_ballot(i < h.n && !old) != 0ull) break;       // past the prefix of oldest links
     }
     if (disagree) return false;
@@ -187,13 +187,11 @@ LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHd
     uint64_t last = 0;
     for (uint32_t base = 0; base < h.n; base += WS) {           // last element of that key's list wins (:129-133)
         const uint32_t i = base + lane;
-        uint64_t cand = 0;
-        if (i < h.n) {
-            const LsElem x = lsw_get(v, L, i);
-            if (x.key_seq == best_seq) cand = ((uint64_t)(i + 1) << 2) | ls_cur(x);
-        }
-        const uint64_t r = wave_max_u64(cand);
-        last = r > last ? r : last;
+        bool mine = false;
+        unsigned c = 0;
+        if (i < h.n) { const LsElem x = lsw_get(v, L, i); mine = x.key_seq == best_seq; c = ls_cur(x); }
+        const unsigned long long kb = wave_ballot(mine);
+        if (kb) last = wave_bcast_u32(c, 63 - __builtin_clzll(kb));          // a later round holds later elements
     }
     const unsigned ch = (unsigned)(last & 3ull);
     // keys whose last element expires leave the HashMap (:84-88): a dead element takes its key along unless a surviving
