@@ -687,6 +687,16 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
             fprintf(stderr, "[ldbg] slow strand %lld (seed %lld %s): %.1f ms, %u iterations, %.2f us/iter, lane %lld of its wave, status %u\n", (long long)i, (long long)(first + i / 2),
                     (i & 1) ? "fwd" : "rev", ms, iters[i], iters[i] ? ms * 1e3 / iters[i] : 0.0, (long long)(i & 63), out.status[i]);
         }
+        {   // the walks that ran to maxLength: how evenly do they progress?
+            std::vector<double> us;
+            uint32_t max_it = 0;
+            for (int64_t i = 0; i < ns; i++) max_it = std::max(max_it, iters[i]);
+            for (int64_t i = 0; i < ns; i++) if (iters[i] == max_it && max_it > 0) us.push_back((tt[2 * i + 1] - tt[2 * i]) / 100.0 / max_it);
+            std::sort(us.begin(), us.end());
+            if (!us.empty())
+                fprintf(stderr, "[ldbg] %zu strands of %u iterations: us/iter p0/p10/p50/p90/p100 = %.2f %.2f %.2f %.2f %.2f\n", us.size(), max_it,
+                        us[0], us[us.size() / 10], us[us.size() / 2], us[us.size() * 9 / 10], us.back());
+        }
         double tot_ms = 0; for (int64_t i = 0; i < ns; i++) tot_ms += (tt[2 * i + 1] - tt[2 * i]) / 1e5;
         fprintf(stderr, "[ldbg] sum of strand durations %.1f s over %lld strands; %llu wavefront loop iterations in %d wavefronts\n", tot_ms / 1e3, (long long)ns,
                 ctr[3], grid);
