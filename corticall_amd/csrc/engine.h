@@ -80,34 +80,41 @@ struct Node {
 };
 
 // edges of the node's record -> neighbour masks; link flags; Java flip from the record's collision bit
-LDBG_HOSTDEV void node_fill(const EngineView& e, Node& n) {
+// `edges4`: the edge bytes of colours 0..3 packed into one word (byte c = colour c), `more`: the row's edge bytes for c >= 4
+LDBG_HOSTDEV void node_fill_bytes(const EngineView& e, Node& n, uint32_t edges4, const uint8_t* more, uint8_t fl) {
     const GraphView& g = e.g;
-    n.npe = 0; n.lflags = 0; n.fj = n.flip;
+    n.npe = 0; n.fj = n.flip;
+    n.lflags = fl & LDBG_ROW_LINK_BITS;
+    // isFlipped() is false for a reverse-complemented k-mer whose two orientations hash alike (Q6)
+    if (e.strict_flip && (fl & LDBG_ROW_HASH_COLLISION)) n.fj = 0;
+    const bool fj = n.fj != 0;
     uint32_t tf = 0, tr = 0, rf = 0, rr = 0;
-    if (n.idx >= 0) {
-        const uint8_t* row = graph_row(g, n.idx);
-        const uint8_t* ed = row + g.edges_off;
-        const uint8_t fl = row[g.flags_off];
-        n.lflags = fl & LDBG_ROW_LINK_BITS;
-        // isFlipped() is false for a reverse-complemented k-mer whose two orientations hash alike (Q6)
-        if (e.strict_flip && (fl & LDBG_ROW_HASH_COLLISION)) n.fj = 0;
-        const bool fj = n.fj != 0;
-        for (int col = 0; col < g.C; col++) {
-            uint32_t ebyte = ed[col];
-            uint32_t lo = ebyte & 0xf, hi = ebyte >> 4;
-            // CortexRecord.getOutEdgesAsBytes: bit i <-> base i ; getInEdgesAsBytes: bit (3-i) <-> base i ;
-            // complement=true relabels base b as 3-b (CortexRecord.java:214-275)
-            uint32_t fwd = !fj ? lo : hi;                      // successor base = bit position
-            uint32_t revn = !fj ? hi : lo;                     // predecessor base = 3 - bit position
-            uint32_t rev = ((revn & 1u) << 3) | ((revn & 2u) << 1) | ((revn & 4u) >> 1) | ((revn & 8u) >> 3);
-            if ((e.trav_mask >> col) & 1u) { tf |= fwd; tr |= rev; }
-            if ((e.recruit_mask >> col) & 1u) { rf |= fwd; rr |= rev; }
-        }
-    } else if (e.recruit_mask != 0) {
-        n.npe = 1;
+    for (int col = 0; col < g.C; col++) {
+        const uint32_t ebyte = col < 4 ? (edges4 >> (8 * col)) & 0xffu : (uint32_t)more[col];
+        const uint32_t lo = ebyte & 0xf, hi = ebyte >> 4;
+        // CortexRecord.getOutEdgesAsBytes: bit i <-> base i ; getInEdgesAsBytes: bit (3-i) <-> base i ;
+        // complement=true relabels base b as 3-b (CortexRecord.java:214-275)
+        const uint32_t fwd = !fj ? lo : hi;                      // successor base = bit position
+        const uint32_t revn = !fj ? hi : lo;                     // predecessor base = 3 - bit position
+        const uint32_t rev = ((revn & 1u) << 3) | ((revn & 2u) << 1) | ((revn & 4u) >> 1) | ((revn & 8u) >> 3);
+        if ((e.trav_mask >> col) & 1u) { tf |= fwd; tr |= rev; }
+        if ((e.recruit_mask >> col) & 1u) { rf |= fwd; rr |= rev; }
     }
     n.next_mask = (uint8_t)(tf ? tf : rf);    // recruitment colours only where the traversal colours give nothing
     n.prev_mask = (uint8_t)(tr ? tr : rr);
+}
+LDBG_HOSTDEV void node_fill(const EngineView& e, Node& n) {
+    const GraphView& g = e.g;
+    if (n.idx >= 0) {
+        const uint8_t* row = graph_row(g, n.idx);
+        const uint8_t* ed = row + g.edges_off;
+        uint32_t edges4 = 0;
+        for (int col = 0; col < g.C && col < 4; col++) edges4 |= (uint32_t)ed[col] << (8 * col);
+        node_fill_bytes(e, n, edges4, ed, row[g.flags_off]);
+    } else {
+        n.npe = e.recruit_mask != 0 ? 1 : 0; n.lflags = 0; n.fj = n.flip;
+        n.next_mask = n.prev_mask = 0;
+    }
 }
 
 // neighbour `base` of vertex p in travel direction `fwd`, through the neighbour index of p's probe row
@@ -234,16 +241,29 @@ LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const No
     uint64_t key = 0, e0 = 0;
     uint32_t h = 0;
     if (early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = t.tab[h]; }
-    // the whole neighbour index of the row travels with it (same cache line): whichever entry the next step needs is here
+    // The row is read in three wide loads (the table lays it out for that: W x u64 key | C edge bytes | flag byte | ... | 8 x u32
+    // neighbour index at a 16-byte boundary): one word with the edge bytes and the flag byte (C <= 3), and the whole neighbour
+    // index, so whichever entry the next step needs is already here.
     uint32_t nb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t ef = 0;
+    const bool packed = g.C <= 3 && (g.edges_off & 3) == 0 && (g.nbr_off & 15) == 0 && (g.stride & 15) == 0;
     if (n.idx >= 0) {
-        const uint32_t* nbp = (const uint32_t*)(graph_row(g, n.idx) + g.nbr_off);
+        const uint8_t* row = graph_row(g, n.idx);
+        if (packed) {
+            struct alignas(16) U4 { uint32_t x, y, z, w; };
+            const U4 a = *(const U4*)(row + g.nbr_off), b = *(const U4*)(row + g.nbr_off + 16);
+            ef = *(const uint32_t*)(row + g.edges_off);
+            nb[0] = a.x; nb[1] = a.y; nb[2] = a.z; nb[3] = a.w; nb[4] = b.x; nb[5] = b.y; nb[6] = b.z; nb[7] = b.w;
+        } else {
+            const uint32_t* nbp = (const uint32_t*)(row + g.nbr_off);
 #pragma unroll
-        for (int q = 0; q < 8; q++) nb[q] = nbp[q];
+            for (int q = 0; q < 8; q++) nb[q] = nbp[q];
+        }
     }
     if (n.idx >= 0 && !(g.k & 1) && (graph_row(g, n.idx)[g.flags_off] & LDBG_ROW_PALINDROME)) flip = false;   // rc(x) == x
     n.flip = flip ? 1 : 0;
-    node_fill(e, n);
+    if (n.idx >= 0 && packed) node_fill_bytes(e, n, ef & ((1u << (8 * g.C)) - 1u), nullptr, (uint8_t)(ef >> (8 * g.C)));
+    else node_fill(e, n);
     if (n.idx >= 0) {
         const uint32_t m = fwd ? n.next_mask : n.prev_mask;
         if (popc4(m) == 1) {
