@@ -172,7 +172,12 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
         }
         wave_grow_tables(a, st, active);
         const bool lean = active && lean_ok(a, st);
-        if (lean) lean_step<W>(a, st, ls);
+        if (lean) {
+            // a short run of lean steps without going round the outer loop (its ballots, refill and regrowth checks): every lean
+            // step claims at most one table slot, and the regrowth check above leaves room for eight
+            lean_step<W>(a, st, ls);
+            for (int r = 1; r < 8 && lean_ok(a, st); r++) lean_step<W>(a, st, ls);
+        }
         if (wave_ballot(active && !lean) == 0ull) continue;          // the whole wavefront took the lean step
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
         const bool cur_mode = active && !lean && st.status == ST_OK && a.e.cursor_on && st.cu.has;
