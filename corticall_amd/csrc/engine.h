@@ -16,6 +16,7 @@ namespace ldbg {
 struct EngineView {
     GraphView g;
     uint32_t trav_mask, recruit_mask, join_mask;
+    uint32_t trav_sel4, recruit_sel4;   // the same masks for colours 0..3 as byte selectors (0xFF per selected colour) over packed edge bytes
     int first_trav;
     int stopper, max_len, connect_all, strict_flip;
     int cursor_on;        // !ec.getLinks().isEmpty(): dfs drives the cursor (TraversalEngine.java:363, 379) even
@@ -88,18 +89,22 @@ LDBG_HOSTDEV void node_fill_bytes(const EngineView& e, Node& n, uint32_t edges4,
     // isFlipped() is false for a reverse-complemented k-mer whose two orientations hash alike (Q6)
     if (e.strict_flip && (fl & LDBG_ROW_HASH_COLLISION)) n.fj = 0;
     const bool fj = n.fj != 0;
-    uint32_t tf = 0, tr = 0, rf = 0, rr = 0;
-    for (int col = 0; col < g.C; col++) {
-        const uint32_t ebyte = col < 4 ? (edges4 >> (8 * col)) & 0xffu : (uint32_t)more[col];
-        const uint32_t lo = ebyte & 0xf, hi = ebyte >> 4;
-        // CortexRecord.getOutEdgesAsBytes: bit i <-> base i ; getInEdgesAsBytes: bit (3-i) <-> base i ;
-        // complement=true relabels base b as 3-b (CortexRecord.java:214-275)
-        const uint32_t fwd = !fj ? lo : hi;                      // successor base = bit position
-        const uint32_t revn = !fj ? hi : lo;                     // predecessor base = 3 - bit position
-        const uint32_t rev = ((revn & 1u) << 3) | ((revn & 2u) << 1) | ((revn & 4u) >> 1) | ((revn & 8u) >> 3);
-        if ((e.trav_mask >> col) & 1u) { tf |= fwd; tr |= rev; }
-        if ((e.recruit_mask >> col) & 1u) { rf |= fwd; rr |= rev; }
+    // Every colour's edge byte goes through the same nibble selection, so the union over the selected colours can be taken on
+    // the bytes first: OR of the traversal (recruitment) colours' bytes, then one nibble split.
+    // CortexRecord.getOutEdgesAsBytes: bit i <-> base i ; getInEdgesAsBytes: bit (3-i) <-> base i ; complement=true relabels
+    // base b as 3-b (CortexRecord.java:214-275)
+    uint32_t tb = edges4 & e.trav_sel4, rb = edges4 & e.recruit_sel4;
+    tb |= tb >> 16; tb |= tb >> 8; rb |= rb >> 16; rb |= rb >> 8;
+    for (int col = 4; col < g.C; col++) {
+        if ((e.trav_mask >> col) & 1u) tb |= more[col];
+        if ((e.recruit_mask >> col) & 1u) rb |= more[col];
     }
+    tb &= 0xffu; rb &= 0xffu;
+    const uint32_t tfw = !fj ? tb & 0xf : tb >> 4, trn = !fj ? tb >> 4 : tb & 0xf;      // successor base = bit position
+    const uint32_t rfw = !fj ? rb & 0xf : rb >> 4, rrn = !fj ? rb >> 4 : rb & 0xf;      // predecessor base = 3 - bit position
+    const uint32_t tf = tfw, rf = rfw;
+    const uint32_t tr = ((trn & 1u) << 3) | ((trn & 2u) << 1) | ((trn & 4u) >> 1) | ((trn & 8u) >> 3);
+    const uint32_t rr = ((rrn & 1u) << 3) | ((rrn & 2u) << 1) | ((rrn & 4u) >> 1) | ((rrn & 8u) >> 3);
     n.next_mask = (uint8_t)(tf ? tf : rf);    // recruitment colours only where the traversal colours give nothing
     n.prev_mask = (uint8_t)(tr ? tr : rr);
 }

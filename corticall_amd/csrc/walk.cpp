@@ -397,6 +397,11 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     for (int i = 0; i < c.n_traversal; i++) view.trav_mask |= 1u << c.traversal_colors[i];
     for (int i = 0; i < c.n_recruitment; i++) view.recruit_mask |= 1u << c.recruitment_colors[i];
     for (int i = 0; i < c.n_joining; i++) view.join_mask |= 1u << c.joining_colors[i];
+    view.trav_sel4 = view.recruit_sel4 = 0;
+    for (int col = 0; col < 4; col++) {
+        if ((view.trav_mask >> col) & 1u) view.trav_sel4 |= 0xFFu << (8 * col);
+        if ((view.recruit_mask >> col) & 1u) view.recruit_sel4 |= 0xFFu << (8 * col);
+    }
     view.first_trav = c.traversal_colors[0];
     view.stopper = c.stopping_rule;
     view.max_len = c.max_branch_length;
