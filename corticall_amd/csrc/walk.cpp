@@ -96,29 +96,30 @@ LDBG_DEV void lean_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) {
     st.iters++;
     Node& cv = st.cv;
     Node av = st.cu.nxt;                               // next()/previous(): step onto it (TraversalEngine.java:241-279)
-    st.cu.cur = av;
     Node x;                                            // its only successor, one step ahead
     node_from_entry(e, st.vt, av, av.ent1, lowbit4(fwd ? av.next_mask : av.prev_mask), fwd, x);
+    // lean_ok() made sure cv and av are different vertices; x can be either of them (a walk turning round on a 1- or 2-cycle):
+    // only then do the cached table entries need patching (node_sync) — the order of reads and writes is the general step's
+    const bool alias = x.vslot == cv.vslot || x.vslot == av.vslot;
     bool has = false;
     const bool seen = vt_seen_e(x.vent, st.cu.epoch);
     if (!seen || ls.n > 0) {                           // :262
-        if (!seen) { node_store(st.vt, x, vt_with_seen(x.vent, st.cu.epoch)); node_sync(st.cu.cur, x); }
-        st.cu.nxt = x;
+        if (!seen) node_store(st.vt, x, vt_with_seen(x.vent, st.cu.epoch));
         has = true;
     }
-    st.cu.has = has;
     if (ls_num_new(ls) > 0) ls_increment_ages(ls);     // :274-276 (Q12)
-    if (has) { node_sync(cv, st.cu.nxt); node_sync(av, st.cu.nxt); }
+    if (alias && has) { node_sync(cv, x); node_sync(av, x); }
     const int cnt = node_count(av);                    // first unused copyIndex :383-389
     av.copy = fwd ? cnt : -cnt;
     const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
     node_store(st.vt, cv, vt_with_count(cv.vent, acopy + 1));      // visited.add(cv) :425
-    node_sync(av, cv); node_sync(st.cu.cur, cv);
-    if (has) node_sync(st.cu.nxt, cv);
+    if (alias && has) node_sync(x, cv);
     st.pw.cur[st.pw.n & (LDBG_PATH_BLOCK - 1)] = pack_vertex(av);   // connectVertex(g, cv, {av}) :432-440
     st.pw.n++;
     st.gV++;
     cv = av;
+    st.cu.has = has;
+    if (has) st.cu.nxt = x;
 }
 
 // BS = lanes per workgroup (a full or partial wavefront).  Fewer lanes per wavefront = fewer strands whose link-store
@@ -177,6 +178,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             // step claims at most one table slot, and the regrowth check above leaves room for eight
             lean_step<W>(a, st, ls);
             for (int r = 1; r < 8 && lean_ok(a, st); r++) lean_step<W>(a, st, ls);
+            st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
         if (wave_ballot(active && !lean) == 0ull) continue;          // the whole wavefront took the lean step
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
