@@ -188,9 +188,10 @@ struct VisitedTable {
     uint32_t used;   // claimed slots
 };
 #define LDBG_VT_KEY_MASK 0x3FFFFFFFFull
-LDBG_HOSTDEV uint32_t vt_hash(uint64_t key) {
-    uint64_t x = key * 0x9E3779B97F4A7C15ull;
-    return (uint32_t)(x >> 32);
+LDBG_HOSTDEV uint32_t vt_hash(uint64_t key) {      // keys are 34 bits; the table index is taken from the LOW bits of this
+    uint32_t x = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;      // 32-bit finaliser: every input bit reaches the low bits
+    return x;
 }
 LDBG_HOSTDEV uint64_t vt_key(int64_t idx, bool flip) { return ((uint64_t)(idx + 1) << 1) | (flip ? 1ull : 0ull); }
 // slot of (idx, flip); claims a free slot (count 0, not seen) if the vertex is not in the table yet

@@ -78,7 +78,7 @@ LDBG_DEV bool lean_ok(const WalkArgs& a, const StrandState& st) {
     const Cursor& cu = st.cu;
     const Node& cv = st.cv;
     const Node& t = cu.nxt;
-    if (!(st.status == ST_OK && a.e.cursor_on && cu.has && !cu.first)) return false;
+    if (!(st.status == ST_OK && a.e.cursor_on && cu.has && !cu.first && (a.e.g.k & 1))) return false;   // odd k: no palindromic k-mers
     const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
     return st.gV >= 2 && st.gV <= (uint32_t)a.e.max_len                            // not the first step, not at the maxLength cut
         && cv.idx >= 0 && t.idx >= 0 && !t.npe && cv.flip == cv.fj && t.flip == t.fj   // records present, no quirk-Q6 vertex
@@ -86,8 +86,16 @@ LDBG_DEV bool lean_ok(const WalkArgs& a, const StrandState& st) {
         && !(t.lflags & a.e.link_flag_mask)                                         // no links to add
         && cv.vslot != t.vslot                                                      // not standing on the vertex it looks at
         && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767                       // cv not visited before, copies in range
-        && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u                                  // room in the current path block
-        && (a.e.g.k & 1);                                                           // odd k: no palindromic k-mers
+        && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u;                                 // room in the current path block
+}
+// between two lean steps of a run: what a lean step can change
+LDBG_DEV bool lean_again(const WalkArgs& a, const StrandState& st) {
+    const Node& cv = st.cv;
+    const Node& t = st.cu.nxt;
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    return st.cu.has && st.gV <= (uint32_t)a.e.max_len && !t.npe && t.flip == t.fj && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u
+        && !(t.lflags & a.e.link_flag_mask) && cv.vslot != t.vslot && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767
+        && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u;
 }
 template <int W>
 LDBG_DEV void lean_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) {
@@ -177,7 +185,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             // a short run of lean steps without going round the outer loop (its ballots, refill and regrowth checks): every lean
             // step claims at most one table slot, and the regrowth check above leaves room for eight
             lean_step<W>(a, st, ls);
-            for (int r = 1; r < 8 && lean_ok(a, st); r++) lean_step<W>(a, st, ls);
+            for (int r = 1; r < 8 && lean_again(a, st); r++) lean_step<W>(a, st, ls);
             st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
         if (wave_ballot(active && !lean) == 0ull) continue;          // the whole wavefront took the lean step
