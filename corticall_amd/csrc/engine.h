@@ -363,8 +363,8 @@ LDBG_HOSTDEV bool ls_key_alive(const LinkStoreDev& s, uint32_t key_seq, uint32_t
 // of the canonical key; JuncRec.is_fw is stored as "link goes forward when the query is the canonical k-mer".
 // s.nkeys = HashMap.size() is maintained incrementally (new key: +1 here; last element of a key expiring: -1 in
 // ls_next_choice); the table doubles when a put() pushes it past 3/4 of the table size (HashMap.resize).
-LDBG_HOSTDEV void ls_add(const LinksView& L, LinkStoreDev& s, int64_t m, bool query_flipped, bool fwd) {
-    for (uint32_t j = L.off[m]; j < L.off[m + 1]; j++) {
+LDBG_HOSTDEV void ls_add(const LinksView& L, LinkStoreDev& s, uint32_t jlo, uint32_t jhi, bool query_flipped, bool fwd) {
+    for (uint32_t j = jlo; j < jhi; j++) {
         const JuncRec jr = L.junc[j];
         bool lgf = ((jr.is_fw & 1u) != 0) != query_flipped;    // recordOrientationMatchesKmer == cjr.isForward() :24
         if (lgf != fwd) continue;
@@ -479,8 +479,8 @@ struct Cursor {
 template <int W>
 LDBG_HOSTDEV void cursor_add_links(const EngineView& e, LinkStoreDev& s, const Node& v, bool fwd) {
     if (!(v.lflags & e.link_flag_mask)) return;
-    const uint32_t m = e.links.rec_of[v.idx];
-    if (m != 0xFFFFFFFFu) ls_add(e.links, s, (int64_t)m, v.flip != 0, fwd);
+    const uint64_t m = e.links.rec_of[v.idx];
+    if (m != ~0ull) ls_add(e.links, s, (uint32_t)m, (uint32_t)m + (uint32_t)(m >> 32), v.flip != 0, fwd);
 }
 // seek(sk): cursor on v, unique neighbour in direction `fwd` looked up (TraversalEngine.java:321-335)
 LDBG_HOSTDEV void cursor_seek(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, const Node& v, bool fwd) {

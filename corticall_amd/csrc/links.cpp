@@ -156,10 +156,10 @@ LDBG_KERNEL void k_set_link_flags(GraphView g, uint8_t* probe, const uint64_t* k
     }
 }
 
-// rec_of[record] = merged link record of that graph record (0xFFFFFFFF: none): a walk standing on a record finds its links
+// rec_of[record] = the junction records of that graph record as (first | count << 32), ~0 = none: a walk standing on a record finds its links
 // with one load instead of a search of the link table
 template <int W>
-LDBG_KERNEL void k_link_rec_of(GraphView g, const uint64_t* keys, int64_t M, uint32_t* rec_of) {
+LDBG_KERNEL void k_link_rec_of(GraphView g, const uint64_t* keys, int64_t M, const uint32_t* off, uint64_t* rec_of) {
     for (int64_t i = global_tid(); i < M; i += global_nthreads()) {
         Kmer<W> q;
 #pragma unroll
@@ -167,7 +167,7 @@ LDBG_KERNEL void k_link_rec_of(GraphView g, const uint64_t* keys, int64_t M, uin
         GraphView exact = g;
         exact.java_tiny = 0;
         int64_t idx = graph_find_canonical<W>(exact, q);
-        if (idx >= 0) rec_of[idx] = (uint32_t)i;
+        if (idx >= 0) rec_of[idx] = (uint64_t)off[i] | ((uint64_t)(off[i + 1] - off[i]) << 32);
     }
 }
 
@@ -391,19 +391,19 @@ MergedLinks::MergedLinks(const std::vector<const Links*>& sets, const Graph& g) 
     d_junc_ = up(junc.data(), junc.size() * sizeof(JuncRec));
     d_bases_ = up(bases.data(), bases.size());
     const int64_t N = g.view.N;
-    d_rec_of_ = rt::dmalloc((size_t)std::max<int64_t>(1, N) * 4);
-    rt::dmemset(d_rec_of_, 0xFF, (size_t)std::max<int64_t>(1, N) * 4, s);
+    d_rec_of_ = rt::dmalloc((size_t)std::max<int64_t>(1, N) * 8);
+    rt::dmemset(d_rec_of_, 0xFF, (size_t)std::max<int64_t>(1, N) * 8, s);
     if (M > 0) {
         const int grid = (int)std::min<int64_t>((M + 255) / 256, 2048);
         switch (W) {
-            case 1: LDBG_LAUNCH(k_link_rec_of<1>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (uint32_t*)d_rec_of_); break;
-            case 2: LDBG_LAUNCH(k_link_rec_of<2>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (uint32_t*)d_rec_of_); break;
-            case 3: LDBG_LAUNCH(k_link_rec_of<3>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (uint32_t*)d_rec_of_); break;
-            default: LDBG_LAUNCH(k_link_rec_of<4>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (uint32_t*)d_rec_of_); break;
+            case 1: LDBG_LAUNCH(k_link_rec_of<1>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (const uint32_t*)d_off_, (uint64_t*)d_rec_of_); break;
+            case 2: LDBG_LAUNCH(k_link_rec_of<2>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (const uint32_t*)d_off_, (uint64_t*)d_rec_of_); break;
+            case 3: LDBG_LAUNCH(k_link_rec_of<3>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (const uint32_t*)d_off_, (uint64_t*)d_rec_of_); break;
+            default: LDBG_LAUNCH(k_link_rec_of<4>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (const uint32_t*)d_off_, (uint64_t*)d_rec_of_); break;
         }
     }
     rt::stream_sync(s);
-    view.rec_of = (const uint32_t*)d_rec_of_;
+    view.rec_of = (const uint64_t*)d_rec_of_;
     view.M = M;
     view.keys = (const uint8_t*)d_keys_;
     view.pstart = (const uint32_t*)d_pstart_;

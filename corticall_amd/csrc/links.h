@@ -32,7 +32,7 @@ struct LinksView {
     const uint32_t* off;      // [M+1]
     const JuncRec* junc;      // per key: set after set (order of addition), each in HashSet iteration order
     const uint8_t* bases;
-    const uint32_t* rec_of;   // [graph records] merged link record of a graph record, 0xFFFFFFFF = none
+    const uint64_t* rec_of;   // [graph records] junction records of a graph record: first | count << 32 ; ~0 = none
 };
 
 struct HostJunction {

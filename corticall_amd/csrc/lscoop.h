@@ -43,9 +43,9 @@ LDBG_DEV void lsw_store_header(LinkStoreDev& s, const LsHdr& h) {
 
 // what an owner lane fetched for its add before the wavefront turns to it (all owners fetch at once)
 struct AddPre { uint32_t jlo, jhi; JuncRec r0, r1; };
-LDBG_DEV AddPre add_prefetch(const LinksView& Lk, int64_t m) {
+LDBG_DEV AddPre add_prefetch(const LinksView& Lk, uint64_t m) {      // m = rec_of entry: first | count << 32
     AddPre p;
-    p.jlo = Lk.off[m]; p.jhi = Lk.off[m + 1];
+    p.jlo = (uint32_t)m; p.jhi = (uint32_t)m + (uint32_t)(m >> 32);
     p.r0 = Lk.junc[p.jlo];
     p.r1 = Lk.junc[p.jlo + 1 < p.jhi ? p.jlo + 1 : p.jlo];
     return p;
@@ -252,27 +252,28 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
     const uint32_t nmask = cur_mode ? (st.fwd ? st.cu.nxt.next_mask : st.cu.nxt.prev_mask) : 0u;
     const bool one_child = cur_mode && popc4(nmask) == 1;
     const bool flagged = cur_mode && (st.cu.nxt.lflags & e.link_flag_mask);
-    uint32_t m_cur = 0xFFFFFFFFu, m_nxt = 0xFFFFFFFFu, child_ent = 0;
+    uint64_t m_cur = ~0ull, m_nxt = ~0ull;
+    uint32_t child_ent = 0;
     if (flagged) m_nxt = e.links.rec_of[st.cu.nxt.idx];
     if (one_child) child_ent = st.cu.nxt.e1 ? st.cu.nxt.ent1 : node_child_entry(e, st.cu.nxt, st.fwd, lowbit4(nmask));
     if (cur_mode && st.cu.first && (st.cu.cur.lflags & e.link_flag_mask)) m_cur = e.links.rec_of[st.cu.cur.idx];
     AddPre ap_cur, ap_nxt;      // read only by the lanes that filled them (the flags below say which)
-    if (m_nxt != 0xFFFFFFFFu) { ap_nxt.jlo = e.links.off[m_nxt]; ap_nxt.jhi = e.links.off[m_nxt + 1]; }
+    if (m_nxt != ~0ull) { ap_nxt.jlo = (uint32_t)m_nxt; ap_nxt.jhi = (uint32_t)m_nxt + (uint32_t)(m_nxt >> 32); }
     pre.has_child = one_child;
     if (one_child) node_from_entry(e, st.vt, st.cu.nxt, child_ent, lowbit4(nmask), st.fwd, pre.child);
-    if (m_nxt != 0xFFFFFFFFu) {
+    if (m_nxt != ~0ull) {
         ap_nxt.r0 = e.links.junc[ap_nxt.jlo];
         ap_nxt.r1 = e.links.junc[ap_nxt.jlo + 1 < ap_nxt.jhi ? ap_nxt.jlo + 1 : ap_nxt.jlo];
     }
-    if (m_cur != 0xFFFFFFFFu) ap_cur = add_prefetch(e.links, (int64_t)m_cur);
+    if (m_cur != ~0ull) ap_cur = add_prefetch(e.links, m_cur);
     pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0;
-    unsigned long long need = wave_ballot(m_cur != 0xFFFFFFFFu || m_nxt != 0xFFFFFFFFu);
+    unsigned long long need = wave_ballot(m_cur != ~0ull || m_nxt != ~0ull);
     while (need) {
         const int L = __builtin_ctzll(need);
         need &= need - 1;
         LsHdr h = lsw_header(ls, L);
         const uint32_t flags = wave_bcast_u32((st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u) |
-                                              (m_cur != 0xFFFFFFFFu ? 8u : 0u) | (m_nxt != 0xFFFFFFFFu ? 16u : 0u), L);
+                                              (m_cur != ~0ull ? 8u : 0u) | (m_nxt != ~0ull ? 16u : 0u), L);
         if (flags & 8u) coop_add(e.links, lw, L, h, bcast_addpre(ap_cur, L), (flags & 1u) != 0, (flags & 4u) != 0);
         if ((flags & 16u) && !h.overflow) coop_add(e.links, lw, L, h, bcast_addpre(ap_nxt, L), (flags & 2u) != 0, (flags & 4u) != 0);
         if (wave_lane() == L) lsw_store_header(ls, h);
