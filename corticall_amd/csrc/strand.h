@@ -38,6 +38,7 @@ struct WalkArgs {
     uint32_t ecap;
     unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
+    unsigned long long* st_gen;     // diagnostics: [n_strands][2] ticks spent before general steps (prepare + cooperative phases), their number
 };
 #define LDBG_VT_INITIAL 4096u
 #ifndef LDBG_LS_FAST

@@ -189,10 +189,19 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
         if (wave_ballot(active && !lean) == 0ull) continue;          // the whole wavefront took the lean step
+#ifndef LDBG_HOSTSIM
+        const unsigned long long t_general = a.st_gen ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
         const bool cur_mode = active && !lean && st.status == ST_OK && a.e.cursor_on && st.cu.has;
         StepPre pre;
         coop_step_prepare<W>(a.e, st, ls, lw, cur_mode, pre);
+#ifndef LDBG_HOSTSIM
+        if (a.st_gen && active && !lean) {       // diagnostics: time this strand spends in general steps (prepare + cooperative phases + step)
+            a.st_gen[2 * st.s] += __builtin_amdgcn_s_memrealtime() - t_general;
+            a.st_gen[2 * st.s + 1] += 1;
+        }
+#endif
         if (active && !lean && strand_step<W>(a, st, ls, pre)) { strand_finish(a, st); active = false; }
     }
 #ifndef LDBG_HOSTSIM
@@ -626,7 +635,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     if (const char* ev = getenv("LDBG_VT_INITIAL")) a.vcap_init = std::max<uint32_t>(64u, next_pow2((uint64_t)atoll(ev)));   // tuning knob
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
 
-    a.wg_times = nullptr; a.st_times = nullptr;
+    a.wg_times = nullptr; a.st_times = nullptr; a.st_gen = nullptr;
     const bool want_times = getenv("LDBG_WG_TIMES") != nullptr;
     rt::Event e0, e1;
     e0.record(s);
@@ -646,6 +655,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     if (want_times) {
         a.wg_times = (unsigned long long*)rt::dmalloc((size_t)grid * 16); rt::dmemset(a.wg_times, 0, (size_t)grid * 16, s);
         a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
+        a.st_gen = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_gen, 0, (size_t)ns * 16, s);
     }
 #define LDBG_WALK_CASE(WW) \
     if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, a); \
@@ -701,6 +711,15 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         std::vector<int64_t> order(ns);
         for (int64_t i = 0; i < ns; i++) order[i] = i;
         std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return tt[2 * x + 1] - tt[2 * x] > tt[2 * y + 1] - tt[2 * y]; });
+        std::vector<unsigned long long> gen((size_t)ns * 2);
+        rt::d2h(gen.data(), a.st_gen, (size_t)ns * 16, s);
+        rt::stream_sync(s);
+        rt::dfree(a.st_gen);
+        for (int r = 0; r < 3 && r < ns; r++) {
+            int64_t i = order[r];
+            fprintf(stderr, "[ldbg] strand %lld: %llu of its %u steps went through the general step, %.1f ms there (%.2f us each, the step itself not included)\n",
+                    (long long)i, gen[2 * i + 1], iters[i], gen[2 * i] / 1e5, gen[2 * i + 1] ? gen[2 * i] / 100.0 / gen[2 * i + 1] : 0.0);
+        }
         for (int r = 0; r < 12 && r < ns; r++) {
             int64_t i = order[r];
             double ms = (tt[2 * i + 1] - tt[2 * i]) / 1e5;
