@@ -217,7 +217,7 @@ LDBG_DEV bool end_branch(const DfsArgs& a, DfsLane<W>& L, bool success) {
 
 // one micro-step; returns true when the strand has ended
 template <int W>
-LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t slot, const StepPre& pre) {
+LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t slot, const StepPre& pre, bool lean) {
     StrandState& st = L.st;
     const EngineView& e = a.w.e;
     const bool fwd = st.fwd;
@@ -278,12 +278,20 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
     }
 
     // ---- PH_ITER: one iteration of the do-loop :373-481
-    st.iters++;
     Node& cv = st.cv;
-    const uint32_t m = fwd ? cv.next_mask : cv.prev_mask;
     int adj = 0;
     uint32_t avs_mask = 0;
     Node av = cv;
+    bool previously = false;
+    if (lean) {
+        // the common case of a link-guided branch (lscoop.h: lean_cursor_ok): cursor step, copyIndex and visited.add(cv) without
+        // the general machinery; what follows — the stopping rule, connectVertex or the end of the branch — is the same
+        av = lean_cursor_advance<W>(e, st, ls);
+        st.cu.cur = av;
+        adj = 1;
+    } else {
+    st.iters++;
+    const uint32_t m = fwd ? cv.next_mask : cv.prev_mask;
     if (e.cursor_on && st.cu.has) {                     // :379-407
         av = cursor_step<W, true>(e, st.cu, ls, st.vt, fwd, &pre);   // its link-store part was done by the wavefront (lscoop.h)
         if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
@@ -304,12 +312,13 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
     }
     const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
     const uint64_t ecv = cv.idx >= 0 ? cv.vent : 0ull;
-    const bool previously = acopy < vt_count_e(ecv);    // :424
+    previously = acopy < vt_count_e(ecv);               // :424
     if (!previously && cv.idx >= 0) {
         if (acopy + 1 > 32767) { st.status = ST_COPY_OVERFLOW; return true; }
         node_store(st.vt, cv, vt_with_count(ecv, acopy + 1));   // visited.add(cv) :425
         node_sync(av, cv);
         if (e.cursor_on) { node_sync(st.cu.cur, cv); if (st.cu.has) node_sync(st.cu.nxt, cv); }
+    }
     }
     L.last_prev = previously;
     bool succ = false, keep = false;
@@ -413,10 +422,12 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
             }
         }
         wave_grow_tables(a.w, L.st, active);
-        const bool cur_mode = active && L.st.status == ST_OK && L.phase == PH_ITER && a.w.e.cursor_on && L.st.cu.has;
+        const bool lean = active && L.phase == PH_ITER && lean_cursor_ok(a.w.e, L.st);
+        const bool cur_mode = active && !lean && L.st.status == ST_OK && L.phase == PH_ITER && a.w.e.cursor_on && L.st.cu.has;
         StepPre pre;
-        coop_step_prepare<W>(a.w.e, L.st, ls, lw, cur_mode, pre);
-        if (active && dfs_step<W>(a, L, ls, slot, pre)) { strand_finish(a.w, L.st); active = false; }
+        pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0; pre.has_child = false;
+        if (wave_ballot(active && !lean) != 0ull) coop_step_prepare<W>(a.w.e, L.st, ls, lw, cur_mode, pre);
+        if (active && dfs_step<W>(a, L, ls, slot, pre, lean)) { strand_finish(a.w, L.st); active = false; }
     }
 }
 

@@ -289,4 +289,61 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
     }
 }
 
+// ---- the lean step.  Nearly all iterations of a link-guided walk or dfs branch are the same case: the cursor has a next
+// vertex, that vertex has one successor with a record, no link annotations, no junction, no quirk.  The general step
+// (coop_step_prepare + cursor_step + the kernel's own step) spends ~1000 instructions per iteration on its generality (PMC:
+// profiles/r01_walk_instructions.log) and a walk cannot go faster than its own instruction stream; this is the same
+// sequence of table reads and writes with the decisions taken out.  Any lane for which lean_cursor_ok() is false takes
+// the general step in the same iteration.
+LDBG_DEV bool lean_cursor_ok(const EngineView& e, const StrandState& st) {
+    const Cursor& cu = st.cu;
+    const Node& cv = st.cv;
+    const Node& t = cu.nxt;
+    if (!(st.status == ST_OK && e.cursor_on && cu.has && !cu.first && (e.g.k & 1))) return false;   // odd k: no palindromic k-mers
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    return cv.idx >= 0 && t.idx >= 0 && !t.npe && cv.flip == cv.fj && t.flip == t.fj   // records present, no quirk-Q6 vertex
+        && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u                                     // exactly one successor, and it has a record
+        && !(t.lflags & e.link_flag_mask)                                           // no links to add
+        && cv.vslot != t.vslot                                                      // not standing on the vertex it looks at
+        && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767;                      // cv not visited before, copies in range
+}
+// between two lean steps of a run: what a lean step can change
+LDBG_DEV bool lean_cursor_again(const EngineView& e, const StrandState& st) {
+    const Node& cv = st.cv;
+    const Node& t = st.cu.nxt;
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    return st.cu.has && !t.npe && t.flip == t.fj && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u
+        && !(t.lflags & e.link_flag_mask) && cv.vslot != t.vslot && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767;
+}
+// next()/previous() (TraversalEngine.java:241-279) onto cu.nxt with its only successor looked up one step ahead, then
+// visited.add(cv) (:425).  Returns the vertex stepped onto with its copyIndex (:383-389); the caller connects it and advances.
+template <int W>
+LDBG_DEV Node lean_cursor_advance(const EngineView& e, StrandState& st, LinkStoreDev& ls) {
+    const bool fwd = st.fwd;
+    st.iters++;
+    Node& cv = st.cv;
+    Node av = st.cu.nxt;
+    Node x;
+    node_from_entry(e, st.vt, av, av.ent1, lowbit4(fwd ? av.next_mask : av.prev_mask), fwd, x);
+    // lean_cursor_ok() made sure cv and av are different vertices; x can be either of them (a walk turning round on a 1- or
+    // 2-cycle): only then do the cached table entries need patching (node_sync) — the order of reads and writes is the general step's
+    const bool alias = x.vslot == cv.vslot || x.vslot == av.vslot;
+    bool has = false;
+    const bool seen = vt_seen_e(x.vent, st.cu.epoch);
+    if (!seen || ls.n > 0) {                           // :262
+        if (!seen) node_store(st.vt, x, vt_with_seen(x.vent, st.cu.epoch));
+        has = true;
+    }
+    if (ls_num_new(ls) > 0) ls_increment_ages(ls);     // :274-276 (Q12)
+    if (alias && has) { node_sync(cv, x); node_sync(av, x); }
+    const int cnt = node_count(av);
+    av.copy = fwd ? cnt : -cnt;
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    node_store(st.vt, cv, vt_with_count(cv.vent, acopy + 1));
+    if (alias && has) node_sync(x, cv);
+    st.cu.has = has;
+    if (has) st.cu.nxt = x;
+    return av;
+}
+
 }  // namespace ldbg

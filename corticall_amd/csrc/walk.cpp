@@ -68,66 +68,22 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, 
     return false;
 }
 
-// ---- the lean step.  Nearly all iterations of a link-guided walk are the same case: the cursor has a next vertex, that
-// vertex has one successor with a record, no link annotations, no junction, no quirk, nothing ends or allocates.  The
-// general step (coop_step_prepare + cursor_step + strand_step) spends ~1000 instructions per iteration on its generality
-// (PMC: profiles/r01_walk_instructions.log) and a walk cannot go faster than its own instruction stream; this is the
-// same sequence of table reads and writes with the decisions taken out.  Any lane for which lean_ok() is false takes
-// the general step in the same iteration.
+// ---- the lean step (lscoop.h: lean_cursor_ok / lean_cursor_advance) as the walk kernel uses it: the cursor part, then
+// connectVertex + advance (:432-440) with nothing that can end the strand or allocate
 LDBG_DEV bool lean_ok(const WalkArgs& a, const StrandState& st) {
-    const Cursor& cu = st.cu;
-    const Node& cv = st.cv;
-    const Node& t = cu.nxt;
-    if (!(st.status == ST_OK && a.e.cursor_on && cu.has && !cu.first && (a.e.g.k & 1))) return false;   // odd k: no palindromic k-mers
-    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
-    return st.gV >= 2 && st.gV <= (uint32_t)a.e.max_len                            // not the first step, not at the maxLength cut
-        && cv.idx >= 0 && t.idx >= 0 && !t.npe && cv.flip == cv.fj && t.flip == t.fj   // records present, no quirk-Q6 vertex
-        && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u                                     // exactly one successor, and it has a record
-        && !(t.lflags & a.e.link_flag_mask)                                         // no links to add
-        && cv.vslot != t.vslot                                                      // not standing on the vertex it looks at
-        && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767                       // cv not visited before, copies in range
-        && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u;                                 // room in the current path block
+    return lean_cursor_ok(a.e, st) && st.gV >= 2 && st.gV <= (uint32_t)a.e.max_len       // not the first step, not at the maxLength cut
+        && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u;                                       // room in the current path block
 }
-// between two lean steps of a run: what a lean step can change
-LDBG_DEV bool lean_again(const WalkArgs& a, const StrandState& st) {
-    const Node& cv = st.cv;
-    const Node& t = st.cu.nxt;
-    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
-    return st.cu.has && st.gV <= (uint32_t)a.e.max_len && !t.npe && t.flip == t.fj && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u
-        && !(t.lflags & a.e.link_flag_mask) && cv.vslot != t.vslot && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767
-        && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u;
+LDBG_DEV bool lean_again(const WalkArgs& a, const StrandState& st) {                     // between two lean steps of a run
+    return lean_cursor_again(a.e, st) && st.gV <= (uint32_t)a.e.max_len && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u;
 }
 template <int W>
 LDBG_DEV void lean_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) {
-    const EngineView& e = a.e;
-    const bool fwd = st.fwd;
-    st.iters++;
-    Node& cv = st.cv;
-    Node av = st.cu.nxt;                               // next()/previous(): step onto it (TraversalEngine.java:241-279)
-    Node x;                                            // its only successor, one step ahead
-    node_from_entry(e, st.vt, av, av.ent1, lowbit4(fwd ? av.next_mask : av.prev_mask), fwd, x);
-    // lean_ok() made sure cv and av are different vertices; x can be either of them (a walk turning round on a 1- or 2-cycle):
-    // only then do the cached table entries need patching (node_sync) — the order of reads and writes is the general step's
-    const bool alias = x.vslot == cv.vslot || x.vslot == av.vslot;
-    bool has = false;
-    const bool seen = vt_seen_e(x.vent, st.cu.epoch);
-    if (!seen || ls.n > 0) {                           // :262
-        if (!seen) node_store(st.vt, x, vt_with_seen(x.vent, st.cu.epoch));
-        has = true;
-    }
-    if (ls_num_new(ls) > 0) ls_increment_ages(ls);     // :274-276 (Q12)
-    if (alias && has) { node_sync(cv, x); node_sync(av, x); }
-    const int cnt = node_count(av);                    // first unused copyIndex :383-389
-    av.copy = fwd ? cnt : -cnt;
-    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
-    node_store(st.vt, cv, vt_with_count(cv.vent, acopy + 1));      // visited.add(cv) :425
-    if (alias && has) node_sync(x, cv);
+    const Node av = lean_cursor_advance<W>(a.e, st, ls);
     st.pw.cur[st.pw.n & (LDBG_PATH_BLOCK - 1)] = pack_vertex(av);   // connectVertex(g, cv, {av}) :432-440
     st.pw.n++;
     st.gV++;
-    cv = av;
-    st.cu.has = has;
-    if (has) st.cu.nxt = x;
+    st.cv = av;
 }
 
 // BS = lanes per workgroup (a full or partial wavefront).  Fewer lanes per wavefront = fewer strands whose link-store
