@@ -54,6 +54,7 @@ struct DfsArgs {
     const int64_t* sink_off;       // [n + 1] (nullptr: no sinks)
     DfsFrame* frames;              // [n_slots][max_depth]
     int max_depth;
+    uint32_t iter_limit;           // loop iterations one seed and direction may take
     int n_trav;
     uint8_t trav_order[LDBG_MAX_COLORS];   // traversal colours in LinkedHashSet order
 };
@@ -223,6 +224,7 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
     const bool fwd = st.fwd;
     if (st.status != ST_OK) return true;
     if ((st.vt.used + 8) * 4 > (st.vt.mask + 1) * 3) { st.status = ST_TABLE_FULL; return true; }   // at its maximum size and filling up
+    if (st.iters > a.iter_limit) { st.status = ST_TABLE_FULL; return true; }   // a rule that neither succeeds nor fails on a cycle (the reference spins here)
 
     if (L.phase == PH_UNDO) {
         if (L.undo_left > 0) {
@@ -786,6 +788,8 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     a.env.sink_keys = d_sink_keys; a.env.sink_words = d_sink_words;
     a.sink_off = d_sink_off;
     a.max_depth = dfs_max_depth;
+    a.iter_limit = 1u << 26;
+    if (const char* ev = getenv("LDBG_DFS_ITER_LIMIT")) a.iter_limit = (uint32_t)std::max<long long>(1, atoll(ev));
     a.n_trav = 0;
     for (int i = 0; i < cfg.n_traversal; i++) {          // LinkedHashSet: first occurrence keeps its place
         bool dup = false;
@@ -826,7 +830,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             case ST_LINKSTORE_FULL: throw StatusError(LDBG_ERR_CAPACITY, "LINKSTORE_FULL");
             case ST_DEPTH_OVERFLOW: throw StatusError(LDBG_ERR_CAPACITY, "DEPTH_OVERFLOW");
             case ST_LOG_FULL: throw StatusError(LDBG_ERR_CAPACITY, "LOG_FULL");
-            case ST_TABLE_FULL: throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs visited more vertices along one chain of branches than the per-seed table holds" + where);
+            case ST_TABLE_FULL: throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs outgrew the per-seed visited table or its step limit (a rule that never stops on a cycle spins in the reference too)" + where);
             case ST_COPY_OVERFLOW: throw StatusError(LDBG_ERR_UNSUPPORTED, "a vertex was visited more than 32767 times in one branch chain" + where);
             default: break;
         }

@@ -7,6 +7,7 @@ import os
 import random
 
 import numpy as np
+import pytest
 
 import corticall_amd as ca
 from corticall_amd import (AND, BOTH, FORWARD, OR, REVERSE, ContigStopper, CortexGraph, CortexLinks,
@@ -882,3 +883,18 @@ def case_join(orc, lib, tmp):
         assert False
     except ca.CortexJDKException as ex:
         assert "Graph kmer sizes are not equal" in str(ex)
+
+
+def case_dfs_step_limit(orc, lib, tmp, monkeypatch):
+    """a rule that ignores maxLength on a cycle with links never returns in the reference; the device path gives up after its step
+    limit instead of spinning"""
+    rng = random.Random(3)
+    unit = rand_seq(rng, 9)
+    g1 = rand_seq(rng, 40) + unit * 8 + rand_seq(rng, 40)
+    cs = Case(orc, tmp, lib, [("a", [g1])], 5, link_samples=["a"], reads={"a": [g1[i:] for i in range(0, len(g1) - 30, 3)]}, name="spin")
+    monkeypatch.setenv("LDBG_DFS_ITER_LIMIT", "5000")
+    f = (TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).links(cs.links["a"]).stoppingRule("GapClosingStopper"))
+    e = f.make()
+    with pytest.raises(ca.LdbgError) as ex:
+        e.dfs_batch(cs.all_kmers()[:20]).graphs()
+    assert "step limit" in str(ex.value)

@@ -137,3 +137,6 @@ def test_sharded_walks_one_rank_rccl(orc, lib, tmp_path):
         sg.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_dfs_step_limit(orc, lib, tmp_path, monkeypatch): pc.case_dfs_step_limit(orc, lib, tmp_path, monkeypatch)

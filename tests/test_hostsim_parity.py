@@ -75,3 +75,6 @@ def test_batch_splitting_on_a_small_device(orc, lib, tmp_path, monkeypatch):
     pc.case_long_walks(orc, lib, tmp_path)
     pc.case_dfs_dense(orc, lib, tmp_path, 1)
     pc.case_partition(orc, lib, tmp_path, 31, 2, True)
+
+
+def test_dfs_step_limit(orc, lib, tmp_path, monkeypatch): pc.case_dfs_step_limit(orc, lib, tmp_path, monkeypatch)
