@@ -19,6 +19,7 @@ struct EngineView {
     uint32_t trav_sel4, recruit_sel4;   // the same masks for colours 0..3 as byte selectors (0xFF per selected colour) over packed edge bytes
     int first_trav;
     int stopper, max_len, connect_all, strict_flip;
+    int lean_rows;        // odd k and the packed row layout (row_is_packed): the lean step's row reads carry no layout tests
     int cursor_on;        // !ec.getLinks().isEmpty(): dfs drives the cursor (TraversalEngine.java:363, 379) even
                           // when none of the configured link sets belongs to a traversal sample
     uint32_t link_flag_mask;   // probe-row link-flag bits of the link sets merged into `links`
@@ -76,12 +77,17 @@ struct Node {
     uint8_t prev_mask;   // bit b: predecessor b+o[:-1]
     uint8_t base;        // base that was appended to reach this vertex (travel direction)
     uint8_t e1;          // ent1 is valid
+#ifdef LDBG_LEAN_PROFILE
+    unsigned long long p1, p2;   // (experiment build only) clock after the row loads were issued / after they returned
+#endif
     uint32_t ent1;       // neighbour-index entry of the vertex's only neighbour in the direction it was reached in (it comes
                          // with the row, so the next step starts without a load)
 };
 
 // edges of the node's record -> neighbour masks; link flags; Java flip from the record's collision bit
 // `edges4`: the edge bytes of colours 0..3 packed into one word (byte c = colour c), `more`: the row's edge bytes for c >= 4
+// FEW: the graph has at most 4 colours (known where the call is compiled), `more` is not read
+template <bool FEW = false>
 LDBG_HOSTDEV void node_fill_bytes(const EngineView& e, Node& n, uint32_t edges4, const uint8_t* more, uint8_t fl) {
     const GraphView& g = e.g;
     n.npe = 0; n.fj = n.flip;
@@ -95,10 +101,11 @@ LDBG_HOSTDEV void node_fill_bytes(const EngineView& e, Node& n, uint32_t edges4,
     // base b as 3-b (CortexRecord.java:214-275)
     uint32_t tb = edges4 & e.trav_sel4, rb = edges4 & e.recruit_sel4;
     tb |= tb >> 16; tb |= tb >> 8; rb |= rb >> 16; rb |= rb >> 8;
-    for (int col = 4; col < g.C; col++) {
-        if ((e.trav_mask >> col) & 1u) tb |= more[col];
-        if ((e.recruit_mask >> col) & 1u) rb |= more[col];
-    }
+    if (!FEW)
+        for (int col = 4; col < g.C; col++) {
+            if ((e.trav_mask >> col) & 1u) tb |= more[col];
+            if ((e.recruit_mask >> col) & 1u) rb |= more[col];
+        }
     tb &= 0xffu; rb &= 0xffu;
     const uint32_t tfw = !fj ? tb & 0xf : tb >> 4, trn = !fj ? tb >> 4 : tb & 0xf;      // successor base = bit position
     const uint32_t rfw = !fj ? rb & 0xf : rb >> 4, rrn = !fj ? rb >> 4 : rb & 0xf;      // predecessor base = 3 - bit position
@@ -199,22 +206,44 @@ LDBG_HOSTDEV uint64_t vt_key(int64_t idx, bool flip) { return ((uint64_t)(idx + 
 struct LsDebug { uint64_t adds = 0, newkeys = 0, choices = 0, scan = 0, maxn = 0, steps = 0, sum_n = 0; };
 inline LsDebug& ls_debug() { static LsDebug d; return d; }
 #endif
-// probe from slot h, whose entry e has already been read; returns the slot and its entry
-LDBG_HOSTDEV uint32_t vt_probe_from(VisitedTable& t, uint64_t key, uint32_t h, uint64_t e, uint64_t* ent) {
+// Linear probing, four slots per round: the entries at h .. h+3 are read together (one trip to memory; they share a cache
+// line or two), and the first of them that is free or holds the key decides.  A wavefront waits for the longest probe chain
+// among its 64 strands at every step, so what counts is the number of ROUNDS, not of entries read.
+struct VtPeek { uint64_t e[4]; };
+LDBG_HOSTDEV VtPeek vt_peek(const VisitedTable& t, uint32_t h) {
+    VtPeek p;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) p.e[q] = LDBG_GLOBAL(const uint64_t, t.tab)[(h + q) & t.mask];
+    return p;
+}
+// probe from slot h, whose round `pk` has already been read; returns the slot and its entry
+LDBG_HOSTDEV uint32_t vt_probe_from(VisitedTable& t, uint64_t key, uint32_t h, VtPeek pk, uint64_t* ent) {
     while (true) {
 #ifdef LDBG_HOSTSIM
         ls_debug().scan++;
 #endif
-        if (e == 0) { t.tab[h] = key; t.used++; *ent = key; return h; }
-        if ((e & LDBG_VT_KEY_MASK) == key) { *ent = e; return h; }
-        h = (h + 1) & t.mask;
-        e = t.tab[h];
+        uint32_t q = 4;
+        uint64_t ev = 0;
+#pragma unroll
+        for (int i = 3; i >= 0; i--) {
+            const bool stop = pk.e[i] == 0 || (pk.e[i] & LDBG_VT_KEY_MASK) == key;
+            q = stop ? (uint32_t)i : q;
+            ev = stop ? pk.e[i] : ev;
+        }
+        if (q < 4) {
+            const uint32_t slot = (h + q) & t.mask;
+            if (ev == 0) { LDBG_GLOBAL(uint64_t, t.tab)[slot] = key; t.used++; ev = key; }
+            *ent = ev;
+            return slot;
+        }
+        h = (h + 4) & t.mask;
+        pk = vt_peek(t, h);
     }
 }
 LDBG_HOSTDEV uint32_t vt_locate(VisitedTable& t, int64_t idx, bool flip, uint64_t* ent) {
     const uint64_t key = vt_key(idx, flip);
     const uint32_t h = vt_hash(key) & t.mask;
-    return vt_probe_from(t, key, h, t.tab[h], ent);
+    return vt_probe_from(t, key, h, vt_peek(t, h), ent);
 }
 LDBG_HOSTDEV int vt_count_e(uint64_t e) { return (int)((e >> 48) & 0x7FFFull); }
 #define LDBG_VT_EPOCH_MAX 0x3FFFu
@@ -224,7 +253,7 @@ LDBG_HOSTDEV uint64_t vt_with_count(uint64_t e, int c) { return (e & ~(0x7FFFull
 LDBG_HOSTDEV void node_locate(VisitedTable& t, Node& n) { if (n.idx >= 0) n.vslot = vt_locate(t, n.idx, n.flip != 0, &n.vent); }
 LDBG_HOSTDEV int node_count(const Node& n) { return n.idx >= 0 ? vt_count_e(n.vent) : 0; }
 // a write to the table: through the node that holds the slot ...
-LDBG_HOSTDEV void node_store(VisitedTable& t, Node& n, uint64_t val) { t.tab[n.vslot] = val; n.vent = val; }
+LDBG_HOSTDEV void node_store(VisitedTable& t, Node& n, uint64_t val) { LDBG_GLOBAL(uint64_t, t.tab)[n.vslot] = val; n.vent = val; }
 // ... and into every other live node that refers to the same vertex (a walk can stand on a k-mer and look at it)
 LDBG_HOSTDEV void node_sync(Node& n, const Node& written) { if (n.idx >= 0 && written.idx >= 0 && n.vslot == written.vslot) n.vent = written.vent; }
 // neighbour `base` of p, with its table slot.  The first probe of the table is issued before the neighbour's row is
@@ -237,23 +266,29 @@ LDBG_HOSTDEV uint32_t node_child_entry(const EngineView& e, const Node& p, bool 
 LDBG_HOSTDEV unsigned nbr_slot(bool fj, bool fwd, unsigned base) {
     return fwd ? (!fj ? base : 4u + (3u - base)) : (!fj ? 4u + base : (3u - base));
 }
+// LEAN: the caller has established that the row layout is the packed one (row_is_packed), k is odd and the entry names a
+// record, so none of that is tested here (the lean step, lscoop.h, whose run time is its instruction count)
+LDBG_HOSTDEV bool row_is_packed(const GraphView& g) { return g.C <= 3 && (g.edges_off & 3) == 0 && (g.nbr_off & 15) == 0 && (g.stride & 15) == 0; }
+template <bool LEAN = false>
 LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const Node& p, uint32_t ent, unsigned base, bool fwd, Node& n) {
     const GraphView& g = e.g;
     const bool fj = p.fj != 0;
     n.idx = (int32_t)(ent & 0x7FFFFFFFu) - 1;
     n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base; n.e1 = 0; n.ent1 = 0;
     bool flip = (((ent >> 31) & 1u) != 0) != fj;
-    const bool early = n.idx >= 0 && (g.k & 1);          // odd k: no palindromes
-    uint64_t key = 0, e0 = 0;
+    const bool rec = LEAN || n.idx >= 0;
+    const bool early = LEAN || (rec && (g.k & 1));       // odd k: no palindromes
+    uint64_t key = 0;
+    VtPeek e0 = {{0, 0, 0, 0}};
     uint32_t h = 0;
-    if (early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = t.tab[h]; }
+    if (early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = vt_peek(t, h); }
     // The row is read in three wide loads (the table lays it out for that: W x u64 key | C edge bytes | flag byte | ... | 8 x u32
     // neighbour index at a 16-byte boundary): one word with the edge bytes and the flag byte (C <= 3), and the whole neighbour
     // index, so whichever entry the next step needs is already here.
     uint32_t nb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t ef = 0;
-    const bool packed = g.C <= 3 && (g.edges_off & 3) == 0 && (g.nbr_off & 15) == 0 && (g.stride & 15) == 0;
-    if (n.idx >= 0) {
+    const bool packed = LEAN || row_is_packed(g);
+    if (rec) {
         const uint8_t* row = graph_row(g, n.idx);
         if (packed) {
             struct alignas(16) U4 { uint32_t x, y, z, w; };
@@ -266,20 +301,30 @@ LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const No
             for (int q = 0; q < 8; q++) nb[q] = nbp[q];
         }
     }
-    if (n.idx >= 0 && !(g.k & 1) && (graph_row(g, n.idx)[g.flags_off] & LDBG_ROW_PALINDROME)) flip = false;   // rc(x) == x
+    if (!LEAN && rec && !(g.k & 1) && (graph_row(g, n.idx)[g.flags_off] & LDBG_ROW_PALINDROME)) flip = false;   // rc(x) == x
+#ifdef LDBG_LEAN_PROFILE
+    if (LEAN) {
+        asm volatile("" ::: "memory");
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t2 = __builtin_readcyclecounter();
+        n.p1 = t1; n.p2 = t2;
+    }
+#endif
     n.flip = flip ? 1 : 0;
-    if (n.idx >= 0 && packed) node_fill_bytes(e, n, ef & ((1u << (8 * g.C)) - 1u), nullptr, (uint8_t)(ef >> (8 * g.C)));
+    if (LEAN) node_fill_bytes<true>(e, n, ef & ((1u << (8 * g.C)) - 1u), nullptr, (uint8_t)(ef >> (8 * g.C)));
+    else if (rec && packed) node_fill_bytes(e, n, ef & ((1u << (8 * g.C)) - 1u), nullptr, (uint8_t)(ef >> (8 * g.C)));
     else node_fill(e, n);
-    if (n.idx >= 0) {
+    if (rec) {
+        // (selected whatever the mask, so that the neighbour index is read together with the edge bytes, not after them)
         const uint32_t m = fwd ? n.next_mask : n.prev_mask;
-        if (popc4(m) == 1) {
-            const unsigned j = nbr_slot(n.fj != 0, fwd, lowbit4(m));
-            uint32_t v = nb[0];
+        const unsigned j = nbr_slot(n.fj != 0, fwd, lowbit4(m));
+        uint32_t v = nb[0];
 #pragma unroll
-            for (unsigned q = 1; q < 8; q++) v = j == q ? nb[q] : v;
-            n.ent1 = v; n.e1 = 1;
-        }
-        if (!early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = t.tab[h]; }
+        for (unsigned q = 1; q < 8; q++) v = j == q ? nb[q] : v;
+        const bool one = popc4(m) == 1;
+        n.ent1 = one ? v : 0u; n.e1 = one ? 1 : 0;
+        if (!early) { key = vt_key(n.idx, flip); h = vt_hash(key) & t.mask; e0 = vt_peek(t, h); }
         n.vslot = vt_probe_from(t, key, h, e0, &n.vent);
     }
 }

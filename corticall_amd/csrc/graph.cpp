@@ -1,6 +1,7 @@
 // Device graph: streaming upload of .ctx records, layout kernels, sortedness check, radix index,
 // and the two bulk DeBruijnGraph kernels (records = iteration/getRecord, find = findRecord).
 #include "graph.h"
+#include "links.h"
 
 #include <fcntl.h>
 #include <strings.h>
@@ -350,6 +351,7 @@ void Graph::upload(const uint8_t* recs) {
 }
 
 Graph::~Graph() {
+    for (Links* l : bound_links) l->graph_closed();
     rt::dfree(d_keys_); rt::dfree(d_cov_); rt::dfree(d_edges_); rt::dfree(d_probe_); rt::dfree(d_pstart_); rt::dfree(d_nbrg);
     rt::stream_destroy(stream);
 }

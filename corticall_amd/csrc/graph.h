@@ -98,6 +98,8 @@ public:
     int color_for_sample_name(const std::string& name) const;
     // link sets bound to this graph get a flag bit in the probe rows (at most 8)
     mutable uint32_t link_slots = 0;                 // bits of the flag byte in use
+    mutable std::vector<class Links*> bound_links;   // the sets holding those bits; told when the graph goes first (a
+                                                     // garbage collector closes handles in any order)
     uint8_t* probe_mutable() const { return (uint8_t*)d_probe_; }
     void* d_nbrg = nullptr;   // shard of a partitioned table: global neighbour index [N][8] u64 (shard.cpp)
 

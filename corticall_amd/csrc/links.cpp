@@ -293,6 +293,7 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
     g.link_slots |= 1u << slot;
     graph_ = &g;
     mark_records(false);
+    g.bound_links.push_back(this);
 }
 
 // set (or, when the link set is closed, clear) this set's bit on the records it has links for
@@ -321,7 +322,10 @@ void Links::mark_records(bool clear) {
 }
 
 Links::~Links() {
-    if (graph_ && slot >= 0) {
+    if (!graph_) return;
+    auto& bl = graph_->bound_links;
+    bl.erase(std::remove(bl.begin(), bl.end(), this), bl.end());
+    if (slot >= 0) {
         try { mark_records(true); } catch (...) {}
         graph_->link_slots &= ~(1u << slot);
     }

@@ -47,7 +47,8 @@ struct HostLinksRecord {
 class Links {
 public:
     Links(const std::string& path, const Graph& g);
-    ~Links();                                        // gives the flag bit back (the graph must still be open)
+    ~Links();                                        // gives the flag bit back if the graph is still open
+    void graph_closed() { graph_ = nullptr; }        // called by ~Graph
     int version = 0, num_colors = 0, k = 0;
     int64_t num_kmers_in_graph = 0, num_kmers_with_links = 0, num_links = 0, link_bytes = 0;
     std::vector<std::string> sample_names;

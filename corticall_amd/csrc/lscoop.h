@@ -324,7 +324,8 @@ LDBG_DEV Node lean_cursor_advance(const EngineView& e, StrandState& st, LinkStor
     Node& cv = st.cv;
     Node av = st.cu.nxt;
     Node x;
-    node_from_entry(e, st.vt, av, av.ent1, lowbit4(fwd ? av.next_mask : av.prev_mask), fwd, x);
+    if (e.lean_rows) node_from_entry<true>(e, st.vt, av, av.ent1, lowbit4(fwd ? av.next_mask : av.prev_mask), fwd, x);
+    else node_from_entry(e, st.vt, av, av.ent1, lowbit4(fwd ? av.next_mask : av.prev_mask), fwd, x);
     // lean_cursor_ok() made sure cv and av are different vertices; x can be either of them (a walk turning round on a 1- or
     // 2-cycle): only then do the cached table entries need patching (node_sync) — the order of reads and writes is the general step's
     const bool alias = x.vslot == cv.vslot || x.vslot == av.vslot;

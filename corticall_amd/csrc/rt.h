@@ -25,6 +25,13 @@
 #define LDBG_WAVE_KERNEL_N(n) __global__ __launch_bounds__(n)
 #define LDBG_DEV __device__ __forceinline__
 #define LDBG_HOSTDEV __host__ __device__ __forceinline__
+// a pointer known to be into HBM (a strand's pointers pass through lane broadcasts, which hide that from the compiler:
+// it would emit flat_ accesses, which also wait on the LDS counter)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LDBG_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
+#else
+#define LDBG_GLOBAL(T, p) (p)
+#endif
 
 namespace ldbg {
 namespace rt {
@@ -113,6 +120,7 @@ LDBG_DEV int wave_count_below(unsigned long long ballot) { return __builtin_popc
 #define LDBG_WAVE_KERNEL_N(n) static
 #define LDBG_DEV inline
 #define LDBG_HOSTDEV inline
+#define LDBG_GLOBAL(T, p) (p)
 #ifndef __forceinline__
 #define __forceinline__
 #endif

@@ -39,6 +39,9 @@ struct WalkArgs {
     unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
     unsigned long long* st_gen;     // diagnostics: [n_strands][2] ticks spent before general steps (prepare + cooperative phases), their number
+#ifdef LDBG_LEAN_PROFILE
+    unsigned long long* st_prof;
+#endif
 };
 #define LDBG_VT_INITIAL 4096u
 #ifndef LDBG_LS_FAST

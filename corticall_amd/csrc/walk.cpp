@@ -79,8 +79,18 @@ LDBG_DEV bool lean_again(const WalkArgs& a, const StrandState& st) {            
 }
 template <int W>
 LDBG_DEV void lean_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) {
+#ifdef LDBG_LEAN_PROFILE
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
     const Node av = lean_cursor_advance<W>(a.e, st, ls);
-    st.pw.cur[st.pw.n & (LDBG_PATH_BLOCK - 1)] = pack_vertex(av);   // connectVertex(g, cv, {av}) :432-440
+#ifdef LDBG_LEAN_PROFILE
+    if (a.st_gen && a.e.lean_rows) {     // [4s..]: issue, wait, rest (cycles), steps — read by hand from the diagnostics
+        const unsigned long long t3 = __builtin_readcyclecounter();
+        a.st_prof[4 * st.s] += st.cu.nxt.p1 - t0; a.st_prof[4 * st.s + 1] += st.cu.nxt.p2 - st.cu.nxt.p1;
+        a.st_prof[4 * st.s + 2] += t3 - st.cu.nxt.p2; a.st_prof[4 * st.s + 3] += 1;
+    }
+#endif
+    LDBG_GLOBAL(uint64_t, st.pw.cur)[st.pw.n & (LDBG_PATH_BLOCK - 1)] = pack_vertex(av);   // connectVertex(g, cv, {av}) :432-440
     st.pw.n++;
     st.gV++;
     st.cv = av;
@@ -140,8 +150,9 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
         if (lean) {
             // a short run of lean steps without going round the outer loop (its ballots, refill and regrowth checks): every lean
             // step claims at most one table slot, and the regrowth check above leaves room for eight
-            lean_step<W>(a, st, ls);
-            for (int r = 1; r < 8 && lean_again(a, st); r++) lean_step<W>(a, st, ls);
+            int r = 0;
+#pragma unroll 1
+            do { lean_step<W>(a, st, ls); } while (++r < 8 && lean_again(a, st));     // one copy of the step: the loop lives in the instruction cache
             st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
         if (wave_ballot(active && !lean) == 0ull) continue;          // the whole wavefront took the lean step
@@ -382,6 +393,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.max_len = c.max_branch_length;
     view.connect_all = c.connect_all_neighbors;
     view.strict_flip = c.strict_java_flip;
+    view.lean_rows = (view.g.k & 1) && row_is_packed(view.g) ? 1 : 0;
     // initializeLinkStore/updateLinkStore :548-597: only link sets whose colour-0 sample is a traversal sample
     for (int i = 0; i < c.nlinks; i++) {
         const Links* l = (const Links*)c.links[i];
@@ -612,6 +624,9 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         a.wg_times = (unsigned long long*)rt::dmalloc((size_t)grid * 16); rt::dmemset(a.wg_times, 0, (size_t)grid * 16, s);
         a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
         a.st_gen = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_gen, 0, (size_t)ns * 16, s);
+#ifdef LDBG_LEAN_PROFILE
+        a.st_prof = (unsigned long long*)rt::dmalloc((size_t)ns * 32); rt::dmemset(a.st_prof, 0, (size_t)ns * 32, s);
+#endif
     }
 #define LDBG_WALK_CASE(WW) \
     if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, a); \
@@ -671,6 +686,19 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         rt::d2h(gen.data(), a.st_gen, (size_t)ns * 16, s);
         rt::stream_sync(s);
         rt::dfree(a.st_gen);
+#ifdef LDBG_LEAN_PROFILE
+        {
+            std::vector<unsigned long long> pr((size_t)ns * 4);
+            rt::d2h(pr.data(), a.st_prof, (size_t)ns * 32, s);
+            rt::stream_sync(s);
+            rt::dfree(a.st_prof);
+            for (int r = 0; r < 6 && r < ns; r++) {
+                int64_t i = order[r];
+                double n = (double)std::max<unsigned long long>(1, pr[4 * i + 3]);
+                fprintf(stderr, "[ldbg] strand %lld lean steps %.0f: cycles per step issue %.0f, wait %.0f, rest %.0f\n", (long long)i, n, pr[4 * i] / n, pr[4 * i + 1] / n, pr[4 * i + 2] / n);
+            }
+        }
+#endif
         for (int r = 0; r < 3 && r < ns; r++) {
             int64_t i = order[r];
             fprintf(stderr, "[ldbg] strand %lld: %llu of its %u steps went through the general step, %.1f ms there (%.2f us each, the step itself not included)\n",

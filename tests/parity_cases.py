@@ -898,3 +898,16 @@ def case_dfs_step_limit(orc, lib, tmp, monkeypatch):
     with pytest.raises(ca.LdbgError) as ex:
         e.dfs_batch(cs.all_kmers()[:20]).graphs()
     assert "step limit" in str(ex.value)
+
+
+def case_close_in_any_order(orc, lib, tmp):
+    """handles are closed by a garbage collector in any order: a graph may go before the link sets bound to it"""
+    rng = random.Random(8)
+    g1 = rand_seq(rng, 300)
+    cs = Case(orc, tmp, lib, [("a", [g1])], 21, link_samples=["a"], name="order")
+    links = cs.links["a"]
+    again = CortexLinks(links.path, cs.g, lib=lib)
+    again.close()                 # the usual order
+    cs.g.close()
+    links.close()                 # after its graph: nothing left to give back
+    links.close()

@@ -140,3 +140,6 @@ def test_sharded_walks_one_rank_rccl(orc, lib, tmp_path):
 
 
 def test_dfs_step_limit(orc, lib, tmp_path, monkeypatch): pc.case_dfs_step_limit(orc, lib, tmp_path, monkeypatch)
+
+
+def test_close_in_any_order(orc, lib, tmp_path): pc.case_close_in_any_order(orc, lib, tmp_path)

@@ -78,3 +78,6 @@ def test_batch_splitting_on_a_small_device(orc, lib, tmp_path, monkeypatch):
 
 
 def test_dfs_step_limit(orc, lib, tmp_path, monkeypatch): pc.case_dfs_step_limit(orc, lib, tmp_path, monkeypatch)
+
+
+def test_close_in_any_order(orc, lib, tmp_path): pc.case_close_in_any_order(orc, lib, tmp_path)
