@@ -15,6 +15,7 @@ struct WalkArgs {
     const uint64_t* seeds;     // [n][W]; word 0 == ~0 marks a seed that is not a k-mer (non-ACGT)
     int64_t n_strands;         // 2n: strand 2i = reverse, 2i+1 = forward
     int64_t n_slots;
+    int lean_run;              // lean steps a lane may take in a row before the wavefront looks at the lanes waiting for a general step
     int64_t fetch_stride;      // strands are handed out in the order (i * fetch_stride) mod n_strands (coprime): neighbouring
                                // seeds walk the same contig, and a wavefront full of identical long walks is the worst tail
     int run_rev, run_fwd;

@@ -152,7 +152,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             // step claims at most one table slot, and the regrowth check above leaves room for eight
             int r = 0;
 #pragma unroll 1
-            do { lean_step<W>(a, st, ls); } while (++r < 8 && lean_again(a, st));     // one copy of the step: the loop lives in the instruction cache
+            do { lean_step<W>(a, st, ls); } while (++r < a.lean_run && lean_again(a, st));     // one copy of the step: the loop lives in the instruction cache
             st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
         if (wave_ballot(active && !lean) == 0ull) continue;          // the whole wavefront took the lean step
@@ -590,6 +590,8 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         while (gcd(st, ns) != 1) st++;
         a.fetch_stride = st % ns ? st % ns : 1;
     }
+    a.lean_run = 8;
+    if (const char* ev = getenv("LDBG_LEAN_RUN")) a.lean_run = (int)std::max<long long>(1, atoll(ev));   // tuning knob
     a.run_rev = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_REVERSE;
     a.run_fwd = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_FORWARD;
     a.next_strand = d_ctr;
