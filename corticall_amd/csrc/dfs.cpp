@@ -722,7 +722,9 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     const uint32_t vcap_max = std::max<uint32_t>(64u, next_pow2_u(2ull * chain));
     // entries one strand's log may hold: the vertices of every branch that returned a graph
     const int max_blocks = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(dfs_log_blocks, (((int64_t)cfg.max_branch_length + 2) * 8 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK + 1));
-    ensure_scratch(ns, link_store_capacity, max_blocks);
+    // the pool follows the walks' table sizes (a chain of branches is rarely longer than a few branches' worth); what it always holds is
+    // one seed's two strands at their largest, so that splitting a batch that ran the pool dry ends in chunks that fit
+    ensure_scratch(ns, link_store_capacity, max_blocks, 2 * vt_series(vt_initial_entries(), vcap_max));
     if (vpool_dirty_ > 0) rt::dmemset(d_vpool_, 0, (size_t)std::min<uint64_t>(vpool_dirty_, vpool_entries_) * 8, s);
 
     struct Tmp { std::vector<void*> p; ~Tmp() { for (void* x : p) rt::dfree(x); } void* get(size_t nbytes) { void* x = rt::dmalloc(nbytes); p.push_back(x); return x; } } tmp;
@@ -780,7 +782,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     a.w.block_table = (uint32_t*)d_block_table_; a.w.max_blocks = max_blocks;
     a.w.strand_n = d_strand_n; a.w.status = d_status; a.w.iters = d_iters; a.w.quirk = d_quirk;
     a.w.term = d_term;
-    a.w.vpool = (uint64_t*)d_vpool_; a.w.vpool_entries = vpool_entries_; a.w.vcap_max = vcap_max; a.w.vcap_init = LDBG_VT_INITIAL;
+    a.w.vpool = (uint64_t*)d_vpool_; a.w.vpool_entries = vpool_entries_; a.w.vcap_max = vcap_max; a.w.vcap_init = vt_initial_entries();
     a.w.ls = (LsElem*)d_ls_; a.w.ecap = ecap_;
     a.env.rois = rois ? rois->view : GraphView{};
     if (!rois) a.env.rois.N = -1;

@@ -45,6 +45,9 @@ struct DfsBatch {
     std::string walk_contig(int64_t i, const char* seed, int color);
 };
 
+uint64_t vt_series(uint64_t init, uint64_t vmax);     // walk.cpp
+uint32_t vt_initial_entries();
+
 class Engine {
 public:
     explicit Engine(const ldbg_engine_config& cfg);
@@ -87,7 +90,8 @@ private:
     bool dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
                    int64_t first, int64_t n, DfsBatch& out);
     void launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks);
-    void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks);
+    void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks, uint64_t table_floor = 0);   // table_floor: entries the table pool holds at least
+    uint64_t table_floor_ = 0;
     void release_scratch();
     bool run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);
 };

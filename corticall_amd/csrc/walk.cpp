@@ -495,17 +495,30 @@ void Engine::clear_batch() {
 }
 
 // per-slot link stores, the visited-table pool, the path block pool and the block table; kept across batches
-void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks) {
+// pool entries a strand needs at worst: tables of init, 4 x init, ... entries, the last one capped at vmax (grown tables are not given back)
+uint64_t vt_series(uint64_t init, uint64_t vmax) {
+    uint64_t c = std::min(init, vmax), sum = 0;
+    while (true) { sum += c; if (c >= vmax) break; c = std::min(c * 4, vmax); }
+    return sum;
+}
+uint32_t vt_initial_entries() {
+    uint32_t v = LDBG_VT_INITIAL;
+    if (const char* ev = getenv("LDBG_VT_INITIAL")) v = std::max<uint32_t>(64u, next_pow2((uint64_t)atoll(ev)));   // tuning knob
+    return v;
+}
+
+void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks, uint64_t table_floor) {
     rt::stream_t s = graph->stream;
-    if (d_vpool_ && ecap_ == ecap && max_blocks_ == max_blocks && bt_strands_ >= ns) return;
+    if (d_vpool_ && ecap_ == ecap && max_blocks_ == max_blocks && bt_strands_ >= ns && table_floor_ >= table_floor) return;
     release_scratch();
     size_t free_b = 0, total_b = 0;
     rt::mem_info(&free_b, &total_b);
     const int64_t slots = ((ns + 63) / 64) * 64;           // every strand of the batch gets a lane
     // memory split: 40% of what is free for the visited-table pool, 35% for the path pool (both capped by need)
     const uint64_t vcap_max = next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 12));
-    uint64_t want_v = (uint64_t)ns * vcap_max * 4 / 3 + LDBG_VT_INITIAL;
+    uint64_t want_v = std::max<uint64_t>((uint64_t)ns * vt_series(vt_initial_entries(), vcap_max), table_floor) + LDBG_VT_INITIAL;
     vpool_entries_ = std::max<uint64_t>(LDBG_VT_INITIAL * 2, std::min<uint64_t>(want_v, (uint64_t)(free_b * 0.40) / 8));
+    table_floor_ = table_floor;
     uint64_t want_blocks = (uint64_t)ns * (uint64_t)max_blocks;
     n_blocks_ = std::max<uint64_t>(2, std::min<uint64_t>(want_blocks, (uint64_t)(free_b * 0.35) / (LDBG_PATH_BLOCK * 8)));
     d_vpool_ = rt::dmalloc((size_t)vpool_entries_ * 8);
@@ -601,8 +614,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.strand_n = d_strand_n; a.status = d_status; a.iters = d_iters; a.quirk = d_quirk;
     a.term = (uint64_t*)out.d_term;
     a.vpool = (uint64_t*)d_vpool_; a.vnext = d_ctr + 2; a.vpool_entries = vpool_entries_; a.vcap_max = vcap_max;
-    a.vcap_init = LDBG_VT_INITIAL;
-    if (const char* ev = getenv("LDBG_VT_INITIAL")) a.vcap_init = std::max<uint32_t>(64u, next_pow2((uint64_t)atoll(ev)));   // tuning knob
+    a.vcap_init = vt_initial_entries();
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
 
     a.wg_times = nullptr; a.st_times = nullptr; a.st_gen = nullptr;

@@ -81,3 +81,13 @@ def test_dfs_step_limit(orc, lib, tmp_path, monkeypatch): pc.case_dfs_step_limit
 
 
 def test_close_in_any_order(orc, lib, tmp_path): pc.case_close_in_any_order(orc, lib, tmp_path)
+
+
+def test_small_visited_tables(orc, lib, tmp_path, monkeypatch):
+    """visited tables that start at 64 entries: probe rounds wrap round the end of a table and tables regrow many times"""
+    monkeypatch.setenv("LDBG_VT_INITIAL", "64")
+    pc.case_long_walks(orc, lib, tmp_path)
+    pc.case_dense_cycles(orc, lib, tmp_path, 2)
+    pc.case_random_walks(orc, lib, tmp_path, 31, 5, True, n=600)
+    pc.case_dfs_dense(orc, lib, tmp_path, 3)
+    pc.case_dfs_rules(orc, lib, tmp_path, 31, 2, True)
