@@ -685,8 +685,7 @@ DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, c
     build_roi_bits();
     const int k = graph->hdr.k, W = graph->hdr.W;
     std::vector<uint64_t> words((size_t)n * W);
-    for (int64_t i = 0; i < n; i++)
-        if (!ascii_to_words(sources + i * k, k, &words[i * W], W)) { for (int w = 0; w < W; w++) words[i * W + w] = ~0ull; }
+    ascii_batch_to_words(sources, n, k, W, words.data(), true);
     const int64_t nsinks = sink_offsets ? sink_offsets[n] : 0;
     std::vector<uint64_t> sink_words((size_t)std::max<int64_t>(1, nsinks) * W);
     for (int64_t i = 0; i < nsinks; i++)
@@ -725,7 +724,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     // the pool follows the walks' table sizes (a chain of branches is rarely longer than a few branches' worth); what it always holds is
     // one seed's two strands at their largest, so that splitting a batch that ran the pool dry ends in chunks that fit
     ensure_scratch(ns, link_store_capacity, max_blocks, 2 * vt_series(vt_initial_entries(), vcap_max));
-    if (vpool_dirty_ > 0) rt::dmemset(d_vpool_, 0, (size_t)std::min<uint64_t>(vpool_dirty_, vpool_entries_) * 8, s);
+    zero_dirty_tables(s);
 
     struct Tmp { std::vector<void*> p; ~Tmp() { for (void* x : p) rt::dfree(x); } void* get(size_t nbytes) { void* x = rt::dmalloc(nbytes); p.push_back(x); return x; } } tmp;
     uint64_t* d_seeds = (uint64_t*)tmp.get((size_t)n * W * 8);

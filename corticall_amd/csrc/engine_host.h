@@ -12,6 +12,7 @@ namespace ldbg {
 struct WalkChunk {
     int64_t first = 0, n = 0;              // seeds [first, first+n)
     void* d_path = nullptr;                // dense u64 path entries of all strands of the chunk
+    size_t path_cap = 0, contigs_cap = 0;  // bytes behind d_path / d_contigs (buffers are reused from batch to batch)
     std::vector<int64_t> strand_off;       // [2n+1] offsets into d_path (strand 2i = reverse, 2i+1 = forward)
     std::vector<uint32_t> status;          // [2n]
     void* d_contigs = nullptr;             // dense ASCII contigs
@@ -93,6 +94,13 @@ private:
     void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks, uint64_t table_floor = 0);   // table_floor: entries the table pool holds at least
     uint64_t table_floor_ = 0;
     void release_scratch();
+    // result buffers of a cleared batch are kept for the next one: allocating and freeing GBs costs milliseconds per batch
+    struct Spare { void* p; size_t bytes; };
+    std::vector<Spare> spares_;
+    void* result_alloc(size_t bytes, size_t* cap);
+    void result_free(void* p, size_t cap);
+    void drop_spares();
+    void zero_dirty_tables(rt::stream_t s);      // the part of the table pool the last launch handed out
     bool run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);
 };
 

@@ -5,6 +5,9 @@
 // (CortexByteKmer.compareTo, J/utils/kmer/CortexByteKmer.java:41-49).
 #pragma once
 #include <stdint.h>
+#include <algorithm>
+#include <thread>
+#include <vector>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -191,6 +194,35 @@ inline bool ascii_to_words(const char* s, int k, uint64_t* w, int W) {
         w[W - 1 - (bit >> 6)] |= v << (bit & 63);
     }
     return true;
+}
+// the same for a batch of n k-mers of k bytes each (seeds of a walk / dfs batch): table lookup, one shift-or per base, a few
+// threads for large batches.  A string with a non-ACGT byte gets word 0 (all words if fill_all) set to ~0.
+inline void ascii_batch_to_words(const char* s, int64_t n, int k, int W, uint64_t* words, bool fill_all) {
+    static const struct Lut {
+        uint8_t v[256];
+        Lut() { for (int i = 0; i < 256; i++) v[i] = 0x80; v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; }
+    } lut;
+    const int nw = (k + 31) / 32, lead = W - nw;         // words that carry bases; leading all-zero words
+    auto run = [&](int64_t lo, int64_t hi) {
+        for (int64_t q = lo; q < hi; q++) {
+            const uint8_t* c = (const uint8_t*)s + q * k;
+            uint64_t* w = words + q * W;
+            unsigned bad = 0;
+            int i = 0;
+            for (int wi = 0; wi < W; wi++) {
+                const int cnt = wi < lead ? 0 : (wi == lead ? k - 32 * (nw - 1) : 32);
+                uint64_t acc = 0;
+                for (int j = 0; j < cnt; j++) { const uint8_t v = lut.v[c[i++]]; bad |= v; acc = (acc << 2) | (uint64_t)(v & 3u); }
+                w[wi] = acc;
+            }
+            if (bad & 0x80u) { if (fill_all) { for (int wi = 0; wi < W; wi++) w[wi] = ~0ull; } else w[0] = ~0ull; }
+        }
+    };
+    const int nt = n >= 8192 ? (int)std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (nt <= 1) { run(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back(run, n * t / nt, n * (t + 1) / nt);
+    for (auto& t : th) t.join();
 }
 inline void words_to_ascii(const uint64_t* w, int k, int W, char* out) {
     for (int i = 0; i < k; i++) {

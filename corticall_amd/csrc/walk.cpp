@@ -3,6 +3,7 @@
 // with or without link annotations.  One strand walk (seed, direction) per lane; lanes pull strand
 // walks from a queue until it is empty.
 #include <algorithm>
+#include <chrono>
 #include <numeric>
 
 #include "lscoop.h"
@@ -410,7 +411,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
 }
 
-Engine::~Engine() { clear_batch(); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
+Engine::~Engine() { clear_batch(); drop_spares(); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
 
 // ROI hits of the walks of the last batch: offsets[n+1] into hits (ROI record numbers, order within a walk arbitrary),
 // has_null[i] = the dfs graph of seed i holds a vertex without a record
@@ -483,13 +484,60 @@ void Engine::launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands
 }
 
 void Engine::release_scratch() {
+    drop_spares();
     rt::dfree(d_vpool_); rt::dfree(d_ls_); rt::dfree(d_pool_); rt::dfree(d_block_table_);
     d_vpool_ = d_ls_ = d_pool_ = d_block_table_ = nullptr;
     n_slots_ = 0; n_blocks_ = 0; bt_strands_ = 0; vpool_entries_ = 0; vpool_dirty_ = 0;
 }
 
+// Zeroing tens of GB of handed-out tables is a tenth of a step's time with the runtime's fill; 16 bytes per lane, grid-stride,
+// runs at the write bandwidth of the device.
+LDBG_KERNEL void k_zero16(uint64_t* p, uint64_t n_pairs) {
+    for (uint64_t i = (uint64_t)global_tid(); i < n_pairs; i += (uint64_t)global_nthreads()) {
+#ifndef LDBG_HOSTSIM
+        struct alignas(16) U2 { uint64_t a, b; };
+        ((U2*)p)[i] = U2{0ull, 0ull};
+#else
+        p[2 * i] = 0; p[2 * i + 1] = 0;
+#endif
+    }
+}
+void Engine::zero_dirty_tables(rt::stream_t s) {
+    if (vpool_dirty_ == 0) { vpool_dirty_ = vpool_entries_; return; }
+    const uint64_t n = std::min<uint64_t>((vpool_dirty_ + 1) & ~1ull, vpool_entries_ & ~1ull);     // entries, in pairs
+    if (n > 0) LDBG_LAUNCH(k_zero16, 256 * 16, 256, s, (uint64_t*)d_vpool_, n / 2);
+    if (n < std::min<uint64_t>(vpool_dirty_, vpool_entries_)) rt::dmemset((uint64_t*)d_vpool_ + n, 0, (size_t)(std::min<uint64_t>(vpool_dirty_, vpool_entries_) - n) * 8, s);
+    vpool_dirty_ = vpool_entries_;      // until the launch that follows has reported how much it handed out
+}
+
+void* Engine::result_alloc(size_t bytes, size_t* cap) {
+    int best = -1;
+    for (int i = 0; i < (int)spares_.size(); i++)
+        if (spares_[i].bytes >= bytes && (best < 0 || spares_[i].bytes < spares_[best].bytes)) best = i;
+    if (best >= 0) {
+        Spare sp = spares_[best];
+        spares_.erase(spares_.begin() + best);
+        *cap = sp.bytes;
+        return sp.p;
+    }
+    void* p = nullptr;
+    try { p = rt::dmalloc(bytes); }
+    catch (const StatusError&) { drop_spares(); p = rt::dmalloc(bytes); }     // the spares may be what is in the way
+    *cap = bytes;
+    return p;
+}
+void Engine::result_free(void* p, size_t cap) {
+    if (!p) return;
+    if (spares_.size() >= 8 || cap == 0) { rt::dfree(p); return; }
+    spares_.push_back({p, cap});
+}
+void Engine::drop_spares() {
+    for (auto& sp : spares_) rt::dfree(sp.p);
+    spares_.clear();
+}
+
 void Engine::clear_batch() {
-    for (auto& c : chunks) { rt::dfree(c.d_path); rt::dfree(c.d_contigs); rt::dfree(c.d_seed_words); rt::dfree(c.d_term); }
+    for (auto& c : chunks) { result_free(c.d_path, c.path_cap); result_free(c.d_contigs, c.contigs_cap); rt::dfree(c.d_seed_words); rt::dfree(c.d_term); }
     chunks.clear();
     batch_n = batch_bytes = batch_traversed = 0;
 }
@@ -530,16 +578,30 @@ void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks, uint64_t 
     n_slots_ = slots; ecap_ = ecap; max_blocks_ = max_blocks; bt_strands_ = ns;
 }
 
+// LDBG_HOST_TIMES=1: wall-clock laps of the host side of a batch on stderr (diagnostics)
+struct HostLaps {
+    bool on = getenv("LDBG_HOST_TIMES") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ldbg] host %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
     if (cfg.stopping_rule != LDBG_STOP_CONTIG || cfg.connect_all_neighbors)
         throw StatusError(LDBG_ERR_UNSUPPORTED, "walk_batch runs ContigStopper without connectAllNeighbors; use dfs_batch for other rules");
     if (cfg.n_secondary > 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "secondary colours are not supported by walk_batch");
     rt::set_device(graph->device);
+    HostLaps laps;
     clear_batch();
+    laps.lap("clear_batch");
     const int k = graph->hdr.k, W = graph->hdr.W;
     std::vector<uint64_t> words((size_t)n * W);
-    for (int64_t i = 0; i < n; i++)
-        if (!ascii_to_words(seeds + i * k, k, &words[i * W], W)) words[i * W] = ~0ull;
+    ascii_batch_to_words(seeds, n, k, W, words.data(), false);
+    laps.lap("seed words");
     batch_n = n;
     int64_t trav = 0;
     // the whole batch in one launch; if the path pool runs dry the batch is split and re-run (exactness first)
@@ -575,8 +637,10 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     // a strand's visited table never needs more than this (longest possible branch at load <= 1/2)
     const uint32_t vcap_max = std::max<uint32_t>(64u, next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 12)));
     const int max_blocks = (int)(((int64_t)cfg.max_branch_length + 2 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK);
+    HostLaps laps;
     ensure_scratch(ns, link_store_capacity, max_blocks);
-    if (vpool_dirty_ > 0) rt::dmemset(d_vpool_, 0, (size_t)std::min<uint64_t>(vpool_dirty_, vpool_entries_) * 8, s);   // only what the last launch used
+    zero_dirty_tables(s);
+    laps.lap("scratch + zero (issued)");
 
     out.d_seed_words = rt::dmalloc((size_t)n * W * 8);
     rt::h2d(out.d_seed_words, &seed_words[first * W], (size_t)n * W * 8, s);
@@ -590,6 +654,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
     auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk); };
 
+    laps.lap("small allocations");
     WalkArgs a;
     a.e = view;
     a.seeds = (const uint64_t*)out.d_seed_words;
@@ -741,6 +806,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     }
     vpool_dirty_ = ctr[2];
     profile_add("walk", rt::Event::elapsed_ms(e0, e1));
+    laps.lap("launch .. results on host");
 
     bool pool_full = false;
     for (int64_t i = 0; i < ns; i++) pool_full |= out.status[i] == ST_POOL_FULL;
@@ -761,8 +827,10 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     int64_t* d_contig_off = (int64_t*)rt::dmalloc((size_t)(n + 1) * 8);
     rt::h2d(d_strand_off, out.strand_off.data(), (size_t)(ns + 1) * 8, s);
     rt::h2d(d_contig_off, out.contig_off.data(), (size_t)(n + 1) * 8, s);
-    out.d_path = rt::dmalloc((size_t)out.strand_off[ns] * 8);
-    out.d_contigs = rt::dmalloc((size_t)out.contig_off[n]);
+    laps.lap("offsets");
+    out.d_path = result_alloc((size_t)out.strand_off[ns] * 8, &out.path_cap);
+    out.d_contigs = result_alloc((size_t)out.contig_off[n], &out.contigs_cap);
+    laps.lap("result buffers");
     rt::Event c0, c1;
     c0.record(s);
     LDBG_LAUNCH(k_compact_paths, grid_for(ns * 64, 256, 4096), 256, s, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
@@ -781,8 +849,10 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     c1.record(s);
     rt::stream_sync(s);
     profile_add("contig", rt::Event::elapsed_ms(c0, c1));
+    laps.lap("compaction + contigs");
     free_tmp();
     rt::dfree(d_walk_len); rt::dfree(d_seed_ok); rt::dfree(d_strand_off); rt::dfree(d_contig_off);
+    laps.lap("frees");
 
     // errors the reference raises as exceptions abort the call
     for (int64_t i = 0; i < ns; i++) {

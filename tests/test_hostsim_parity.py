@@ -29,7 +29,7 @@ def test_ref_go_forward_and_backward(orc, lib, tmp_path): pc.test_ref_go_forward
 def test_ref_link_guided_walk(orc, lib, tmp_path): pc.test_ref_link_guided_walk(orc, lib, tmp_path)
 
 
-@pytest.mark.parametrize("k,seed,links", [(9, 1, False), (9, 2, True), (21, 3, False), (31, 4, True), (47, 5, True), (63, 6, False)])
+@pytest.mark.parametrize("k,seed,links", [(9, 1, False), (9, 2, True), (21, 3, False), (31, 4, True), (47, 5, True), (63, 6, False), (33, 7, True), (32, 8, False), (64, 9, False), (65, 10, False)])
 def test_random_walks(orc, lib, tmp_path, k, seed, links): pc.case_random_walks(orc, lib, tmp_path, k, seed, links)
 
 
