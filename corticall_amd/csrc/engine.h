@@ -349,6 +349,22 @@ struct LsElem {
     uint16_t nx;       // the next nxn <= 8 junction bases from `pos` on (2 bits each, complemented already): the
                        // junction logic reads the pool of junction strings once per 8 positions
 };
+static_assert(sizeof(LsElem) == 24, "LsElem is moved as six words");
+// element copies through pointers of a known address space (six word moves; the compiler pairs them up)
+template <typename P> LDBG_HOSTDEV LsElem ls_elem_in(P q) {
+    uint32_t w[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = q[i];
+    LsElem x;
+    __builtin_memcpy(&x, w, 24);
+    return x;
+}
+template <typename P> LDBG_HOSTDEV void ls_elem_out(P q, const LsElem& x) {
+    uint32_t w[6];
+    __builtin_memcpy(w, &x, 24);
+#pragma unroll
+    for (int i = 0; i < 6; i++) q[i] = w[i];
+}
 struct LinkStoreDev {
     LsElem* fast;       // the first `fast_cap` elements live here (LDS in the walk kernel), element i at fast[i * fast_stride]
     LsElem* el;         // the rest spill to HBM: element i at el[i - fast_cap]
@@ -362,8 +378,15 @@ struct LinkStoreDev {
     uint32_t n_new;     // elements with age 0
     bool overflow;
 };
-LDBG_HOSTDEV LsElem ls_get(const LinkStoreDev& s, uint32_t i) { return i < s.fast_cap ? s.fast[i * s.fast_stride] : s.el[i - s.fast_cap]; }
-LDBG_HOSTDEV void ls_set(LinkStoreDev& s, uint32_t i, const LsElem& x) { if (i < s.fast_cap) s.fast[i * s.fast_stride] = x; else s.el[i - s.fast_cap] = x; }
+// (on the device `fast` is only ever LDS and `el` HBM: said explicitly, or the accesses become flat_ ones that wait for both memories)
+LDBG_HOSTDEV LsElem ls_get(const LinkStoreDev& s, uint32_t i) {
+    if (i < s.fast_cap) return ls_elem_in(LDBG_LDS(const uint32_t, s.fast + i * s.fast_stride));
+    return ls_elem_in(LDBG_GLOBAL(const uint32_t, s.el + (i - s.fast_cap)));
+}
+LDBG_HOSTDEV void ls_set(LinkStoreDev& s, uint32_t i, const LsElem& x) {
+    if (i < s.fast_cap) ls_elem_out(LDBG_LDS(uint32_t, s.fast + i * s.fast_stride), x);
+    else ls_elem_out(LDBG_GLOBAL(uint32_t, s.el + (i - s.fast_cap)), x);
+}
 LDBG_HOSTDEV void ls_clear(LinkStoreDev& s) { s.n = 0; s.java_cap = 0; s.nkeys = 0; s.next_seq = 0; s.age = 0; s.n_new = 0; s.overflow = false; }
 LDBG_HOSTDEV unsigned ls_char(const LinksView& L, const LsElem& x, uint32_t i) {
     unsigned b = L.bases[x.str_off + i];

@@ -22,10 +22,12 @@ struct LsWave {
     uint32_t ecap;
 };
 LDBG_DEV LsElem lsw_get(const LsWave& v, int L, uint32_t i) {
-    return i < v.fast_cap ? v.fast[i * v.stride + (uint32_t)L] : v.el[(size_t)L * v.ecap + (i - v.fast_cap)];
+    if (i < v.fast_cap) return ls_elem_in(LDBG_LDS(const uint32_t, v.fast + (i * v.stride + (uint32_t)L)));
+    return ls_elem_in(LDBG_GLOBAL(const uint32_t, v.el + ((size_t)L * v.ecap + (i - v.fast_cap))));
 }
 LDBG_DEV void lsw_set(const LsWave& v, int L, uint32_t i, const LsElem& x) {
-    if (i < v.fast_cap) v.fast[i * v.stride + (uint32_t)L] = x; else v.el[(size_t)L * v.ecap + (i - v.fast_cap)] = x;
+    if (i < v.fast_cap) ls_elem_out(LDBG_LDS(uint32_t, v.fast + (i * v.stride + (uint32_t)L)), x);
+    else ls_elem_out(LDBG_GLOBAL(uint32_t, v.el + ((size_t)L * v.ecap + (i - v.fast_cap))), x);
 }
 
 // the owner's store header, identical on every lane while the wavefront works on it

@@ -29,8 +29,10 @@
 // it would emit flat_ accesses, which also wait on the LDS counter)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LDBG_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
+#define LDBG_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))       // likewise for a pointer into the workgroup's LDS
 #else
-#define LDBG_GLOBAL(T, p) (p)
+#define LDBG_GLOBAL(T, p) ((T*)(p))
+#define LDBG_LDS(T, p) ((T*)(p))
 #endif
 
 namespace ldbg {
@@ -120,7 +122,8 @@ LDBG_DEV int wave_count_below(unsigned long long ballot) { return __builtin_popc
 #define LDBG_WAVE_KERNEL_N(n) static
 #define LDBG_DEV inline
 #define LDBG_HOSTDEV inline
-#define LDBG_GLOBAL(T, p) (p)
+#define LDBG_GLOBAL(T, p) ((T*)(p))
+#define LDBG_LDS(T, p) ((T*)(p))
 #ifndef __forceinline__
 #define __forceinline__
 #endif

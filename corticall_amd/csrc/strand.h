@@ -170,7 +170,7 @@ LDBG_DEV void wave_grow_tables(const WalkArgs& a, StrandState& st, bool active) 
         const uint32_t nt_mask = wave_bcast_u32(new_cap, L) - 1;
         if (nt_tab) {
             for (uint32_t i = (uint32_t)lane; i <= old_mask; i += (uint32_t)wave_size()) {
-                const uint64_t e = old_tab[i];
+                const uint64_t e = LDBG_GLOBAL(const uint64_t, old_tab)[i];
                 if (e == 0) continue;
                 uint32_t h = vt_hash(e & LDBG_VT_KEY_MASK) & nt_mask;
                 while (atomic_cas_u64(&nt_tab[h], 0ull, (unsigned long long)e) != 0ull) h = (h + 1) & nt_mask;
