@@ -93,6 +93,7 @@ private:
     void launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks);
     void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks, uint64_t table_floor = 0);   // table_floor: entries the table pool holds at least
     uint64_t table_floor_ = 0;
+    uint64_t* h_log_ = nullptr; size_t h_log_cap_ = 0;   // page-locked landing buffer of the dfs logs (dfs.cpp)
     void release_scratch();
     // result buffers of a cleared batch are kept for the next one: allocating and freeing GBs costs milliseconds per batch
     struct Spare { void* p; size_t bytes; };

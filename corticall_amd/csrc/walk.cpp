@@ -411,7 +411,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
 }
 
-Engine::~Engine() { clear_batch(); drop_spares(); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
+Engine::~Engine() { clear_batch(); drop_spares(); rt::hfree_pinned(h_log_); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
 
 // ROI hits of the walks of the last batch: offsets[n+1] into hits (ROI record numbers, order within a walk arbitrary),
 // has_null[i] = the dfs graph of seed i holds a vertex without a record
