@@ -668,7 +668,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         while (gcd(st, ns) != 1) st++;
         a.fetch_stride = st % ns ? st % ns : 1;
     }
-    a.lean_run = 8;
+    a.lean_run = 4;
     if (const char* ev = getenv("LDBG_LEAN_RUN")) a.lean_run = (int)std::max<long long>(1, atoll(ev));   // tuning knob
     a.run_rev = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_REVERSE;
     a.run_fwd = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_FORWARD;
@@ -680,6 +680,12 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.term = (uint64_t*)out.d_term;
     a.vpool = (uint64_t*)d_vpool_; a.vnext = d_ctr + 2; a.vpool_entries = vpool_entries_; a.vcap_max = vcap_max;
     a.vcap_init = vt_initial_entries();
+    if (!getenv("LDBG_VT_INITIAL")) {
+        // Regrowing a table stalls the owner's whole wavefront (strand.h), and the regrowths of its 64 strands add up: start as large as
+        // half of the pool allows when every strand of the batch takes one (C3: 65,536 entries, launch 291 -> 250 ms against 4,096)
+        const uint64_t per = vpool_entries_ / 2 / (uint64_t)std::max<int64_t>(1, ns);
+        while ((uint64_t)a.vcap_init * 4 <= per && (uint64_t)a.vcap_init * 4 <= vcap_max) a.vcap_init *= 4;
+    }
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
 
     a.wg_times = nullptr; a.st_times = nullptr; a.st_gen = nullptr;
