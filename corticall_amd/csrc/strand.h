@@ -15,6 +15,7 @@ struct WalkArgs {
     const uint64_t* seeds;     // [n][W]; word 0 == ~0 marks a seed that is not a k-mer (non-ACGT)
     int64_t n_strands;         // 2n: strand 2i = reverse, 2i+1 = forward
     int64_t n_slots;
+    int grow_at;               // a table is regrown when (entries + 8) * grow_at exceeds its size (2 = half full; 0 is read as 2)
     int lean_run;              // lean steps a lane may take in a row before the wavefront looks at the lanes waiting for a general step
     int64_t fetch_stride;      // strands are handed out in the order (i * fetch_stride) mod n_strands (coprime): neighbouring
                                // seeds walk the same contig, and a wavefront full of identical long walks is the worst tail
@@ -149,7 +150,7 @@ LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls,
 // slots it carries.
 LDBG_DEV void wave_grow_tables(const WalkArgs& a, StrandState& st, bool active) {
     const uint32_t cap = st.vt.mask + 1;
-    const bool need = active && st.status == ST_OK && (st.vt.used + 8) * 2 > cap && cap < a.vcap_max;
+    const bool need = active && st.status == ST_OK && (st.vt.used + 8) * (uint32_t)(a.grow_at > 2 ? a.grow_at : 2) > cap && cap < a.vcap_max;
     unsigned long long ballot = wave_ballot(need);
     const int lane = wave_lane();
     while (ballot) {

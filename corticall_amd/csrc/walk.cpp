@@ -669,6 +669,8 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         a.fetch_stride = st % ns ? st % ns : 1;
     }
     a.lean_run = 4;
+    a.grow_at = 2;
+    if (const char* ev = getenv("LDBG_VT_GROW_AT")) a.grow_at = (int)std::max<long long>(2, std::min<long long>(8, atoll(ev)));   // tuning knob
     if (const char* ev = getenv("LDBG_LEAN_RUN")) a.lean_run = (int)std::max<long long>(1, atoll(ev));   // tuning knob
     a.run_rev = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_REVERSE;
     a.run_fwd = cfg.direction == LDBG_DIR_BOTH || cfg.direction == LDBG_DIR_FORWARD;
