@@ -405,6 +405,7 @@ ldbg_status ldbg_engine_previous(ldbg_engine* e, char* kmer_out, int64_t* rec_ou
 void ldbg_debug_ls(uint64_t* out) {
     auto& d = ldbg::ls_debug();
     out[0] = d.adds; out[1] = d.newkeys; out[2] = d.choices; out[3] = d.scan; out[4] = d.maxn; out[5] = d.steps; out[6] = d.sum_n;
+    out[7] = d.runs_a; out[8] = d.runs_b; out[9] = d.run_vertices; out[10] = d.retries; out[11] = d.repeats;
     d = ldbg::LsDebug();
 }
 #endif

@@ -783,6 +783,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     a.w.term = d_term;
     a.w.vpool = (uint64_t*)d_vpool_; a.w.vpool_entries = vpool_entries_; a.w.vcap_max = vcap_max; a.w.vcap_init = vt_initial_entries();
     a.w.ls = (LsElem*)d_ls_; a.w.ecap = ecap_;
+    a.w.strand_c = nullptr; a.w.retry = nullptr; a.w.snap = nullptr;
     a.env.rois = rois ? rois->view : GraphView{};
     if (!rois) a.env.rois.N = -1;
     a.env.roi_bits = (const uint32_t*)d_roi_bits_;

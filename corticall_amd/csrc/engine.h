@@ -13,6 +13,9 @@
 
 namespace ldbg {
 
+// the records in unitig order for this engine's colour masks (runs.h); uinfo == nullptr: no index
+struct RunIndexView { const uint64_t* uinfo; const uint32_t* uo; const uint8_t* ubase; };
+
 struct EngineView {
     GraphView g;
     uint32_t trav_mask, recruit_mask, join_mask;
@@ -24,6 +27,7 @@ struct EngineView {
                           // when none of the configured link sets belongs to a traversal sample
     uint32_t link_flag_mask;   // probe-row link-flag bits of the link sets merged into `links`
     LinksView links;      // the traversal's link sets merged into one table (links.h)
+    RunIndexView runs;    // set for walk launches only (walk.cpp); the cursor and dfs kernels step k-mer by k-mer
 };
 
 // strand status codes (per seed and direction)
@@ -37,7 +41,9 @@ enum : uint32_t {
     ST_STOPPER_CONFIG = 6, // the stopping rule needs a ROI graph that was not configured (CortexJDKException in the reference)
     ST_DEPTH_OVERFLOW = 7, // dfs recursion deeper than the frame stack -> host retries with a deeper one
     ST_TABLE_FULL = 8,     // a strand's visited table reached its maximum size
-    ST_LOG_FULL = 9        // a strand's dfs log outgrew its block table -> host retries with a longer one
+    ST_LOG_FULL = 9,       // a strand's dfs log outgrew its block table -> host retries with a longer one
+    ST_RETRY_PLAIN = 10    // walk kernel: the strand met a case the run steps (runstep.h) leave to the k-mer-by-k-mer code -> the host
+                           // walks it again without the run index
 };
 
 // ---- path entry: one vertex of a branch, 8 bytes
@@ -82,6 +88,7 @@ struct Node {
 #endif
     uint32_t ent1;       // neighbour-index entry of the vertex's only neighbour in the direction it was reached in (it comes
                          // with the row, so the next step starts without a load)
+    uint64_t ui;         // run-index entry of the record (runs.h), 0 = none; read with the row where the engine has an index
 };
 
 // edges of the node's record -> neighbour masks; link flags; Java flip from the record's collision bit
@@ -117,6 +124,7 @@ LDBG_HOSTDEV void node_fill_bytes(const EngineView& e, Node& n, uint32_t edges4,
 }
 LDBG_HOSTDEV void node_fill(const EngineView& e, Node& n) {
     const GraphView& g = e.g;
+    n.ui = e.runs.uinfo && n.idx >= 0 ? e.runs.uinfo[n.idx] : 0ull;
     if (n.idx >= 0) {
         const uint8_t* row = graph_row(g, n.idx);
         const uint8_t* ed = row + g.edges_off;
@@ -177,7 +185,7 @@ LDBG_HOSTDEV void node_find(const EngineView& e, const Kmer<W>& sk, Node& n) {
 }
 LDBG_HOSTDEV void node_null(const EngineView& e, Node& n) {   // not a k-mer (non-ACGT): findRecord misses (Q4)
     n.idx = -1; n.copy = 0; n.vslot = 0; n.vent = 0; n.e1 = 0; n.ent1 = 0; n.flip = 0; n.fj = 0; n.lflags = 0; n.base = 0;
-    n.next_mask = n.prev_mask = 0;
+    n.next_mask = n.prev_mask = 0; n.ui = 0;
     n.npe = e.recruit_mask != 0 ? 1 : 0;
 }
 
@@ -203,7 +211,7 @@ LDBG_HOSTDEV uint32_t vt_hash(uint64_t key) {      // keys are 34 bits; the tabl
 LDBG_HOSTDEV uint64_t vt_key(int64_t idx, bool flip) { return ((uint64_t)(idx + 1) << 1) | (flip ? 1ull : 0ull); }
 // slot of (idx, flip); claims a free slot (count 0, not seen) if the vertex is not in the table yet
 #ifdef LDBG_HOSTSIM
-struct LsDebug { uint64_t adds = 0, newkeys = 0, choices = 0, scan = 0, maxn = 0, steps = 0, sum_n = 0; };
+struct LsDebug { uint64_t adds = 0, newkeys = 0, choices = 0, scan = 0, maxn = 0, steps = 0, sum_n = 0, runs_a = 0, runs_b = 0, run_vertices = 0, retries = 0, repeats = 0; };
 inline LsDebug& ls_debug() { static LsDebug d; return d; }
 #endif
 // Linear probing, four slots per round: the entries at h .. h+3 are read together (one trip to memory; they share a cache
@@ -288,6 +296,8 @@ LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const No
     uint32_t nb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t ef = 0;
     const bool packed = LEAN || row_is_packed(g);
+    uint64_t ui = 0;
+    if (rec && e.runs.uinfo) ui = LDBG_GLOBAL(const uint64_t, e.runs.uinfo)[n.idx];
     if (rec) {
         const uint8_t* row = graph_row(g, n.idx);
         if (packed) {
@@ -315,6 +325,7 @@ LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const No
     if (LEAN) node_fill_bytes<true>(e, n, ef & ((1u << (8 * g.C)) - 1u), nullptr, (uint8_t)(ef >> (8 * g.C)));
     else if (rec && packed) node_fill_bytes(e, n, ef & ((1u << (8 * g.C)) - 1u), nullptr, (uint8_t)(ef >> (8 * g.C)));
     else node_fill(e, n);
+    n.ui = ui;
     if (rec) {
         // (selected whatever the mask, so that the neighbour index is read together with the edge bytes, not after them)
         const uint32_t m = fwd ? n.next_mask : n.prev_mask;
@@ -584,7 +595,7 @@ struct StepPre {
 // PRE: the link-store work of the step was done ahead by the caller (walk kernel) and arrives in *pre; the one-lane
 // LinkStore code is then not even compiled into the kernel.
 template <int W, bool PRE = false>
-LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd, const StepPre* pre = nullptr) {
+LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, VisitedTable& vt, bool fwd, const StepPre* pre = nullptr, uint32_t* marks = nullptr) {
     const bool links_done = PRE;
     if (cu.first) {
         cu.first = false;                              // seek(cur) recomputes the same state; then
@@ -607,6 +618,7 @@ LDBG_HOSTDEV Node cursor_step(const EngineView& e, Cursor& cu, LinkStoreDev& s, 
             if (x.idx >= 0 && !vt_seen_e(ex, cu.epoch)) {                // seen.add(nextKmer)
                 node_store(vt, x, vt_with_seen(ex, cu.epoch));
                 node_sync(cu.cur, x);
+                if (marks) ++*marks;
             }
             cu.nxt = x;
             has = true;

@@ -69,6 +69,7 @@ public:
     int dfs_max_depth = 64;
     int dfs_log_blocks = 64;          // path blocks (1024 entries) one strand's dfs log may use
     int64_t dfs_traversed() const { return dfs_traversed_; }
+    int64_t retried_strands() const { return retried_strands_; }
 
     int64_t batch_n = 0, batch_bytes = 0, batch_traversed = 0;
     std::vector<WalkChunk> chunks;
@@ -76,7 +77,7 @@ public:
 
 private:
     // per-slot scratch kept across batches: visited tables, link stores, table generations
-    void* d_vpool_ = nullptr; void* d_ls_ = nullptr;
+    void* d_vpool_ = nullptr; void* d_ls_ = nullptr; void* d_snap_ = nullptr;
     void* d_pool_ = nullptr; void* d_block_table_ = nullptr;
     int64_t n_slots_ = 0, bt_strands_ = 0;
     uint64_t n_blocks_ = 0, vpool_entries_ = 0, vpool_dirty_ = 0;
@@ -87,6 +88,8 @@ private:
     void* d_roi_of_ = nullptr;
     int64_t dfs_traversed_ = 0;
     std::unique_ptr<MergedLinks> merged_;
+    std::unique_ptr<class RunIndex> runs_;     // records in unitig order for this engine's colour masks (runs.h), built by the first walk batch
+    int64_t retried_strands_ = 0;              // strands the run steps handed back to the k-mer-by-k-mer code (diagnostics)
     void build_roi_bits();
     bool dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
                    int64_t first, int64_t n, DfsBatch& out);

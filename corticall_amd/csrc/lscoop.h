@@ -320,7 +320,7 @@ LDBG_DEV bool lean_cursor_again(const EngineView& e, const StrandState& st) {
 // next()/previous() (TraversalEngine.java:241-279) onto cu.nxt with its only successor looked up one step ahead, then
 // visited.add(cv) (:425).  Returns the vertex stepped onto with its copyIndex (:383-389); the caller connects it and advances.
 template <int W>
-LDBG_DEV Node lean_cursor_advance(const EngineView& e, StrandState& st, LinkStoreDev& ls) {
+LDBG_DEV Node lean_cursor_advance(const EngineView& e, StrandState& st, LinkStoreDev& ls, uint32_t* marks = nullptr) {
     const bool fwd = st.fwd;
     st.iters++;
     Node& cv = st.cv;
@@ -334,7 +334,7 @@ LDBG_DEV Node lean_cursor_advance(const EngineView& e, StrandState& st, LinkStor
     bool has = false;
     const bool seen = vt_seen_e(x.vent, st.cu.epoch);
     if (!seen || ls.n > 0) {                           // :262
-        if (!seen) node_store(st.vt, x, vt_with_seen(x.vent, st.cu.epoch));
+        if (!seen) { node_store(st.vt, x, vt_with_seen(x.vent, st.cu.epoch)); if (marks) ++*marks; }
         has = true;
     }
     if (ls_num_new(ls) > 0) ls_increment_ages(ls);     // :274-276 (Q12)

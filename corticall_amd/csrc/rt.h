@@ -114,6 +114,12 @@ LDBG_DEV uint64_t wave_shfl_xor_u64(uint64_t v, int m) {
 LDBG_DEV uint64_t wave_min_u64(uint64_t v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o < v ? o : v; } return v; }
 LDBG_DEV uint64_t wave_max_u64(uint64_t v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o > v ? o : v; } return v; }
 LDBG_DEV int wave_count_below(unsigned long long ballot) { return __builtin_popcountll(ballot & ((1ull << wave_lane()) - 1ull)); }
+// inclusive prefix sum over the lanes of a wavefront
+LDBG_DEV uint32_t wave_incl_scan_u32(uint32_t v) {
+    const int lane = wave_lane();
+    for (int d = 1; d < wave_size(); d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += o; }
+    return v;
+}
 }  // namespace ldbg
 
 #else  // ------------------------------------------------------------------ LDBG_HOSTSIM (tests only)
@@ -174,6 +180,7 @@ inline void wave_fence() {}
 inline uint64_t wave_min_u64(uint64_t v) { return v; }
 inline uint64_t wave_max_u64(uint64_t v) { return v; }
 inline int wave_count_below(unsigned long long) { return 0; }
+inline uint32_t wave_incl_scan_u32(uint32_t v) { return v; }
 }  // namespace ldbg
 
 // sequential "launch": every simulated thread runs to completion in turn.  Kernels must therefore

@@ -32,12 +32,15 @@ struct WalkArgs {
     uint32_t vcap_max;         // largest table a strand may need
     uint32_t vcap_init;        // size a strand's table starts with
     uint32_t* strand_n;        // vertices in the strand's branch graph (0 = empty graph)
+    uint32_t* strand_c;        // walk kernel: entries the strand wrote to its path blocks (runs are written as descriptors)
+    const uint32_t* retry;     // walk kernel: the strands of this launch (a second launch that re-walks some strands k-mer by k-mer), or nullptr = all
     uint32_t* status;
     uint32_t* iters;
     uint8_t* quirk;            // [n_strands] the strand contains a Q6 vertex
     uint64_t* term;            // [n_strands][W]
     LsElem* ls;                // [n_slots][ecap]
     uint32_t ecap;
+    struct LsSnap* snap;       // walk kernel: [n_slots][LDBG_SNAP_CAP] link-store snapshots of the repeat detection (runstep.h), or nullptr
     unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
     unsigned long long* st_gen;     // diagnostics: [n_strands][2] ticks spent before general steps (prepare + cooperative phases), their number
@@ -51,6 +54,32 @@ struct WalkArgs {
                                   // fit a CU and every strand of a 50,000-seed batch has a lane (profiles/r01_exp_ls_fast.log:
                                   // 8/12/16 elements 0.356 s per launch, 24 elements 0.41 s, 32 elements 0.44 s)
 #endif
+
+// ---- path descriptors (walk kernel).  A vertex entry (engine.h: path_pack) uses bits 0..60; an entry with bit 63 set is the head
+// of a descriptor, followed by one payload word (a pair never straddles two path blocks: a PAD entry fills the gap).
+//   RUN     head: len (bits 0..19) | |copyIndex| (20..35) | ascending positions (36) | flips inverted (37); payload: first position.
+//           = len consecutive vertices of the run index (runs.h), all with the same copyIndex
+//   REPEAT  head: count (bits 0..31); payload: first | period << 32.  The 2 * period vertices of this strand from vertex `first` on
+//           are two revolutions of a walk that has been shown to repeat itself (runstep.h: periodic_check); `count` further
+//           vertices follow: revolution after revolution the same records, each copyIndex moving on by the difference between
+//           the two revolutions on record
+#define LDBG_PD_TAG (1ull << 63)
+#define LDBG_PD_KIND(e) ((unsigned)((e) >> 60) & 7u)
+#define LDBG_PD_RUN 0u
+#define LDBG_PD_REPEAT 1u
+#define LDBG_PD_PAD 7u
+LDBG_HOSTDEV uint64_t pd_run_head(uint32_t len, uint32_t acopy, bool asc, bool inv) {
+    return LDBG_PD_TAG | ((uint64_t)LDBG_PD_RUN << 60) | (uint64_t)(len & 0xFFFFFu) | ((uint64_t)(acopy & 0xFFFFu) << 20) | ((uint64_t)(asc ? 1 : 0) << 36) | ((uint64_t)(inv ? 1 : 0) << 37);
+}
+LDBG_HOSTDEV uint64_t pd_repeat_head(uint32_t count) { return LDBG_PD_TAG | ((uint64_t)LDBG_PD_REPEAT << 60) | (uint64_t)count; }
+LDBG_HOSTDEV uint64_t pd_pad() { return LDBG_PD_TAG | ((uint64_t)LDBG_PD_PAD << 60); }
+// vertices an entry stands for, given the entry before it (0 if there is none)
+LDBG_HOSTDEV uint32_t pd_expanded(uint64_t prev, uint64_t e) {
+    if ((prev & LDBG_PD_TAG) && LDBG_PD_KIND(prev) != LDBG_PD_PAD) return 0u;        // e is a payload word
+    if (!(e & LDBG_PD_TAG)) return 1u;
+    const unsigned kd = LDBG_PD_KIND(e);
+    return kd == LDBG_PD_RUN ? (uint32_t)(e & 0xFFFFFu) : (kd == LDBG_PD_REPEAT ? (uint32_t)e : 0u);
+}
 
 LDBG_DEV uint64_t pack_vertex(const Node& v) { return path_pack(v.idx, v.flip != 0, v.base, v.copy, v.flip && !v.fj); }
 
@@ -76,6 +105,10 @@ LDBG_DEV bool path_append(const WalkArgs& a, int64_t s, PathWriter& pw, uint64_t
     pw.cur[off] = entry;
     pw.n++;
     return true;
+}
+LDBG_DEV bool path_append_pair(const WalkArgs& a, int64_t s, PathWriter& pw, uint64_t head, uint64_t payload) {
+    if ((pw.n & (LDBG_PATH_BLOCK - 1)) == LDBG_PATH_BLOCK - 1 && !path_append(a, s, pw, pd_pad())) return false;
+    return path_append(a, s, pw, head) && path_append(a, s, pw, payload);
 }
 LDBG_DEV uint64_t path_read(const WalkArgs& a, int64_t s, uint32_t pos) {
     return a.pool[(uint64_t)a.block_table[s * a.max_blocks + pos / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK + (pos & (LDBG_PATH_BLOCK - 1))];

@@ -7,13 +7,23 @@
 #include <numeric>
 
 #include "lscoop.h"
+#include "runs.h"
+#include "runstep.h"
 #include "strand.h"
 
 namespace ldbg {
 
+// the walk kernel's strand_finish: strand_n counts VERTICES (runs are stored as descriptors), strand_c the stored entries
+LDBG_DEV void walk_finish(const WalkArgs& a, StrandState& st) {
+    strand_finish(a, st);
+    const bool good = !st.branch_null && st.status == ST_OK;
+    a.strand_n[st.s] = good ? st.gV : 0u;
+    a.strand_c[st.s] = good ? st.pw.n : 0u;
+}
+
 // one iteration of the do-loop at TraversalEngine.java:373-481; returns true when the branch has ended
 template <int W>
-LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, const StepPre& pre) {
+LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, const StepPre& pre, RunState& rs) {
     const EngineView& e = a.e;
     const bool fwd = st.fwd;
     if (st.status != ST_OK) return true;     // pool exhausted while regrowing the table
@@ -23,7 +33,7 @@ LDBG_DEV bool strand_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, 
     int adj = 0;
     Node av = cv;
     if (e.cursor_on && st.cu.has) {                     // :379-407
-        av = cursor_step<W, true>(e, st.cu, ls, st.vt, fwd, &pre);
+        av = cursor_step<W, true>(e, st.cu, ls, st.vt, fwd, &pre, &rs.seen_marks);
         if (st.cu.status != ST_OK) { st.status = st.cu.status; return true; }
         if (st.cu.has) { node_sync(cv, st.cu.nxt); node_sync(av, st.cu.nxt); }   // the `seen` mark may sit in a slot they hold
         const int cnt = node_count(av);                 // first unused copyIndex
@@ -75,15 +85,16 @@ LDBG_DEV bool lean_ok(const WalkArgs& a, const StrandState& st) {
     return lean_cursor_ok(a.e, st) && st.gV >= 2 && st.gV <= (uint32_t)a.e.max_len       // not the first step, not at the maxLength cut
         && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u;                                       // room in the current path block
 }
-LDBG_DEV bool lean_again(const WalkArgs& a, const StrandState& st) {                     // between two lean steps of a run
-    return lean_cursor_again(a.e, st) && st.gV <= (uint32_t)a.e.max_len && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u;
+LDBG_DEV bool lean_again(const WalkArgs& a, const StrandState& st, const RunState& rs) {                     // between two lean steps of a run
+    return lean_cursor_again(a.e, st) && st.gV <= (uint32_t)a.e.max_len && (st.pw.n & (LDBG_PATH_BLOCK - 1)) != 0u
+        && !(a.e.runs.uinfo && run_entry_a(a.e, st, rs));      // the interior of a piece belongs to the run step (runstep.h)
 }
 template <int W>
-LDBG_DEV void lean_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls) {
+LDBG_DEV void lean_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, RunState& rs) {
 #ifdef LDBG_LEAN_PROFILE
     const unsigned long long t0 = __builtin_readcyclecounter();
 #endif
-    const Node av = lean_cursor_advance<W>(a.e, st, ls);
+    const Node av = lean_cursor_advance<W>(a.e, st, ls, &rs.seen_marks);
 #ifdef LDBG_LEAN_PROFILE
     if (a.st_gen && a.e.lean_rows) {     // [4s..]: issue, wait, rest (cycles), steps — read by hand from the diagnostics
         const unsigned long long t3 = __builtin_readcyclecounter();
@@ -126,6 +137,10 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     lw.el = a.ls + (size_t)(slot - wave_lane()) * a.ecap; lw.ecap = a.ecap;
     StrandState st;
     st.vt.tab = nullptr; st.vt.mask = 0; st.vt.used = 0; st.status = ST_OK;
+    RunState rs;
+    rs.seed_pos = LDBG_RUN_NONE; rs.seen_marks = 0; rs.choices = 0; rs.anchor_at = 0; rs.anchor_gv = 0; rs.anchor_marks = 0; rs.anchor_n = 0; rs.anchor_cap = 0;
+    rs.period = 0; rs.anchor_sig = 0; rs.anchor_cv = 0; rs.anchor_t = 0;
+    const bool runs_on = a.e.runs.uinfo != nullptr;
     bool active = false, exhausted = false;
     unsigned long long wave_iterations = 0;
     // all lanes of a wavefront stay in the loop until every one of them has run out of strands: the table
@@ -136,41 +151,64 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             const int64_t fi = (int64_t)atomic_add_u64(a.next_strand, 1ull);
             if (fi >= a.n_strands) exhausted = true;
             else {
-                const int64_t s = (int64_t)(((unsigned __int128)fi * (unsigned __int128)a.fetch_stride) % (unsigned __int128)a.n_strands);
+                int64_t s;
+                if (a.retry) s = (int64_t)a.retry[fi];
+                else s = (int64_t)(((unsigned __int128)fi * (unsigned __int128)a.fetch_stride) % (unsigned __int128)a.n_strands);
                 const bool fwd = (s & 1) != 0;
                 if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
-                    a.strand_n[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0; a.quirk[s] = 0;
+                    a.strand_n[s] = 0; a.strand_c[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0; a.quirk[s] = 0;
                 } else {
                     active = strand_begin<W>(a, st, ls, s);
-                    if (!active) strand_finish(a, st);
+                    rs.seed_pos = st.cv.idx >= 0 && ui_valid(st.cv.ui) ? ui_pos(st.cv.ui) : LDBG_RUN_NONE;
+                    rs.seen_marks = 0; rs.choices = 0; rs.anchor_at = 0; rs.period = 0;
+                    if (!active) walk_finish(a, st);
                 }
             }
         }
         wave_grow_tables(a, st, active);
-        const bool lean = active && lean_ok(a, st);
+        // ---- run step: a whole unbranched stretch at once (runstep.h)
+        bool stepped = false;
+        if (runs_on && active) {
+            const bool ma = run_mode_a(a, st, rs);
+            const bool mb = !ma && run_mode_b(a, st, rs);
+            if (ma || mb) {
+                stepped = true;
+                if (run_step<W>(a, st, ls, rs, ma)) { walk_finish(a, st); active = false; }
+            }
+        }
+        const bool lean = active && !stepped && lean_ok(a, st) && !(runs_on && run_entry_a(a.e, st, rs));
         if (lean) {
             // a short run of lean steps without going round the outer loop (its ballots, refill and regrowth checks): every lean
             // step claims at most one table slot, and the regrowth check above leaves room for eight
             int r = 0;
+            const uint32_t used0 = st.vt.used;
 #pragma unroll 1
-            do { lean_step<W>(a, st, ls); } while (++r < a.lean_run && lean_again(a, st));     // one copy of the step: the loop lives in the instruction cache
+            do { lean_step<W>(a, st, ls, rs); } while (++r < a.lean_run && lean_again(a, st, rs));     // one copy of the step: the loop lives in the instruction cache
+            rs.seen_marks += st.vt.used - used0;
             st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
-        if (wave_ballot(active && !lean) == 0ull) continue;          // the whole wavefront took the lean step
+        if (wave_ballot(active && !lean && !stepped) == 0ull) continue;          // the whole wavefront took a lean or a run step
 #ifndef LDBG_HOSTSIM
         const unsigned long long t_general = a.st_gen ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
-        const bool cur_mode = active && !lean && st.status == ST_OK && a.e.cursor_on && st.cu.has;
+        const bool general = active && !lean && !stepped;
+        const bool cur_mode = general && st.status == ST_OK && a.e.cursor_on && st.cu.has;
         StepPre pre;
+        const uint32_t used1 = st.vt.used;
         coop_step_prepare<W>(a.e, st, ls, lw, cur_mode, pre);
 #ifndef LDBG_HOSTSIM
-        if (a.st_gen && active && !lean) {       // diagnostics: time this strand spends in general steps (prepare + cooperative phases + step)
+        if (a.st_gen && general) {       // diagnostics: time this strand spends in general steps (prepare + cooperative phases + step)
             a.st_gen[2 * st.s] += __builtin_amdgcn_s_memrealtime() - t_general;
             a.st_gen[2 * st.s + 1] += 1;
         }
 #endif
-        if (active && !lean && strand_step<W>(a, st, ls, pre)) { strand_finish(a, st); active = false; }
+        if (general) {
+            bool ended = strand_step<W>(a, st, ls, pre, rs);
+            rs.seen_marks += st.vt.used - used1;
+            if (!ended && a.snap && pre.choice_done && st.status == ST_OK) ended = periodic_check(a, st, ls, rs, a.snap + (size_t)slot * LDBG_SNAP_CAP);
+            if (ended) { walk_finish(a, st); active = false; }
+        }
     }
 #ifndef LDBG_HOSTSIM
     if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -219,6 +257,81 @@ LDBG_KERNEL void k_compact_paths(const uint64_t* pool, const uint32_t* block_tab
         const int64_t o = strand_off[s], n = strand_off[s + 1] - o;
         for (int64_t j = lane; j < n; j += 64)
             dense[o + j] = pool[(uint64_t)block_table[s * max_blocks + j / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK + (j & (LDBG_PATH_BLOCK - 1))];
+    }
+}
+
+// ---- walk paths: stored entries (vertices and run descriptors, strand.h) -> one 8-byte vertex entry per vertex.  One wavefront per
+// strand: 64 stored entries at a time, a prefix sum of the vertices they stand for gives every entry its place; a RUN is then
+// written by the whole wavefront from the run index (coalesced reads of uo / ubase, coalesced writes), a REPEAT from the vertices
+// of this strand that are already in place.  This is where the k-mers of an unbranched stretch are materialised: 8 bytes written
+// and 5 read per vertex.
+struct ExpandArgs {
+    const uint64_t* pool; const uint32_t* block_table; int max_blocks;
+    const uint32_t* strand_c;          // stored entries per strand
+    const int64_t* strand_off;         // [n_strands + 1] vertices before each strand
+    int64_t n_strands;
+    RunIndexView runs;
+    uint64_t* dense;
+    uint32_t* status;                  // a REPEAT that takes a copyIndex out of range reports ST_COPY_OVERFLOW here
+};
+LDBG_DEV uint64_t expand_stored(const ExpandArgs& a, int64_t s, uint32_t j) {
+    return a.pool[(uint64_t)a.block_table[s * a.max_blocks + j / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK + (j & (LDBG_PATH_BLOCK - 1))];
+}
+LDBG_KERNEL void k_expand_paths(ExpandArgs a) {
+    const int64_t wave = global_tid() / wave_size(), nwaves = (global_nthreads() + wave_size() - 1) / wave_size();
+    const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
+    for (int64_t s = wave; s < a.n_strands; s += nwaves) {
+        const uint32_t nc = a.strand_c[s];
+        uint64_t* out = a.dense + a.strand_off[s];
+        const bool fwd = (s & 1) != 0;
+        uint32_t base_v = 0;                                   // vertices before the current group of stored entries
+        for (uint32_t j0 = 0; j0 < nc; j0 += WS) {
+            const uint32_t j = j0 + lane;
+            uint64_t e = 0, prev = 0;
+            if (j < nc) {
+                e = expand_stored(a, s, j);
+                if (j & (LDBG_PATH_BLOCK - 1)) prev = expand_stored(a, s, j - 1);      // a pair never straddles two blocks
+            }
+            const uint32_t cnt = j < nc ? pd_expanded(prev, e) : 0u;
+            const uint32_t incl = wave_incl_scan_u32(cnt);
+            const uint32_t at = base_v + incl - cnt;
+            const bool head = cnt > 0u && (e & LDBG_PD_TAG) != 0ull;
+            if (cnt == 1u && !head) out[at] = e;
+            unsigned long long hb = wave_ballot(head);
+            while (hb) {
+                const int L = __builtin_ctzll(hb);
+                hb &= hb - 1;
+                const uint64_t he = wave_bcast_u64(e, L);
+                const uint32_t hat = wave_bcast_u32(at, L);
+                const uint32_t hj = j0 + (uint32_t)L;
+                const uint64_t payload = expand_stored(a, s, hj + 1);
+                const uint32_t len = wave_bcast_u32(cnt, L);
+                if (LDBG_PD_KIND(he) == LDBG_PD_RUN) {
+                    const uint32_t acopy = (uint32_t)(he >> 20) & 0xFFFFu;
+                    const bool asc = (he >> 36) & 1ull, inv = (he >> 37) & 1ull;
+                    const uint32_t first = (uint32_t)payload;
+                    const int copy = fwd ? (int)acopy : -(int)acopy;
+                    for (uint32_t i = lane; i < len; i += WS) {
+                        const uint32_t pos = asc ? first + i : first - i;
+                        const uint32_t u = a.runs.uo[pos];
+                        const unsigned bb = a.runs.ubase[pos];
+                        const unsigned b0 = !inv ? (bb & 3u) : 3u - ((bb >> 2) & 3u), b1 = !inv ? ((bb >> 2) & 3u) : 3u - (bb & 3u);
+                        out[hat + i] = path_pack((int64_t)(u & 0x7FFFFFFFu), ((u >> 31) != 0u) != inv, fwd ? b1 : b0, copy);
+                    }
+                } else {                                       // REPEAT: always the last entry of its strand
+                    wave_fence();
+                    const uint32_t first = (uint32_t)payload, period = (uint32_t)(payload >> 32);
+                    for (uint32_t i = lane; i < len; i += WS) {
+                        const uint32_t o = i % period;
+                        const uint64_t s1 = LDBG_GLOBAL(const uint64_t, out)[first + o], s2 = LDBG_GLOBAL(const uint64_t, out)[first + period + o];
+                        const int c = path_copy(s2) + (int)(i / period + 1u) * (path_copy(s2) - path_copy(s1));
+                        if (c > 32767 || c < -32767) a.status[s] = ST_COPY_OVERFLOW;     // as the k-mer-by-k-mer walk reports it (:383-389 never ends; ours does)
+                        out[hat + i] = (s2 & ~(0xFFFFFFull << 36)) | (((uint64_t)(uint32_t)c & 0xFFFFFFull) << 36);
+                    }
+                }
+            }
+            base_v += wave_bcast_u32(incl, (int)WS - 1);
+        }
     }
 }
 
@@ -485,8 +598,8 @@ void Engine::launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands
 
 void Engine::release_scratch() {
     drop_spares();
-    rt::dfree(d_vpool_); rt::dfree(d_ls_); rt::dfree(d_pool_); rt::dfree(d_block_table_);
-    d_vpool_ = d_ls_ = d_pool_ = d_block_table_ = nullptr;
+    rt::dfree(d_vpool_); rt::dfree(d_ls_); rt::dfree(d_snap_); rt::dfree(d_pool_); rt::dfree(d_block_table_);
+    d_vpool_ = d_ls_ = d_snap_ = d_pool_ = d_block_table_ = nullptr;
     n_slots_ = 0; n_blocks_ = 0; bt_strands_ = 0; vpool_entries_ = 0; vpool_dirty_ = 0;
 }
 
@@ -571,6 +684,7 @@ void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks, uint64_t 
     n_blocks_ = std::max<uint64_t>(2, std::min<uint64_t>(want_blocks, (uint64_t)(free_b * 0.35) / (LDBG_PATH_BLOCK * 8)));
     d_vpool_ = rt::dmalloc((size_t)vpool_entries_ * 8);
     d_ls_ = rt::dmalloc((size_t)slots * ecap * sizeof(LsElem));
+    d_snap_ = rt::dmalloc((size_t)slots * LDBG_SNAP_CAP * sizeof(LsSnap));
     d_pool_ = rt::dmalloc((size_t)n_blocks_ * LDBG_PATH_BLOCK * 8);
     d_block_table_ = rt::dmalloc((size_t)ns * max_blocks * 4);
     rt::dmemset(d_vpool_, 0, (size_t)vpool_entries_ * 8, s);
@@ -646,17 +760,28 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     rt::h2d(out.d_seed_words, &seed_words[first * W], (size_t)n * W * 8, s);
     out.d_term = rt::dmalloc((size_t)ns * W * 8);
     uint32_t* d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    uint32_t* d_strand_c = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    uint32_t* d_retry = nullptr;
     uint32_t* d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint32_t* d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint8_t* d_quirk = (uint8_t*)rt::dmalloc((size_t)ns);
     unsigned long long* d_ctr = (unsigned long long*)rt::dmalloc(32);
     rt::dmemset(d_ctr, 0, 32, s);
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
-    auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk); };
+    auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_strand_c); rt::dfree(d_retry); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk); };
 
     laps.lap("small allocations");
     WalkArgs a;
     a.e = view;
+    if (!runs_ && !getenv("LDBG_NO_RUNS") && (view.g.k & 1)) {       // the run index of this engine's colour masks (runs.h), built on first use
+        runs_.reset(new RunIndex(view, graph->device, s));
+        profile_add("run_index", runs_->build_ms);
+        if (getenv("LDBG_HOST_TIMES"))
+            fprintf(stderr, "[ldbg] run index: %lld chains hold %lld of %lld records, built in %.1f ms\n", (long long)runs_->n_chains,
+                    (long long)runs_->n_in_chains, (long long)view.g.N, runs_->build_ms);
+    }
+    if (runs_) a.e.runs = runs_->view;
+    a.retry = nullptr;
     a.seeds = (const uint64_t*)out.d_seed_words;
     a.n_strands = ns;
     a.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
@@ -678,7 +803,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.next_block = d_ctr + 1;
     a.pool = (uint64_t*)d_pool_; a.n_blocks = n_blocks_;
     a.block_table = (uint32_t*)d_block_table_; a.max_blocks = max_blocks;
-    a.strand_n = d_strand_n; a.status = d_status; a.iters = d_iters; a.quirk = d_quirk;
+    a.strand_n = d_strand_n; a.strand_c = d_strand_c; a.status = d_status; a.iters = d_iters; a.quirk = d_quirk;
     a.term = (uint64_t*)out.d_term;
     a.vpool = (uint64_t*)d_vpool_; a.vnext = d_ctr + 2; a.vpool_entries = vpool_entries_; a.vcap_max = vcap_max;
     a.vcap_init = vt_initial_entries();
@@ -689,6 +814,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         while ((uint64_t)a.vcap_init * 4 <= per && (uint64_t)a.vcap_init * 4 <= vcap_max) a.vcap_init *= 4;
     }
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
+    a.snap = getenv("LDBG_NO_REPEAT") ? nullptr : (LsSnap*)d_snap_;
 
     a.wg_times = nullptr; a.st_times = nullptr; a.st_gen = nullptr;
     const bool want_times = getenv("LDBG_WG_TIMES") != nullptr;
@@ -728,6 +854,36 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
 #undef LDBG_WALK_CASE
     e1.record(s);
 
+    // strands the run steps handed back (ST_RETRY_PLAIN) are walked again k-mer by k-mer, without the run index
+    out.status.resize(ns);
+    rt::d2h(out.status.data(), d_status, (size_t)ns * 4, s);
+    rt::stream_sync(s);
+    if (runs_) {
+        std::vector<uint32_t> again;
+        for (int64_t i = 0; i < ns; i++) if (out.status[i] == ST_RETRY_PLAIN) again.push_back((uint32_t)i);
+        if (!again.empty()) {
+            d_retry = (uint32_t*)rt::dmalloc(again.size() * 4);
+            rt::h2d(d_retry, again.data(), again.size() * 4, s);
+            rt::dmemset(d_ctr, 0, 8, s);                       // the strand queue starts over; the pool cursors carry on
+            WalkArgs b = a;
+            b.e.runs = RunIndexView{nullptr, nullptr, nullptr};
+            b.retry = d_retry;
+            b.n_strands = (int64_t)again.size();
+            retried_strands_ += (int64_t)again.size();
+#define LDBG_WALK_CASE(WW) \
+    if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, b); \
+    else if (block == 64) LDBG_LAUNCH((k_walk<WW, 64>), grid, 64, s, b); \
+    else LDBG_LAUNCH((k_walk<WW, 32>), grid, 32, s, b)
+            switch (W) {
+                case 1: LDBG_WALK_CASE(1); break;
+                case 2: LDBG_WALK_CASE(2); break;
+                case 3: LDBG_WALK_CASE(3); break;
+                default: LDBG_WALK_CASE(4); break;
+            }
+#undef LDBG_WALK_CASE
+        }
+    }
+
     // lengths + seed test
     int64_t* d_walk_len = (int64_t*)rt::dmalloc((size_t)n * 8);
     uint8_t* d_seed_ok = (uint8_t*)rt::dmalloc((size_t)n);
@@ -739,7 +895,6 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     LDBG_LAUNCH(k_walk_lengths, grid_for(n, 256, 2048), 256, s, aa);
 
     std::vector<uint32_t> strand_n(ns), iters(ns);
-    out.status.resize(ns);
     out.walk_len.resize(n);
     out.seed_ok.resize(n);
     rt::d2h(strand_n.data(), d_strand_n, (size_t)ns * 4, s);
@@ -841,8 +996,13 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     laps.lap("result buffers");
     rt::Event c0, c1;
     c0.record(s);
-    LDBG_LAUNCH(k_compact_paths, grid_for(ns * 64, 256, 4096), 256, s, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
-                (const int64_t*)d_strand_off, ns, (uint64_t*)out.d_path);
+    {
+        ExpandArgs xa;
+        xa.pool = (const uint64_t*)d_pool_; xa.block_table = (const uint32_t*)d_block_table_; xa.max_blocks = max_blocks;
+        xa.strand_c = d_strand_c; xa.strand_off = d_strand_off; xa.n_strands = ns;
+        xa.runs = a.e.runs; xa.dense = (uint64_t*)out.d_path; xa.status = d_status;
+        LDBG_LAUNCH(k_expand_paths, grid_for(ns * 64, 64, 256 * 64), 64, s, xa);
+    }
     const int cg = grid_for(n * 64, 256, 4096);
     ContigArgs ca;
     ca.g = graph->view; ca.n = n; ca.seeds = a.seeds; ca.dense = (const uint64_t*)out.d_path; ca.strand_off = d_strand_off;
@@ -855,6 +1015,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         default: LDBG_LAUNCH(k_contigs<4>, cg, 256, s, ca); break;
     }
     c1.record(s);
+    rt::d2h(out.status.data(), d_status, (size_t)ns * 4, s);       // (the expansion reports copy counts that leave their range)
     rt::stream_sync(s);
     profile_add("contig", rt::Event::elapsed_ms(c0, c1));
     laps.lap("compaction + contigs");

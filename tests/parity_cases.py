@@ -334,6 +334,60 @@ def case_dense_cycles(orc, lib, tmp, seed):
     compare_walks(cs, seeds, trav=[0, 1], links=["a", "b"], max_len=12)
 
 
+def compare_walk_vertices(case, seeds, **cfg):
+    """vertex by vertex: (k-mer, record, copyIndex, index) of every walk against the vertex set of the oracle's dfs graph"""
+    oe, e = case.engines(**cfg)
+    seeds = list(seeds)
+    e.walk_batch_arrays(seeds, fetch=False)
+    for i, s in enumerate(seeds):
+        got = e.walk_vertices(i)
+        r = oe.dfs(s)
+        exp = [] if r.is_null else r.vertices()
+        gt = sorted((v.getKmerAsString(), v.getCortexRecord() is not None, v.getCopyIndex(), v.getIndex()) for v in got)
+        if got:
+            et = sorted((km, rec >= 0, ci, ix) for km, rec, ci, ix in exp)
+            assert gt == et, (s, cfg, len(gt), len(et), [x for x in gt if x not in et][:4], [x for x in et if x not in gt][:4])
+        r.free()
+
+
+def case_run_steps(orc, lib, tmp, seed):
+    """long unbranched stretches crossed several times: tandem arrays with long units (a link-guided walk goes round them, every
+    revolution crossing the same stretches with the next copyIndex), seeds in the middle of a stretch that the walk comes
+    back to, inverted repeats (the same stretch in both orientations), maxLength falling inside a stretch.  Exercises the run
+    steps and the repeat detection of the walk kernel (csrc/runstep.h) against the k-mer-by-k-mer oracle."""
+    rng = random.Random(1000 + seed)
+    k = rng.choice([9, 11, 15, 21])
+    parts = []
+    for _ in range(3):
+        parts.append(rand_seq(rng, rng.randint(40, 160)))
+        unit = rand_seq(rng, rng.randint(k + 3, 3 * k + 20))
+        parts.append(unit * rng.randint(2, 9))
+        parts.append(rand_seq(rng, rng.randint(30, 90)))
+        inv = rand_seq(rng, rng.randint(k + 5, 3 * k))
+        parts.append(inv + rand_seq(rng, rng.randint(5, 40)) + orc.revcomp(inv))
+    rep = rand_seq(rng, rng.randint(2 * k, 4 * k))
+    g1 = "".join(parts) + rep + rand_seq(rng, 50) + rep + rand_seq(rng, 60)
+    g2 = mutate(rng, g1, snv=0.01, indel=0.0)
+    rl = rng.choice([4 * k, 6 * k, 12 * k])
+    reads = {"a": [g1[i:i + rl] for i in range(0, max(1, len(g1) - rl + 1), max(1, k // 2))] + [g1[-rl:]]}
+    cs = Case(orc, tmp, lib, [("a", [g1]), ("b", [g2])], k, link_samples=["a"], reads=reads, name="rs%d" % seed)
+    kmers = cs.all_kmers()
+    seeds = rng.sample(kmers, min(100, len(kmers)))
+    seeds = [s if rng.random() < 0.5 else orc.revcomp(s) for s in seeds] + [g1[:k], g1[-k:], orc.revcomp(g1[100:100 + k])]
+    compare_walks(cs, seeds[:6], trav=[0], links=["a"], max_len=75000)
+    for ml in (3000, 997):
+        compare_walks(cs, seeds, trav=[0], links=["a"], max_len=ml)
+    compare_walks(cs, seeds, trav=[0])
+    compare_walks(cs, seeds[:60], trav=[0, 1], links=["a"], max_len=2000)
+    compare_walks(cs, seeds[:60], trav=[0], recruit=[1], links=["a"], max_len=1500, direction=FORWARD)
+    compare_walks(cs, seeds[:60], trav=[1], links=["a"], max_len=1500)           # cursor driven, no usable links
+    for ml in rng.sample(range(20, 400), 6):
+        compare_walks(cs, seeds[:40], trav=[0], links=["a"], max_len=ml)
+        compare_walks(cs, seeds[:40], trav=[0], max_len=ml)
+    compare_walk_vertices(cs, seeds[:50], trav=[0], links=["a"], max_len=1200)
+    compare_walk_vertices(cs, seeds[:30], trav=[0], max_len=300)
+
+
 def case_long_walks(orc, lib, tmp):
     """walks far longer than the initial per-strand visited table (4096 entries) and than one path block (1024):
     exercises table regrowth, block chaining, and the maxLength cut"""

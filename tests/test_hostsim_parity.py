@@ -37,6 +37,10 @@ def test_random_walks(orc, lib, tmp_path, k, seed, links): pc.case_random_walks(
 def test_dense_cycles(orc, lib, tmp_path, seed): pc.case_dense_cycles(orc, lib, tmp_path, seed)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_run_steps(orc, lib, tmp_path, seed): pc.case_run_steps(orc, lib, tmp_path, seed)
+
+
 def test_long_walks(orc, lib, tmp_path): pc.case_long_walks(orc, lib, tmp_path)
 
 
