@@ -28,10 +28,11 @@ N_SEEDS = 50000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def workload_files(args, rank):
+def workload_files(args, rank, n_seeds=None):
     """generate (or reuse) the synthetic inputs; returns (prefix, stats)"""
     from tools import synth
-    tag = "c3_L%d_k%d_s%d_r%d" % (args.genome_len, args.k, args.seeds, rank)
+    n_seeds = n_seeds or args.seeds
+    tag = "c3_L%d_k%d_s%d_r%d" % (args.genome_len, args.k, n_seeds, rank)
     d = os.environ.get("LDBG_BENCH_DIR", "/tmp/ldbg_bench")
     os.makedirs(d, exist_ok=True)
     prefix = os.path.join(d, tag)
@@ -42,13 +43,13 @@ def workload_files(args, rank):
     # every rank builds the same graph (same seed); only the seed-list RNG stream differs per rank
     st = synth.generate(prefix, args.genome_len, args.k, colours=3, with_links=True, seed=0xC0FFEE03, n_chrom=14,
                         n_repeat_families=args.repeat_families, repeat_copies=4, repeat_len=(50, 300),
-                        n_seeds=args.seeds, threads=min(16, os.cpu_count() or 1))
+                        n_seeds=n_seeds, threads=min(16, os.cpu_count() or 1))
     st["gen_seconds"] = round(time.time() - t, 1)
     json.dump(st, open(meta, "w"))
     return prefix, st
 
 
-def cpu_baseline(prefix, args, gpu_contigs, seeds_ascii):
+def cpu_baseline(prefix, args, gpu_contigs, seeds_ascii, n_batch):
     """oracle ("port" of the reference algorithm: ASCII 3-point search, LRU, link store) on a bounded sample"""
     import numpy as np
     from oracle import pyoracle as orc
@@ -59,7 +60,7 @@ def cpu_baseline(prefix, args, gpu_contigs, seeds_ascii):
     t0 = time.time()
     n = 0
     mismatches = 0
-    while n < len(seeds_ascii) and time.time() - t0 < budget:
+    while n < len(seeds_ascii) and time.time() - t0 < budget:        # (seeds_ascii is a random sample of the batch, drawn by the caller)
         contig, _ = e.walk(seeds_ascii[n].tobytes().decode())
         if contig != gpu_contigs[n]:
             mismatches += 1
@@ -68,8 +69,8 @@ def cpu_baseline(prefix, args, gpu_contigs, seeds_ascii):
     trav = e.kmers_traversed()
     return {
         "value": trav / dt, "unit": "k-mers traversed/s", "cores": 1, "kind": "port",
-        "sample": "first %d of the %d seeds of rank 0 (%d k-mers traversed in %.1f s), oracle in faithful mode "
-                  "(ASCII 3-point binary search + 1M-entry LRU, CortexGraph.java:272-317)" % (n, len(seeds_ascii), trav, dt),
+        "sample": "%d seeds drawn at random (seed 20261004) from the %d of rank 0 (%d k-mers traversed in %.1f s), oracle in faithful mode "
+                  "(ASCII 3-point binary search + 1M-entry LRU, CortexGraph.java:272-317)" % (n, n_batch, trav, dt),
         "contigs_per_s": n / dt,
     }, n, mismatches
 
@@ -413,15 +414,16 @@ def main():
     # same graph on every rank: rank 0 generates the files (once), the others wait for them
     if dist is not None and rank != 0:
         dist.barrier()
-    prefix, st = workload_files(args, 0)
+    # weak scaling: world x 50,000 DISTINCT seeds are drawn from the one graph and dealt out, rank r walks seeds r, r + world, ...
+    # (the de novo k-mers are a fixed set of ~21,600, so with N ranks each rank's share holds 1/N of them and more random child k-mers)
+    prefix, st = workload_files(args, 0, n_seeds=args.seeds * max(1, world))
     if dist is not None and rank == 0:
         dist.barrier()
     seeds = np.fromfile(prefix + ".seeds", dtype=np.uint8).reshape(-1, args.k)
+    if world > 1:
+        seeds = np.ascontiguousarray(seeds[rank::world])
     if args.use_seeds:
         seeds = seeds[np.random.default_rng(7).permutation(len(seeds))[:args.use_seeds]]
-    if world > 1:                               # weak scaling: each rank walks its own seeds
-        rng = np.random.default_rng(1000 + rank)
-        seeds = seeds[rng.permutation(len(seeds))]
 
     if args.workload == "c5s":
         return bench_c5s(args, ca, prefix, seeds, rank, local_rank, world, dist)
@@ -457,6 +459,15 @@ def main():
     dt = time.time() - t0
     walk_ms, walk_launches = ca.profile_get("walk")
     contig_ms, _ = ca.profile_get("contig")
+    # the same steps with every contig downloaded to the caller (what the reference's walk() hands over): reported beside `value`
+    sync()
+    t1 = time.time()
+    fetched_bytes = 0
+    for _ in range(args.steps):
+        arena, _, _ = eng.walk_batch_arrays(seeds, fetch=True)
+        fetched_bytes += len(arena)
+    sync()
+    dt_fetch = time.time() - t1
 
     tot_trav, tot_seeds, max_dt = traversed, len(seeds) * args.steps, dt
     if dist is not None:
@@ -476,15 +487,21 @@ def main():
         per_launch_units = traversed / max(1, walk_launches)
         avg_ms = walk_ms / max(1, walk_launches)
         achieved = per_launch_units * (b_find + b_link) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes of tools/profile_walk.sh (FETCH_SIZE, WRITE_SIZE); only trusted when they were
+        # taken on this very build of the library
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "walk_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r02_walk_traffic.json")
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tf))
+            if tj.get("library") == ca.default_lib().dll.ldbg_version().decode():
+                traffic = tj.get("hbm_bytes_per_launch")
+        measured = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None
         out = {
             "metric": "k-mers traversed/sec (whole node) + contigs/sec, k=47 3-color LdBG",
             "value": tot_trav / max_dt, "unit": "k-mers traversed/s", "contigs_per_s": tot_seeds / max_dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "library": ca.default_lib().dll.ldbg_version().decode(),
             "config": {
                 "workload": "configs[2]: synthetic %.1f Mb 3-colour k=%d LdBG with child links (read 250 bp / stride 8), "
                             "link-guided ContigStopper walks BOTH/OR from %d seeds per GPU (%d de novo), maxLength %d"
@@ -498,12 +515,21 @@ def main():
                 "bound": "hbm", "kernel": "k_walk<%d>" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_kmer": b_find + b_link, "avg_launch_ms": avg_ms, "launches": walk_launches,
+                "frac_b_find_only": per_launch_units * b_find / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
+                "measured_gbs": measured, "measured_frac": measured / HBM_PEAK_GBS if measured else None,
+                "note": "achieved = k-mers traversed x the reference's per-k-mer search bytes (SURVEY 8d) / launch time: the run index "
+                        "(records in unitig order) crosses an unbranched stretch in one step, so the kernel no longer performs those "
+                        "searches and the algorithmic figure exceeds the HBM peak; measured_gbs is the kernel's real HBM traffic",
                 "contig_kernels_ms_per_step": contig_ms / max(1, args.steps),
             },
+            "with_contigs_fetched": {"value": tot_trav / max_dt * dt / dt_fetch if dt_fetch > 0 else None, "ms_per_step": dt_fetch / args.steps * 1e3,
+                                     "bytes_per_step": fetched_bytes // max(1, args.steps),
+                                     "note": "rank 0's steps again with all contigs copied to host memory (PCIe)"},
         }
         if not args.no_cpu_baseline:
-            contigs, _ = eng.walk_batch(seeds[:2000])
-            base, n_cmp, mism = cpu_baseline(prefix, args, contigs, seeds)
+            pick = np.random.default_rng(20261004).choice(len(seeds), min(2000, len(seeds)), replace=False)
+            contigs, _ = eng.walk_batch(seeds[pick])
+            base, n_cmp, mism = cpu_baseline(prefix, args, contigs, seeds[pick], len(seeds))
             out["cpu_baseline"] = base
             out["cpu_baseline_tuned_all_cores"] = cpu_baseline_tuned(prefix, args, seeds)
             out["parity"] = "%d/%d sampled contigs bit-exact vs oracle" % (n_cmp - mism, n_cmp)

@@ -51,7 +51,10 @@ ldbg_engine_config unwrap(const ldbg_engine_config& c, std::vector<const ldbg_li
 extern "C" {
 
 const char* ldbg_last_error(void) { return g_err.c_str(); }
-const char* ldbg_version(void) { return "ldbg 0.1 (gfx950)"; }
+#ifndef LDBG_SRCID
+#define LDBG_SRCID "unstamped"
+#endif
+const char* ldbg_version(void) { return "ldbg 0.2 (gfx950, src " LDBG_SRCID ")"; }
 ldbg_status ldbg_device_count(int* count) { *count = rt::device_count(); return LDBG_OK; }
 
 ldbg_status ldbg_kmer_encode(const char* ascii, int k, uint64_t* words_out) {
@@ -225,12 +228,26 @@ ldbg_status ldbg_graph_find(const ldbg_graph* g, const uint64_t* packed, int64_t
 }
 ldbg_status ldbg_graph_find_ascii(const ldbg_graph* g, const char* kmers, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {
     return guard([&] {
-        const int W = g->g.hdr.W, k = g->g.hdr.k;
+        rt::set_device(g->g.device);
+        const int W = g->g.hdr.W, k = g->g.hdr.k, C = g->g.hdr.C;
+        if (n <= 0) return;
         std::vector<uint64_t> packed((size_t)n * W);
-        for (int64_t i = 0; i < n; i++)
-            if (!ascii_to_words(kmers + i * k, k, &packed[i * W], W)) packed[i * W] = ~0ull;   // Q4: non-ACGT never matches
-        ldbg_status st = ldbg_graph_find(g, packed.data(), n, idx_out, cov_out, edges_out);
-        if (st != LDBG_OK) throw StatusError(st, g_err);
+        std::vector<uint8_t> valid((size_t)n);
+        ascii_batch_to_words(kmers, n, k, W, packed.data(), valid.data());      // Q4: a string with a non-ACGT byte never matches
+        rt::stream_t s = g->g.stream;
+        uint64_t* dq = (uint64_t*)rt::dmalloc((size_t)n * W * 8);
+        uint8_t* dv = (uint8_t*)rt::dmalloc((size_t)n);
+        int64_t* di = (int64_t*)rt::dmalloc((size_t)n * 8);
+        uint32_t* dc = cov_out ? (uint32_t*)rt::dmalloc((size_t)n * C * 4) : nullptr;
+        uint8_t* de = edges_out ? (uint8_t*)rt::dmalloc((size_t)n * C) : nullptr;
+        rt::h2d(dq, packed.data(), (size_t)n * W * 8, s);
+        rt::h2d(dv, valid.data(), (size_t)n, s);
+        g->g.find_dev(dq, n, di, dc, de, s, dv);
+        rt::d2h(idx_out, di, (size_t)n * 8, s);
+        if (cov_out) rt::d2h(cov_out, dc, (size_t)n * C * 4, s);
+        if (edges_out) rt::d2h(edges_out, de, (size_t)n * C, s);
+        rt::stream_sync(s);
+        rt::dfree(dq); rt::dfree(dv); rt::dfree(di); rt::dfree(dc); rt::dfree(de);
     });
 }
 

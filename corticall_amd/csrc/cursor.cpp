@@ -37,12 +37,12 @@ LDBG_DEV void cs_reseek(const EngineView& e, CursorStateDev<W>& st, uint64_t* vt
 }
 
 template <int W>
-LDBG_KERNEL void k_cursor_seek(EngineView e, CursorStateDev<W>* stp, const uint64_t* words, uint64_t* vtab, uint32_t vcap) {
+LDBG_KERNEL void k_cursor_seek(EngineView e, CursorStateDev<W>* stp, const uint64_t* words, int is_kmer, uint64_t* vtab, uint32_t vcap) {
     if (global_tid() != 0) return;
     CursorStateDev<W>& st = *stp;
     Kmer<W> sk;
     for (int i = 0; i < W; i++) sk.w[i] = words[i];
-    if (words[0] != ~0ull) node_find<W>(e, sk, st.cur);
+    if (is_kmer) node_find<W>(e, sk, st.cur);
     else node_null(e, st.cur);
     for (int i = 0; i < W; i++) st.cur_words[i] = sk.w[i];
     cs_reseek<W>(e, st, vtab, vcap);
@@ -144,13 +144,14 @@ void CursorHost::seek(const char* kmer) {
     const int W = eng_.graph->hdr.W, k = eng_.graph->hdr.k;
     rt::stream_t s = eng_.graph->stream;
     std::vector<uint64_t> w(W);
-    if (!ascii_to_words(kmer, k, w.data(), W)) w[0] = ~0ull;
+    const int is_kmer = ascii_to_words(kmer, k, w.data(), W) ? 1 : 0;       // validity beside the words: at k = 32, 64, ... no bit pattern is free (Q4)
+    if (!is_kmer) std::fill(w.begin(), w.end(), 0ull);
     rt::h2d(impl_->d_words, w.data(), (size_t)W * 8, s);
     switch (W) {
-        case 1: LDBG_LAUNCH(k_cursor_seek<1>, 1, 64, s, eng_.view, (CursorStateDev<1>*)impl_->d_state, (const uint64_t*)impl_->d_words, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
-        case 2: LDBG_LAUNCH(k_cursor_seek<2>, 1, 64, s, eng_.view, (CursorStateDev<2>*)impl_->d_state, (const uint64_t*)impl_->d_words, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
-        case 3: LDBG_LAUNCH(k_cursor_seek<3>, 1, 64, s, eng_.view, (CursorStateDev<3>*)impl_->d_state, (const uint64_t*)impl_->d_words, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
-        default: LDBG_LAUNCH(k_cursor_seek<4>, 1, 64, s, eng_.view, (CursorStateDev<4>*)impl_->d_state, (const uint64_t*)impl_->d_words, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
+        case 1: LDBG_LAUNCH(k_cursor_seek<1>, 1, 64, s, eng_.view, (CursorStateDev<1>*)impl_->d_state, (const uint64_t*)impl_->d_words, is_kmer, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
+        case 2: LDBG_LAUNCH(k_cursor_seek<2>, 1, 64, s, eng_.view, (CursorStateDev<2>*)impl_->d_state, (const uint64_t*)impl_->d_words, is_kmer, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
+        case 3: LDBG_LAUNCH(k_cursor_seek<3>, 1, 64, s, eng_.view, (CursorStateDev<3>*)impl_->d_state, (const uint64_t*)impl_->d_words, is_kmer, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
+        default: LDBG_LAUNCH(k_cursor_seek<4>, 1, 64, s, eng_.view, (CursorStateDev<4>*)impl_->d_state, (const uint64_t*)impl_->d_words, is_kmer, (uint64_t*)impl_->d_vtab, impl_->vcap); break;
     }
     rt::stream_sync(s);
     impl_->sought = true;

@@ -376,7 +376,7 @@ LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64
 #pragma unroll
     for (int i = 0; i < W; i++) sk.w[i] = sw[i];
     Node v;
-    if (sw[0] != ~0ull) { node_find<W>(e, sk, v); node_locate(st.vt, v); }
+    if (a.w.seed_valid[s >> 1]) { node_find<W>(e, sk, v); node_locate(st.vt, v); }
     else node_null(e, v);
     if (v.npe) { st.status = ST_NULLPTR; return false; }
     open_branch<W>(a, L, ls, v, sk, 0);
@@ -435,10 +435,11 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
 
 // per sink k-mer: its (record, orientation) key for the rules' sink tests
 template <int W>
-LDBG_KERNEL void k_sink_nodes(EngineView e, const uint64_t* words, int64_t n, uint64_t* keys) {
+LDBG_KERNEL void k_sink_nodes(EngineView e, const uint64_t* words, const uint8_t* valid, int64_t n, uint64_t* keys) {
     for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
-        uint64_t key = 0;
-        if (words[i * W] != ~0ull) {
+        uint64_t key = ~0ull;             // a sink string that is not a k-mer equals no vertex's k-mer (neither key nor words are compared)
+        if (valid[i]) {
+            key = 0;
             Kmer<W> sk;
             for (int w = 0; w < W; w++) sk.w[w] = words[i * W + w];
             Node v;
@@ -685,11 +686,12 @@ DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, c
     build_roi_bits();
     const int k = graph->hdr.k, W = graph->hdr.W;
     std::vector<uint64_t> words((size_t)n * W);
-    ascii_batch_to_words(sources, n, k, W, words.data(), true);
+    seed_valid_.resize((size_t)std::max<int64_t>(1, n));
+    ascii_batch_to_words(sources, n, k, W, words.data(), seed_valid_.data());
     const int64_t nsinks = sink_offsets ? sink_offsets[n] : 0;
     std::vector<uint64_t> sink_words((size_t)std::max<int64_t>(1, nsinks) * W);
-    for (int64_t i = 0; i < nsinks; i++)
-        if (!ascii_to_words(sinks + i * k, k, &sink_words[i * W], W)) { for (int w = 0; w < W; w++) sink_words[i * W + w] = ~0ull; }
+    sink_valid_.resize((size_t)std::max<int64_t>(1, nsinks));
+    ascii_batch_to_words(sinks, nsinks, k, W, sink_words.data(), sink_valid_.data());
 
     std::unique_ptr<DfsBatch> out(new DfsBatch);
     out->k = k; out->W = W; out->C = graph->hdr.C; out->graph = graph;
@@ -729,10 +731,13 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     struct Tmp { std::vector<void*> p; ~Tmp() { for (void* x : p) rt::dfree(x); } void* get(size_t nbytes) { void* x = rt::dmalloc(nbytes); p.push_back(x); return x; } } tmp;
     uint64_t* d_seeds = (uint64_t*)tmp.get((size_t)n * W * 8);
     rt::h2d(d_seeds, &seed_words[first * W], (size_t)n * W * 8, s);
+    uint8_t* d_seed_valid = (uint8_t*)tmp.get((size_t)n);
+    rt::h2d(d_seed_valid, &seed_valid_[first], (size_t)n, s);
     const int64_t sink_lo = sink_offsets ? sink_offsets[first] : 0, sink_hi = sink_offsets ? sink_offsets[first + n] : 0;
     const int64_t nsk = sink_hi - sink_lo;
     uint64_t* d_sink_words = (uint64_t*)tmp.get((size_t)std::max<int64_t>(1, nsk) * W * 8);
     uint64_t* d_sink_keys = (uint64_t*)tmp.get((size_t)std::max<int64_t>(1, nsk) * 8);
+    uint8_t* d_sink_valid = (uint8_t*)tmp.get((size_t)std::max<int64_t>(1, nsk));
     int64_t* d_sink_off = nullptr;
     if (sink_offsets) {
         std::vector<int64_t> off((size_t)n + 1);
@@ -742,12 +747,13 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         rt::stream_sync(s);    // `off` leaves scope
         if (nsk > 0) {
             rt::h2d(d_sink_words, &sink_words[sink_lo * W], (size_t)nsk * W * 8, s);
+            rt::h2d(d_sink_valid, &sink_valid_[sink_lo], (size_t)nsk, s);
             const int g = grid_of(nsk, 256, 1024);
             switch (W) {
-                case 1: LDBG_LAUNCH(k_sink_nodes<1>, g, 256, s, view, (const uint64_t*)d_sink_words, nsk, d_sink_keys); break;
-                case 2: LDBG_LAUNCH(k_sink_nodes<2>, g, 256, s, view, (const uint64_t*)d_sink_words, nsk, d_sink_keys); break;
-                case 3: LDBG_LAUNCH(k_sink_nodes<3>, g, 256, s, view, (const uint64_t*)d_sink_words, nsk, d_sink_keys); break;
-                default: LDBG_LAUNCH(k_sink_nodes<4>, g, 256, s, view, (const uint64_t*)d_sink_words, nsk, d_sink_keys); break;
+                case 1: LDBG_LAUNCH(k_sink_nodes<1>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, nsk, d_sink_keys); break;
+                case 2: LDBG_LAUNCH(k_sink_nodes<2>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, nsk, d_sink_keys); break;
+                case 3: LDBG_LAUNCH(k_sink_nodes<3>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, nsk, d_sink_keys); break;
+                default: LDBG_LAUNCH(k_sink_nodes<4>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, nsk, d_sink_keys); break;
             }
         }
     }
@@ -763,10 +769,11 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     memset(&a, 0, sizeof(a));
     a.w.e = view;
     a.w.seeds = d_seeds;
+    a.w.seed_valid = d_seed_valid;
     a.w.n_strands = ns;
     a.w.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
     // every workgroup resident: LDBG_LS_FAST x 64 x 24 B of LDS each; 194 VGPRs per lane leave 2 wavefronts per SIMD = 8 per CU
-    a.w.n_slots = std::min<int64_t>(a.w.n_slots, (int64_t)std::min<size_t>(8, 160 * 1024 / (LDBG_LS_FAST * 64 * sizeof(LsElem))) * 256 * 64);
+    a.w.n_slots = std::min<int64_t>(a.w.n_slots, (int64_t)std::min<size_t>(8, 160 * 1024 / (LDBG_LS_FAST * 64 * sizeof(LsElem))) * rt::cu_count(graph->device) * 64);
     a.w.n_slots = std::max<int64_t>(64, (a.w.n_slots / 64) * 64);
     {
         auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };

@@ -89,7 +89,9 @@ private:
     int64_t dfs_traversed_ = 0;
     std::unique_ptr<MergedLinks> merged_;
     std::unique_ptr<class RunIndex> runs_;     // records in unitig order for this engine's colour masks (runs.h), built by the first walk batch
-    int64_t retried_strands_ = 0;              // strands the run steps handed back to the k-mer-by-k-mer code (diagnostics)
+    int64_t retried_strands_ = 0;
+    std::vector<uint8_t> sink_valid_;
+    std::vector<uint8_t> seed_valid_;          // per seed of the current walk batch: is the string a k-mer over ACGT (Q4)              // strands the run steps handed back to the k-mer-by-k-mer code (diagnostics)
     void build_roi_bits();
     bool dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
                    int64_t first, int64_t n, DfsBatch& out);

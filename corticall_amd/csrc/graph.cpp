@@ -154,7 +154,7 @@ LDBG_KERNEL void k_records(GraphView g, int64_t first, int64_t n, uint64_t* word
 
 // findRecord in bulk: one query per lane; canonicalise in registers, radix index, block search
 template <int W>
-LDBG_KERNEL void k_find(GraphView g, const uint64_t* packed, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {
+LDBG_KERNEL void k_find(GraphView g, const uint64_t* packed, const uint8_t* vmask, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {
     for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
         Kmer<W> q;
 #pragma unroll
@@ -162,7 +162,7 @@ LDBG_KERNEL void k_find(GraphView g, const uint64_t* packed, int64_t n, int64_t*
         int64_t idx = -1;
         // a word with bits above 2k set marks "not a k-mer" (non-ACGT ASCII query, Q4)
         const int top = 2 * g.k - 64 * (W - 1);
-        bool valid = top >= 64 || (q.w[0] >> top) == 0;
+        bool valid = (top >= 64 || (q.w[0] >> top) == 0) && (!vmask || vmask[i] != 0);
         if (valid) {
             bool f;
             Kmer<W> c = kmer_canonical<W>(q, g.k, &f);
@@ -224,6 +224,21 @@ static int grid_for(int64_t n, int block, int max_blocks) {
     return (int)b;
 }
 
+// Records are numbered in 31 bits throughout the device structures: a neighbour-index entry is (record + 1) | flip << 31, a
+// vertex is an int32 record number (engine.h: Node), a visited-table key is 34 bits wide, the run index numbers 2N oriented
+// vertices in 32 bits.  A table at or beyond 2^31 - 1 records must be hash-sharded (corticall_amd.distributed) — it is refused
+// here, never walked with wrapped indices.  LDBG_MAX_RECORDS (tests) lowers the limit.
+int64_t max_records_per_device() {
+    int64_t lim = (1LL << 31) - 2;
+    if (const char* ev = getenv("LDBG_MAX_RECORDS")) lim = std::min<int64_t>(lim, atoll(ev));
+    return lim;
+}
+void check_record_count(int64_t n, const std::string& path) {
+    if (n > max_records_per_device())
+        throw StatusError(LDBG_ERR_UNSUPPORTED, "Cortex graph file '" + path + "' holds " + std::to_string(n) + " records; one device table holds at most " +
+                          std::to_string(max_records_per_device()) + " (hash-shard the table over several devices)");
+}
+
 Graph::Graph(const std::string& p, const void* image, int64_t nbytes, int dev) : device(dev), path(p) {
     if (rt::device_count() <= dev) throw StatusError(LDBG_ERR_HIP, "no HIP device " + std::to_string(dev) + " available (libldbg has no CPU fallback)");
     rt::set_device(dev);
@@ -249,16 +264,26 @@ Graph::Graph(const std::string& p, const void* image, int64_t nbytes, int dev) :
     try {
         hdr = parse_ctx_header(base, size, (int64_t)size, p);
         if (hdr.W > 4) throw StatusError(LDBG_ERR_UNSUPPORTED, "k > 128 is not supported (k=" + std::to_string(hdr.k) + ")");
-        if (hdr.num_records >= (1LL << 32)) throw StatusError(LDBG_ERR_UNSUPPORTED, "more than 2^32-1 records per device shard");
+        check_record_count(hdr.num_records, p);
         stream = rt::stream_create();
         upload(base + hdr.data_offset);
     } catch (...) {
+        // ~Graph does not run for a constructor that throws: give back what upload() had taken (a rejected open — "Records are not
+        // sorted", then Sort, then open again — must not leak a table's worth of HBM every time)
+        release_device();
         if (map) munmap(map, size);
         if (fd >= 0) ::close(fd);
         throw;
     }
     if (map) munmap(map, size);
     if (fd >= 0) ::close(fd);
+}
+
+void Graph::release_device() {
+    rt::dfree(d_keys_); rt::dfree(d_cov_); rt::dfree(d_edges_); rt::dfree(d_probe_); rt::dfree(d_pstart_); rt::dfree(d_nbrg);
+    d_keys_ = d_cov_ = d_edges_ = d_probe_ = d_pstart_ = nullptr; d_nbrg = nullptr;
+    rt::stream_destroy(stream);
+    stream = nullptr;
 }
 
 void Graph::upload(const uint8_t* recs) {
@@ -352,8 +377,7 @@ void Graph::upload(const uint8_t* recs) {
 
 Graph::~Graph() {
     for (Links* l : bound_links) l->graph_closed();
-    rt::dfree(d_keys_); rt::dfree(d_cov_); rt::dfree(d_edges_); rt::dfree(d_probe_); rt::dfree(d_pstart_); rt::dfree(d_nbrg);
-    rt::stream_destroy(stream);
+    release_device();
 }
 
 void Graph::records_dev(int64_t first, int64_t n, uint64_t* d_words, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const {
@@ -365,16 +389,16 @@ void Graph::records_dev(int64_t first, int64_t n, uint64_t* d_words, uint32_t* d
     profile_add("records", rt::Event::elapsed_ms(e0, e1));
 }
 
-void Graph::find_dev(const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const {
+void Graph::find_dev(const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s, const uint8_t* d_valid) const {
     if (n <= 0) return;
     rt::Event e0, e1;
     e0.record(s);
     int grid = grid_for(n, 256, 256 * 16);
     switch (view.W) {
-        case 1: LDBG_LAUNCH(k_find<1>, grid, 256, s, view, d_packed, n, d_idx, d_cov, d_edges); break;
-        case 2: LDBG_LAUNCH(k_find<2>, grid, 256, s, view, d_packed, n, d_idx, d_cov, d_edges); break;
-        case 3: LDBG_LAUNCH(k_find<3>, grid, 256, s, view, d_packed, n, d_idx, d_cov, d_edges); break;
-        default: LDBG_LAUNCH(k_find<4>, grid, 256, s, view, d_packed, n, d_idx, d_cov, d_edges); break;
+        case 1: LDBG_LAUNCH(k_find<1>, grid, 256, s, view, d_packed, d_valid, n, d_idx, d_cov, d_edges); break;
+        case 2: LDBG_LAUNCH(k_find<2>, grid, 256, s, view, d_packed, d_valid, n, d_idx, d_cov, d_edges); break;
+        case 3: LDBG_LAUNCH(k_find<3>, grid, 256, s, view, d_packed, d_valid, n, d_idx, d_cov, d_edges); break;
+        default: LDBG_LAUNCH(k_find<4>, grid, 256, s, view, d_packed, d_valid, n, d_idx, d_cov, d_edges); break;
     }
     e1.record(s);
     profile_add("find", rt::Event::elapsed_ms(e0, e1));

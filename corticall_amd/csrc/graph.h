@@ -94,7 +94,9 @@ public:
     std::string path;
 
     void records_dev(int64_t first, int64_t n, uint64_t* d_words, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const;
-    void find_dev(const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s) const;
+    // d_valid (optional): per query 0 = not a k-mer over ACGT -> miss (Q4).  Without it a query whose words carry bits above 2k is
+    // taken as "not a k-mer" (a convention callers of the packed entry points may use when k is not a multiple of 32)
+    void find_dev(const uint64_t* d_packed, int64_t n, int64_t* d_idx, uint32_t* d_cov, uint8_t* d_edges, rt::stream_t s, const uint8_t* d_valid = nullptr) const;
     int color_for_sample_name(const std::string& name) const;
     // link sets bound to this graph get a flag bit in the probe rows (at most 8)
     mutable uint32_t link_slots = 0;                 // bits of the flag byte in use
@@ -106,7 +108,11 @@ public:
 private:
     void* d_keys_ = nullptr; void* d_cov_ = nullptr; void* d_edges_ = nullptr; void* d_probe_ = nullptr; void* d_pstart_ = nullptr;
     void upload(const uint8_t* records_host);
+    void release_device();
 };
+
+int64_t max_records_per_device();
+void check_record_count(int64_t n, const std::string& path);
 
 // hash partitioning of the table over devices (graph.cpp)
 void shard_owner_dev(int k, const uint64_t* d_packed, int64_t n, int world, uint64_t* d_canon, int32_t* d_owner, rt::stream_t s);

@@ -196,8 +196,9 @@ inline bool ascii_to_words(const char* s, int k, uint64_t* w, int W) {
     return true;
 }
 // the same for a batch of n k-mers of k bytes each (seeds of a walk / dfs batch): table lookup, one shift-or per base, a few
-// threads for large batches.  A string with a non-ACGT byte gets word 0 (all words if fill_all) set to ~0.
-inline void ascii_batch_to_words(const char* s, int64_t n, int k, int W, uint64_t* words, bool fill_all) {
+// threads for large batches.  valid[q] = 1 where string q is a k-mer over ACGT, 0 otherwise (findRecord then misses, quirk Q4):
+// validity travels beside the words — at k = 32, 64, 96, 128 every bit pattern of the words is a k-mer, none is left for a mark.
+inline void ascii_batch_to_words(const char* s, int64_t n, int k, int W, uint64_t* words, uint8_t* valid) {
     static const struct Lut {
         uint8_t v[256];
         Lut() { for (int i = 0; i < 256; i++) v[i] = 0x80; v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; }
@@ -215,7 +216,8 @@ inline void ascii_batch_to_words(const char* s, int64_t n, int k, int W, uint64_
                 for (int j = 0; j < cnt; j++) { const uint8_t v = lut.v[c[i++]]; bad |= v; acc = (acc << 2) | (uint64_t)(v & 3u); }
                 w[wi] = acc;
             }
-            if (bad & 0x80u) { if (fill_all) { for (int wi = 0; wi < W; wi++) w[wi] = ~0ull; } else w[0] = ~0ull; }
+            if (bad & 0x80u) for (int wi = 0; wi < W; wi++) w[wi] = 0ull;
+            valid[q] = (bad & 0x80u) ? 0 : 1;
         }
     };
     const int nt = n >= 8192 ? (int)std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;

@@ -48,6 +48,11 @@ inline int device_count() {
     return n;
 }
 inline void set_device(int d) { check(hipSetDevice(d), "hipSetDevice"); }
+inline int cu_count(int d) {            // compute units of the device (256 on an MI355X in SPX mode; fewer on a partition)
+    int n = 0;
+    check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d), "hipDeviceGetAttribute");
+    return n > 0 ? n : 256;
+}
 inline void* dmalloc(size_t n) { void* p = nullptr; check(hipMalloc(&p, n ? n : 1), "hipMalloc"); return p; }
 inline void dfree(void* p) { if (p) (void)hipFree(p); }
 inline void* hmalloc_pinned(size_t n) { void* p = nullptr; check(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault), "hipHostMalloc"); return p; }
@@ -138,6 +143,7 @@ namespace ldbg {
 namespace rt {
 inline int device_count() { return 1; }
 inline void set_device(int) {}
+inline int cu_count(int) { return 256; }
 inline void* dmalloc(size_t n) { return calloc(n ? n : 1, 1); }
 inline void dfree(void* p) { free(p); }
 inline void* hmalloc_pinned(size_t n) { return malloc(n ? n : 1); }

@@ -12,7 +12,8 @@ namespace ldbg {
 
 struct WalkArgs {
     EngineView e;
-    const uint64_t* seeds;     // [n][W]; word 0 == ~0 marks a seed that is not a k-mer (non-ACGT)
+    const uint64_t* seeds;     // [n][W]
+    const uint8_t* seed_valid; // [n] 0 = the seed string is not a k-mer over ACGT (findRecord misses, Q4)
     int64_t n_strands;         // 2n: strand 2i = reverse, 2i+1 = forward
     int64_t n_slots;
     int grow_at;               // a table is regrown when (entries + 8) * grow_at exceeds its size (2 = half full; 0 is read as 2)
@@ -169,7 +170,7 @@ LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls,
     Kmer<W> sk;
 #pragma unroll
     for (int i = 0; i < W; i++) sk.w[i] = sw[i];
-    if (sw[0] != ~0ull) { node_find<W>(e, sk, st.cv); node_locate(st.vt, st.cv); }
+    if (a.seed_valid[s >> 1]) { node_find<W>(e, sk, st.cv); node_locate(st.vt, st.cv); }
     else node_null(e, st.cv);   // not a k-mer: findRecord misses (Q4)
     if (st.cv.npe) { st.status = ST_NULLPTR; return false; }
     if (e.cursor_on) cursor_seek(e, st.cu, ls, st.vt, st.cv, st.fwd);   // :363-365

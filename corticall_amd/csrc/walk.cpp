@@ -714,7 +714,8 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
     laps.lap("clear_batch");
     const int k = graph->hdr.k, W = graph->hdr.W;
     std::vector<uint64_t> words((size_t)n * W);
-    ascii_batch_to_words(seeds, n, k, W, words.data(), false);
+    seed_valid_.resize((size_t)std::max<int64_t>(1, n));
+    ascii_batch_to_words(seeds, n, k, W, words.data(), seed_valid_.data());
     laps.lap("seed words");
     batch_n = n;
     int64_t trav = 0;
@@ -758,6 +759,8 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
 
     out.d_seed_words = rt::dmalloc((size_t)n * W * 8);
     rt::h2d(out.d_seed_words, &seed_words[first * W], (size_t)n * W * 8, s);
+    uint8_t* d_seed_valid = (uint8_t*)rt::dmalloc((size_t)n);
+    rt::h2d(d_seed_valid, &seed_valid_[first], (size_t)n, s);
     out.d_term = rt::dmalloc((size_t)ns * W * 8);
     uint32_t* d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     uint32_t* d_strand_c = (uint32_t*)rt::dmalloc((size_t)ns * 4);
@@ -768,7 +771,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     unsigned long long* d_ctr = (unsigned long long*)rt::dmalloc(32);
     rt::dmemset(d_ctr, 0, 32, s);
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
-    auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_strand_c); rt::dfree(d_retry); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk); };
+    auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_strand_c); rt::dfree(d_retry); rt::dfree(d_seed_valid); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk); };
 
     laps.lap("small allocations");
     WalkArgs a;
@@ -783,6 +786,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     if (runs_) a.e.runs = runs_->view;
     a.retry = nullptr;
     a.seeds = (const uint64_t*)out.d_seed_words;
+    a.seed_valid = d_seed_valid;
     a.n_strands = ns;
     a.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
     if (const char* ev = getenv("LDBG_MAX_SLOTS")) a.n_slots = std::max<int64_t>(64, std::min<int64_t>(a.n_slots, (atoll(ev) / 64) * 64));   // tuning knob
@@ -808,10 +812,16 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.vpool = (uint64_t*)d_vpool_; a.vnext = d_ctr + 2; a.vpool_entries = vpool_entries_; a.vcap_max = vcap_max;
     a.vcap_init = vt_initial_entries();
     if (!getenv("LDBG_VT_INITIAL")) {
-        // Regrowing a table stalls the owner's whole wavefront (strand.h), and the regrowths of its 64 strands add up: start as large as
-        // half of the pool allows when every strand of the batch takes one (C3: 65,536 entries, launch 291 -> 250 ms against 4,096)
-        const uint64_t per = vpool_entries_ / 2 / (uint64_t)std::max<int64_t>(1, ns);
-        while ((uint64_t)a.vcap_init * 4 <= per && (uint64_t)a.vcap_init * 4 <= vcap_max) a.vcap_init *= 4;
+        if (runs_) {
+            // with the run index a strand's table holds the fringes of the stretches it crosses and the junction vertices between
+            // them: a few entries per thousand k-mers.  Small tables = little to zero between batches (C3: 8.5 ms -> 0.3 ms)
+            a.vcap_init = std::min<uint32_t>(2048u, vcap_max);
+        } else {
+            // Regrowing a table stalls the owner's whole wavefront (strand.h), and the regrowths of its 64 strands add up: start as large as
+            // half of the pool allows when every strand of the batch takes one (C3: 65,536 entries, launch 291 -> 250 ms against 4,096)
+            const uint64_t per = vpool_entries_ / 2 / (uint64_t)std::max<int64_t>(1, ns);
+            while ((uint64_t)a.vcap_init * 4 <= per && (uint64_t)a.vcap_init * 4 <= vcap_max) a.vcap_init *= 4;
+        }
     }
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
     a.snap = getenv("LDBG_NO_REPEAT") ? nullptr : (LsSnap*)d_snap_;
@@ -829,7 +839,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     // residency: LDS per workgroup, and 152 VGPRs per lane leave 3 wavefronts per SIMD = 12 per CU
     int wg_per_cu = std::min<int>(12, (int)(160 * 1024 / (LDBG_LS_FAST * (size_t)block * sizeof(LsElem))));
     if (const char* ev = getenv("LDBG_WG_PER_CU")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(ev)));   // tuning knob
-    a.n_slots = std::min<int64_t>(a.n_slots, (int64_t)wg_per_cu * 256 * block);
+    a.n_slots = std::min<int64_t>(a.n_slots, (int64_t)wg_per_cu * rt::cu_count(graph->device) * block);
     a.n_slots = (a.n_slots / block) * block;
     if (a.n_slots < block) a.n_slots = block;
     const int grid = (int)((a.n_slots + block - 1) / block);

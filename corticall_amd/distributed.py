@@ -39,7 +39,7 @@ def gather_strings(local, group=None):
 
 def ctx_header(buf):
     """Cortex v6 header (CortexGraph.java:66-168, docs/ctx_spec.md) -> dict(k, W, C, data_offset)"""
-    if bytes(buf[0:6]) != b"CORTEX":
+    if bytes(buf[0:6]).upper() != b"CORTEX":      # equalsIgnoreCase, like the reference and the C++ parser
         raise _native.CortexJDKException("The file does not appear to be a Cortex graph (bad magic)")
     version, k, W, Cc = struct.unpack_from("<IIII", buf, 6)
     if version != 6:
@@ -53,7 +53,7 @@ def ctx_header(buf):
         p += 4 + 4 + 4
         (ln,) = struct.unpack_from("<I", buf, p)
         p += 4 + ln
-    if bytes(buf[p:p + 6]) != b"CORTEX":
+    if bytes(buf[p:p + 6]).upper() != b"CORTEX":
         raise _native.CortexJDKException("The Cortex graph header does not end with the magic word")
     return {"k": k, "W": W, "C": Cc, "data_offset": p + 6}
 

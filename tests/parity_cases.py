@@ -120,6 +120,19 @@ def case_fixture_graph(orc, lib, tmp):
     w, c, e = g.records(0, 66)
     for i, r in enumerate(rows):
         assert [int(x) for x in w[i]] == orc.encode_kmer(r[0])
+    # BASELINE configs[0]: full-graph iterate (above) + one walk — from record 0's k-mer in colour 0, and from every other record
+    # in both colours, against the oracle on the same file
+    og = orc.Graph(os.path.join(GOLDEN, "two_short_contigs.ctx"))
+    for colour in (0, 1):
+        oe = orc.Engine(og, [colour], stopper="ContigStopper")
+        e = TraversalEngineFactory(lib=lib).traversalColors(colour).graph(g).stoppingRule(ContigStopper).make()
+        seeds = [r[0] for r in rows] + [orc.revcomp(r[0]) for r in rows[:8]]
+        got, wl = e.walk_batch(seeds)
+        for sd, c, n in zip(seeds, got, wl):
+            exp, nv = oe.walk(sd)
+            assert c == exp and n == nv, (colour, sd, c, exp)
+        if colour == 0:
+            assert TraversalUtils.toContig(e.walk(rows[0][0])) == got[0] and len(got[0]) >= 31
     g.close()
 
 
@@ -157,6 +170,34 @@ def case_random_find(orc, lib, tmp, k, ncol, n=3000, seed=1):
         assert [int(x) for x in w[i]] == ow and list(c[i]) == oc and list(e[i]) == oe_
 
 
+def case_all_bits_kmers(orc, lib, tmp, k):
+    """k = 32, 64, 96: every bit pattern of the packed words is a k-mer, so "not a k-mer" (a string with an N, quirk Q4) must travel
+    beside the words.  Poly-T stretches make the all-ones words a real k-mer of the graph."""
+    rng = random.Random(k)
+    hap = rand_seq(rng, 150) + "T" * (k + 40) + rand_seq(rng, 150) + "A" * (k + 3) + rand_seq(rng, 80)
+    cs = Case(orc, tmp, lib, [("a", [hap])], k, link_samples=["a"], name="ones%d" % k)
+    polyt = "T" * k
+    seeds = [polyt, "A" * k, hap[150 - 9:150 - 9 + k], hap[150 + 5:150 + 5 + k], "T" * 32 + hap[150 + k + 8:150 + k + 8 + k - 32] if k > 32 else polyt,
+             "N" + "T" * (k - 1), "T" * (k - 1) + "N", "N" * k, hap[:k], orc.revcomp(hap[200 + k:200 + 2 * k])]
+    seeds = [s for s in seeds if len(s) == k]
+    idx, cov, edges = cs.g.find_batch(seeds)
+    for s_, i in zip(seeds, idx):
+        exp = cs.og.find(s_)[0]
+        assert exp == int(i), (k, s_, exp, int(i))
+    assert idx[0] >= 0 and idx[5] == -1 and idx[6] == -1 and idx[7] == -1
+    assert cs.g.findRecord("N" + "T" * (k - 1)) is None and cs.g.findRecord(polyt) is not None
+    compare_walks(cs, seeds, trav=[0])
+    compare_walks(cs, seeds, trav=[0], links=["a"], max_len=300)
+    for stopper in ("ContigStopper", "DestinationStopper", "ExplorationStopper"):
+        compare_dfs(cs, seeds[:8], sinks=[[polyt], ["N" * k], [hap[160:160 + k]], ["N" + "T" * (k - 1)], [polyt], [], [polyt, "N" * k], ["A" * k]],
+                    trav=[0], stopper=stopper, links=["a"], max_len=200)
+    oe, e = cs.engines(trav=[0], links=["a"])
+    for sd in ("N" + "T" * (k - 1), polyt):
+        e.seek(sd)
+        oe.seek(sd)
+        assert e.hasNext() == oe.has_next() and e.hasPrevious() == oe.has_previous()
+
+
 def case_q1_tiny(orc, lib, tmp):
     p = str(tmp / "tiny.ctx")
     orc.build_graph(p, [("s", ["ACGTT"])], 4)
@@ -184,6 +225,47 @@ def case_unsorted_rejected(orc, lib, tmp):
         raise AssertionError("bad magic accepted")
     except ca.CortexJDKException as ex:
         assert "does not appear to be a Cortex graph" in str(ex)
+    open(p, "wb").write(b"cortex" + src[6:])          # the reference compares the magic word ignoring case (CortexGraph.java:96)
+    CortexGraph(p, lib=lib).close()
+
+
+def case_record_count_guard(orc, lib, tmp, monkeypatch):
+    """a table beyond what the 31-bit record numbers of the device structures can hold is refused at open (the limit itself is
+    2^31 - 2 records; LDBG_MAX_RECORDS lowers it so that a 66-record file can stand in for a 2-billion-record one)"""
+    fx = os.path.join(GOLDEN, "two_short_contigs.ctx")
+    monkeypatch.setenv("LDBG_MAX_RECORDS", "65")
+    try:
+        CortexGraph(fx, lib=lib)
+        raise AssertionError("a table over the record limit was opened")
+    except ca.LdbgError as ex:
+        assert ex.status == 4 and "holds 66 records" in str(ex) and "at most 65" in str(ex)
+    monkeypatch.setenv("LDBG_MAX_RECORDS", "66")
+    CortexGraph(fx, lib=lib).close()
+    monkeypatch.delenv("LDBG_MAX_RECORDS")
+    CortexGraph(fx, lib=lib).close()
+
+
+def case_rejected_open_frees_device_memory(lib, tmp):
+    """(GPU) opening an unsorted file again and again leaves the free device memory where it was"""
+    import torch
+    src = open(os.path.join(GOLDEN, "two_short_contigs.ctx"), "rb").read()
+    off, rs = 148, 18
+    recs = [src[off + i * rs: off + (i + 1) * rs] for i in range(66)] * 1      # small file; what leaks is per open (buffers + a stream)
+    big = recs * 40000                                                           # 2.6 M records, unsorted by construction: ~50 MB of rows
+    p = str(tmp / "unsorted_big.ctx")
+    open(p, "wb").write(src[:off] + b"".join(big))
+    free0 = None
+    for it in range(6):
+        try:
+            CortexGraph(p, lib=lib)
+            raise AssertionError("unsorted graph accepted")
+        except ca.CortexJDKException:
+            pass
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info()
+        if it == 1:
+            free0 = free
+    assert free0 - free < 32 << 20, (free0, free)
 
 
 # ------------------------------------------------------------------ reference tests through the product API

@@ -23,8 +23,14 @@ def test_fixture_graph(orc, lib, tmp_path): pc.case_fixture_graph(orc, lib, tmp_
 def test_random_find(orc, lib, tmp_path, k, ncol): pc.case_random_find(orc, lib, tmp_path, k, ncol)
 
 
+@pytest.mark.parametrize("k", [32, 64, 96])
+def test_all_bits_kmers(orc, lib, tmp_path, k): pc.case_all_bits_kmers(orc, lib, tmp_path, k)
+
+
 def test_q1_tiny(orc, lib, tmp_path): pc.case_q1_tiny(orc, lib, tmp_path)
 def test_unsorted_rejected(orc, lib, tmp_path): pc.case_unsorted_rejected(orc, lib, tmp_path)
+def test_record_count_guard(orc, lib, tmp_path, monkeypatch): pc.case_record_count_guard(orc, lib, tmp_path, monkeypatch)
+def test_rejected_open_frees_device_memory(lib, tmp_path): pc.case_rejected_open_frees_device_memory(lib, tmp_path)
 def test_ref_short_contig_reconstruction(orc, lib, tmp_path): pc.test_ref_short_contig_reconstruction(orc, lib, tmp_path)
 def test_ref_recruitment(orc, lib, tmp_path): pc.test_ref_recruitment(orc, lib, tmp_path)
 def test_ref_cycles_without_and_with_links(orc, lib, tmp_path): pc.test_ref_cycles_without_and_with_links(orc, lib, tmp_path)
