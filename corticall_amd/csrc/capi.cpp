@@ -25,7 +25,7 @@ struct ldbg_engine {
     explicit ldbg_engine(const ldbg_engine_config& c) : e(c) {}
 };
 struct ldbg_dfs_result { std::unique_ptr<DfsBatch> b; };
-struct ldbg_bsp_walker { BspWalker w; explicit ldbg_bsp_walker(const Engine& e) : w(e) {} };
+struct ldbg_image { ShardImage img; ldbg_image(const Graph& shard, int64_t cap, int64_t global) : img(shard, cap, global) {} };
 
 namespace {
 thread_local std::string g_err;
@@ -186,27 +186,54 @@ ldbg_status ldbg_shard_owner(int k, const uint64_t* packed, int64_t n, int world
         rt::stream_destroy(s);
     });
 }
-ldbg_status ldbg_shard_nbr_queries(const ldbg_graph* g, int64_t first, int64_t n, uint64_t* d_words, uint8_t* d_flips) {
-    return guard([&] { rt::set_device(g->g.device); shard_nbr_queries(g->g, first, n, d_words, d_flips); });
+ldbg_status ldbg_shard_nbr_queries(const ldbg_graph* g, int64_t first, int64_t n, uint64_t* d_words, uint8_t* d_flips, uint8_t* d_have) {
+    return guard([&] { rt::set_device(g->g.device); shard_nbr_queries(g->g, first, n, d_words, d_flips, d_have); });
 }
 ldbg_status ldbg_shard_set_nbr(ldbg_graph* g, int64_t first, int64_t n, const int32_t* d_owner, const int64_t* d_lidx, const uint8_t* d_flips) {
     return guard([&] { rt::set_device(g->g.device); shard_set_nbr(g->g, first, n, d_owner, d_lidx, d_flips); });
 }
-ldbg_status ldbg_shard_row_bytes(const ldbg_graph* g, int* bytes) { return guard([&] { *bytes = shard_row_bytes(g->g); }); }
-ldbg_status ldbg_shard_rows(const ldbg_graph* g, const int64_t* d_lidx, int64_t n, uint8_t* d_rows) {
-    return guard([&] { rt::set_device(g->g.device); shard_rows(g->g, d_lidx, n, d_rows); });
+// ---- the local image of a hash-sharded table (image.h) and walks over it, one bulk-synchronous round at a time
+ldbg_status ldbg_image_create(const ldbg_graph* shard, int64_t cap, int64_t global_records, ldbg_image** out) {
+    return guard([&] {
+        *out = nullptr;
+        if (cap < 1 || cap > ldbg::max_records_per_device()) throw StatusError(LDBG_ERR_ARG, "image capacity out of range");
+        *out = new ldbg_image(shard->g, cap, global_records);
+    });
 }
-ldbg_status ldbg_bsp_create(const ldbg_engine* e, ldbg_bsp_walker** out) { return guard([&] { *out = nullptr; *out = new ldbg_bsp_walker(e->e); }); }
-ldbg_status ldbg_bsp_destroy(ldbg_bsp_walker* w) { return guard([&] { delete w; }); }
-ldbg_status ldbg_bsp_start(ldbg_bsp_walker* w, int64_t n, const int32_t* d_owner, const int64_t* d_lidx, const uint8_t* d_flip, int32_t* d_ro, int64_t* d_rl) {
-    return guard([&] { w->w.start(n, d_owner, d_lidx, d_flip, d_ro, d_rl); });
+ldbg_status ldbg_image_destroy(ldbg_image* im) { return guard([&] { delete im; }); }
+ldbg_status ldbg_image_graph(ldbg_image* im, ldbg_graph** g) { return guard([&] { *g = reinterpret_cast<ldbg_graph*>(&im->img.graph()); }); }
+ldbg_status ldbg_image_row_bytes(const ldbg_image* im, int* bytes) { return guard([&] { *bytes = im->img.row_bytes(); }); }
+ldbg_status ldbg_image_clear(ldbg_image* im) { return guard([&] { rt::set_device(im->img.graph().device); im->img.clear(); }); }
+static rt::stream_t image_stream(const ldbg_image* im, void* stream) { return stream ? (rt::stream_t)stream : im->img.graph().stream; }
+ldbg_status ldbg_image_serve(const ldbg_image* im, int my_rank, const uint64_t* d_keys, int64_t n, uint8_t* d_out, void* stream) {
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.serve(my_rank, (const unsigned long long*)d_keys, n, d_out, image_stream(im, stream)); });
 }
-ldbg_status ldbg_bsp_step(ldbg_bsp_walker* w, const uint8_t* d_have, const uint8_t* d_rows, int32_t* d_ro, int64_t* d_rl) {
-    return guard([&] { w->w.step(d_have, d_rows, d_ro, d_rl); });
+ldbg_status ldbg_image_insert(ldbg_image* im, const ldbg_engine* e, const uint8_t* d_rows, int64_t n, void* stream) {
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.insert(e ? &e->e : nullptr, d_rows, n, image_stream(im, stream)); });
 }
-ldbg_status ldbg_bsp_results(ldbg_bsp_walker* w, uint32_t* strand_n, uint32_t* status, uint32_t* iters, uint8_t* bases, int64_t stride) {
-    return guard([&] { w->w.results(strand_n, status, iters, bases, stride); });
+ldbg_status ldbg_image_lookup(const ldbg_image* im, const uint64_t* d_keys, int64_t n, int32_t* d_slots, void* stream) {
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.lookup((const unsigned long long*)d_keys, n, d_slots, image_stream(im, stream)); });
 }
+ldbg_status ldbg_image_bucket(ldbg_image* im, int world, uint32_t cap_per_owner, uint64_t* d_send, void* stream) {
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.bucket(world, cap_per_owner, (unsigned long long*)d_send, image_stream(im, stream)); });
+}
+ldbg_status ldbg_image_request(ldbg_image* im, const uint64_t* d_keys, int64_t n, void* stream) {
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.request((const unsigned long long*)d_keys, n, image_stream(im, stream)); });
+}
+ldbg_status ldbg_image_reset_requests(ldbg_image* im, void* stream) {
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.reset_requests(image_stream(im, stream)); });
+}
+ldbg_status ldbg_image_counters(const ldbg_image* im, int64_t* n_rows, int64_t* n_req, int* overflow) {
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.counters(n_rows, n_req, overflow); });
+}
+ldbg_status ldbg_engine_sharded_walk_begin(ldbg_engine* e, ldbg_image* im, const char* seeds, int64_t n, const int32_t* d_seed_slot, void* stream) {
+    return guard([&] { e->e.sharded_walk_begin(im->img, seeds, n, d_seed_slot, (rt::stream_t)stream); });
+}
+ldbg_status ldbg_engine_sharded_walk_round(ldbg_engine* e, int64_t* d_stats) { return guard([&] { e->e.sharded_walk_round(d_stats); }); }
+ldbg_status ldbg_engine_sharded_walk_finish(ldbg_engine* e, int64_t* total_bytes, int64_t* traversed) {
+    return guard([&] { e->e.sharded_walk_finish(total_bytes, traversed); });
+}
+
 ldbg_status ldbg_graph_find(const ldbg_graph* g, const uint64_t* packed, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {
     return guard([&] {
         if (n <= 0) return;

@@ -46,6 +46,8 @@ struct DfsBatch {
     std::string walk_contig(int64_t i, const char* seed, int color);
 };
 
+struct WalkRun;
+class ShardImage;
 uint64_t vt_series(uint64_t init, uint64_t vmax);     // walk.cpp
 uint32_t vt_initial_entries();
 
@@ -64,6 +66,12 @@ public:
     void walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index);
     void clear_batch();
     void walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, uint8_t* has_null);
+    // walk_batch_run over the local image of a hash-sharded table, one bulk-synchronous round at a time (image.h): begin with the
+    // seeds' image slots (device array, -1 = no record), then rounds until no rank has a strand left, then finish
+    void sharded_walk_begin(ShardImage& img, const char* seeds, int64_t n, const int32_t* d_seed_slot, rt::stream_t round_stream);
+    void sharded_walk_round(int64_t* d_stats);        // d_stats[0] = strands of this rank not done yet, d_stats[1] = requests filed (device memory)
+    void sharded_walk_finish(int64_t* total_contig_bytes, int64_t* kmers_traversed);
+    void sharded_abort();
     // dfs(source, sinks...) for n sources; sinks as CSR over ASCII k-mers (sink_offsets may be nullptr)
     DfsBatch* dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets);
     int dfs_max_depth = 64;
@@ -108,6 +116,13 @@ private:
     void drop_spares();
     void zero_dirty_tables(rt::stream_t s);      // the part of the table pool the last launch handed out
     bool run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);
+    void walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkRun& r, ShardImage* img, const int32_t* d_seed_slot);
+    void walk_launch(WalkRun& r);
+    bool walk_finish(WalkRun& r, int64_t* traversed);
+    WalkRun* sharded_run_ = nullptr;           // the batch in progress over a sharded table's image (sharded_walk_begin .. _finish)
+    ShardImage* sharded_img_ = nullptr;
+    rt::stream_t sharded_stream_ = nullptr;
+    int64_t sharded_rounds_ = 0;
 };
 
 }  // namespace ldbg

@@ -279,6 +279,22 @@ Graph::Graph(const std::string& p, const void* image, int64_t nbytes, int dev) :
     if (fd >= 0) ::close(fd);
 }
 
+Graph::Graph(const CtxHeader& h, int64_t cap, int dev, const GraphView& like, bool tiny) : device(dev), path("#image") {
+    rt::set_device(dev);
+    hdr = h;
+    is_image = true;
+    stream = rt::stream_create();
+    view = like;
+    view.N = cap; view.keys = nullptr; view.cov = nullptr; view.edges = nullptr; view.pstart = nullptr; view.p = 0;
+    view.java_tiny = tiny ? 1 : 0; view.nbr_on = 1;
+    try {
+        d_probe_ = rt::dmalloc((size_t)std::max<int64_t>(1, cap) * (size_t)view.stride);
+        rt::dmemset(d_probe_, 0, (size_t)std::max<int64_t>(1, cap) * (size_t)view.stride, stream);
+        rt::stream_sync(stream);
+    } catch (...) { release_device(); throw; }
+    view.probe = (const uint8_t*)d_probe_;
+}
+
 void Graph::release_device() {
     rt::dfree(d_keys_); rt::dfree(d_cov_); rt::dfree(d_edges_); rt::dfree(d_probe_); rt::dfree(d_pstart_); rt::dfree(d_nbrg);
     d_keys_ = d_cov_ = d_edges_ = d_probe_ = d_pstart_ = nullptr; d_nbrg = nullptr;

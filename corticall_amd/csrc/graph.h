@@ -86,6 +86,9 @@ class Graph {
 public:
     // file_or_image: if image != nullptr the graph is built from memory, else `path` is mmapped
     Graph(const std::string& path, const void* image, int64_t nbytes, int device);
+    // the local image of a hash-sharded table (image.h): `cap` zeroed rows laid out like those of `like`, filled as rows arrive
+    Graph(const CtxHeader& h, int64_t cap, int device, const GraphView& like, bool java_tiny);
+    bool is_image = false;
     ~Graph();
     CtxHeader hdr;
     int device = 0;

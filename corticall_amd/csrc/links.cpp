@@ -397,7 +397,7 @@ MergedLinks::MergedLinks(const std::vector<const Links*>& sets, const Graph& g) 
     const int64_t N = g.view.N;
     d_rec_of_ = rt::dmalloc((size_t)std::max<int64_t>(1, N) * 8);
     rt::dmemset(d_rec_of_, 0xFF, (size_t)std::max<int64_t>(1, N) * 8, s);
-    if (M > 0) {
+    if (M > 0 && !g.is_image) {             // (an image learns the link records of a row when the row arrives: image.cpp)
         const int grid = (int)std::min<int64_t>((M + 255) / 256, 2048);
         switch (W) {
             case 1: LDBG_LAUNCH(k_link_rec_of<1>, grid, 256, s, g.view, (const uint64_t*)d_keys_, M, (const uint32_t*)d_off_, (uint64_t*)d_rec_of_); break;

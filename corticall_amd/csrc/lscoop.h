@@ -304,7 +304,7 @@ LDBG_DEV bool lean_cursor_ok(const EngineView& e, const StrandState& st) {
     if (!(st.status == ST_OK && e.cursor_on && cu.has && !cu.first && (e.g.k & 1))) return false;   // odd k: no palindromic k-mers
     const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
     return cv.idx >= 0 && t.idx >= 0 && !t.npe && cv.flip == cv.fj && t.flip == t.fj   // records present, no quirk-Q6 vertex
-        && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u                                     // exactly one successor, and it has a record
+        && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u && (t.ent1 & 0x7FFFFFFFu) != 0x7FFFFFFFu   // exactly one successor, it has a record (and its row is here: image.h)
         && !(t.lflags & e.link_flag_mask)                                           // no links to add
         && cv.vslot != t.vslot                                                      // not standing on the vertex it looks at
         && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767;                      // cv not visited before, copies in range
@@ -314,7 +314,7 @@ LDBG_DEV bool lean_cursor_again(const EngineView& e, const StrandState& st) {
     const Node& cv = st.cv;
     const Node& t = st.cu.nxt;
     const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
-    return st.cu.has && !t.npe && t.flip == t.fj && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u
+    return st.cu.has && !t.npe && t.flip == t.fj && t.e1 && (t.ent1 & 0x7FFFFFFFu) != 0u && (t.ent1 & 0x7FFFFFFFu) != 0x7FFFFFFFu
         && !(t.lflags & e.link_flag_mask) && cv.vslot != t.vslot && acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767;
 }
 // next()/previous() (TraversalEngine.java:241-279) onto cu.nxt with its only successor looked up one step ahead, then

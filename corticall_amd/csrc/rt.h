@@ -72,6 +72,10 @@ struct Event {
     hipEvent_t e = nullptr;
     Event() { check(hipEventCreate(&e), "hipEventCreate"); }
     ~Event() { if (e) (void)hipEventDestroy(e); }
+    Event(Event&& o) noexcept : e(o.e) { o.e = nullptr; }
+    Event& operator=(Event&& o) noexcept { if (this != &o) { if (e) (void)hipEventDestroy(e); e = o.e; o.e = nullptr; } return *this; }
+    Event(const Event&) = delete;
+    Event& operator=(const Event&) = delete;
     void record(stream_t s) { check(hipEventRecord(e, s), "hipEventRecord"); }
     static float elapsed_ms(Event& a, Event& b) {
         check(hipEventSynchronize(b.e), "hipEventSynchronize");
@@ -111,6 +115,7 @@ LDBG_DEV uint64_t wave_bcast_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 LDBG_DEV void wave_fence() { __threadfence_block(); }
+LDBG_DEV void device_fence() { __threadfence(); }
 LDBG_DEV uint64_t wave_shfl_xor_u64(uint64_t v, int m) {
     uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
     return ((uint64_t)hi << 32) | lo;
@@ -183,6 +188,7 @@ inline unsigned long long wave_ballot(bool p) { return p ? 1ull : 0ull; }
 inline uint32_t wave_bcast_u32(uint32_t v, int) { return v; }
 inline uint64_t wave_bcast_u64(uint64_t v, int) { return v; }
 inline void wave_fence() {}
+inline void device_fence() {}
 inline uint64_t wave_min_u64(uint64_t v) { return v; }
 inline uint64_t wave_max_u64(uint64_t v) { return v; }
 inline int wave_count_below(unsigned long long) { return 0; }

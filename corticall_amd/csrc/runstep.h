@@ -58,6 +58,15 @@ struct RunState {
     uint64_t anchor_cv, anchor_t;   // table keys of cv and of the cursor's next vertex at the anchor
 };
 
+// what a lane keeps of its strand from one bulk-synchronous round to the next (walks over a sharded table's image, image.h)
+struct StrandSave {
+    StrandState st;
+    RunState rs;
+    uint32_t ls_n, ls_java_cap, ls_nkeys, ls_next_seq, ls_age, ls_n_new;
+    uint8_t ls_overflow, active, begun, pad;
+    LsElem fast[LDBG_LS_FAST];
+};
+
 // ---- walks that repeat themselves.  With links a walk may go round a tandem repeat for ever (the links it picks up on every
 // revolution tell it to go round once more); the reference stops it at maxLength (:428), 75,000 vertices later.  Whatever the
 // loop at :373-481 does next is a function of the current vertex, the cursor's next vertex, the LinkStore (elements with their

@@ -2,6 +2,7 @@
 // queue arguments, path-block storage, visited-table allocation and the wave-cooperative table regrowth.
 #pragma once
 #include "engine_host.h"
+#include "image.h"
 
 namespace ldbg {
 
@@ -42,6 +43,12 @@ struct WalkArgs {
     LsElem* ls;                // [n_slots][ecap]
     uint32_t ecap;
     struct LsSnap* snap;       // walk kernel: [n_slots][LDBG_SNAP_CAP] link-store snapshots of the repeat detection (runstep.h), or nullptr
+    // ---- walks over the local image of a hash-sharded table (image.h); img_on == 0: the table is resident
+    int img_on;
+    ImageView img;
+    const int32_t* seed_slot;  // [n] image slot of each seed's record (-1 = the seed has no record); the rows are in the image before the first round
+    struct StrandSave* save;   // [n_slots] the strand a lane is working on, kept from one bulk-synchronous round to the next
+    unsigned long long* unfinished;   // strands that were still in progress when the round's launch ended
     unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
     unsigned long long* st_gen;     // diagnostics: [n_strands][2] ticks spent before general steps (prepare + cooperative phases), their number
@@ -152,6 +159,18 @@ LDBG_DEV void strand_finish(const WalkArgs& a, StrandState& st) {
 #endif
 }
 
+// node_find (engine.h) for a seed whose record is already known: its image slot, -1 = no record
+template <int W>
+LDBG_DEV void seed_node(const EngineView& e, const Kmer<W>& sk, int32_t slot, Node& n) {
+    bool fc;
+    const Kmer<W> c = kmer_canonical<W>(sk, e.g.k, &fc);
+    n.idx = slot;
+    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = 0; n.e1 = 0; n.ent1 = 0;
+    n.flip = fc ? 1 : 0;
+    node_fill(e, n);
+    if (n.idx < 0 && e.strict_flip && fc) n.fj = kmer_java_hash<W>(c, e.g.k) != kmer_java_hash<W>(sk, e.g.k) ? 1 : 0;
+}
+
 // returns false when the strand ended at once
 template <int W>
 LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, int64_t s) {
@@ -170,8 +189,11 @@ LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls,
     Kmer<W> sk;
 #pragma unroll
     for (int i = 0; i < W; i++) sk.w[i] = sw[i];
-    if (a.seed_valid[s >> 1]) { node_find<W>(e, sk, st.cv); node_locate(st.vt, st.cv); }
-    else node_null(e, st.cv);   // not a k-mer: findRecord misses (Q4)
+    if (a.seed_valid[s >> 1]) {
+        if (a.img_on) seed_node<W>(e, sk, a.seed_slot[s >> 1], st.cv);     // the routed findRecord of the seed was done before the first round
+        else node_find<W>(e, sk, st.cv);
+        node_locate(st.vt, st.cv);
+    } else node_null(e, st.cv);   // not a k-mer: findRecord misses (Q4)
     if (st.cv.npe) { st.status = ST_NULLPTR; return false; }
     if (e.cursor_on) cursor_seek(e, st.cu, ls, st.vt, st.cv, st.fwd);   // :363-365
     return true;

@@ -9,6 +9,7 @@
 #include "lscoop.h"
 #include "runs.h"
 #include "runstep.h"
+#include "shard.h"
 #include "strand.h"
 
 namespace ldbg {
@@ -142,10 +143,23 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     rs.period = 0; rs.anchor_sig = 0; rs.anchor_cv = 0; rs.anchor_t = 0;
     const bool runs_on = a.e.runs.uinfo != nullptr;
     bool active = false, exhausted = false;
+    // over an image (image.h): a strand that needs a row that has not been sent yet SUSPENDS for the rest of this launch; the
+    // strand a lane was working on when the previous round ended is taken up again
+    bool suspended = false, begun = true;
+    if (a.save) {
+        const StrandSave& sv = a.save[slot];
+        if (sv.active) {
+            st = sv.st; rs = sv.rs;
+            ls.n = sv.ls_n; ls.java_cap = sv.ls_java_cap; ls.nkeys = sv.ls_nkeys; ls.next_seq = sv.ls_next_seq; ls.age = sv.ls_age; ls.n_new = sv.ls_n_new;
+            ls.overflow = sv.ls_overflow != 0;
+            for (uint32_t i = 0; i < LDBG_LS_FAST && i < sv.ls_n; i++) ls_set(ls, i, sv.fast[i]);
+            active = true; begun = sv.begun != 0;
+        }
+    }
     unsigned long long wave_iterations = 0;
     // all lanes of a wavefront stay in the loop until every one of them has run out of strands: the table
     // regrowth below is a wave-wide operation
-    while (wave_ballot(active || !exhausted) != 0ull) {
+    while (wave_ballot((active && !suspended) || (!active && !exhausted)) != 0ull) {
         wave_iterations++;
         if (!active && !exhausted) {
             const int64_t fi = (int64_t)atomic_add_u64(a.next_strand, 1ull);
@@ -157,6 +171,8 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
                 const bool fwd = (s & 1) != 0;
                 if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
                     a.strand_n[s] = 0; a.strand_c[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0; a.quirk[s] = 0;
+                } else if (a.img_on) {
+                    st.s = s; st.fwd = fwd; active = true; begun = false;       // begins below, once the rows around its seed are here
                 } else {
                     active = strand_begin<W>(a, st, ls, s);
                     rs.seed_pos = st.cv.idx >= 0 && ui_valid(st.cv.ui) ? ui_pos(st.cv.ui) : LDBG_RUN_NONE;
@@ -165,10 +181,38 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
                 }
             }
         }
-        wave_grow_tables(a, st, active);
+        if (a.img_on && active && !suspended) {
+            if (!begun) {
+                // the first iteration looks at the seed's neighbours (cursor_seek :321-335, or the branch loop itself :373-376)
+                const int32_t sl = a.seed_valid[st.s >> 1] ? a.seed_slot[st.s >> 1] : -1;
+                bool ready = true;
+                if (sl >= 0) {
+                    Kmer<W> sk;
+                    const uint64_t* sw = a.seeds + (st.s >> 1) * W;
+#pragma unroll
+                    for (int i = 0; i < W; i++) sk.w[i] = sw[i];
+                    Node sn;
+                    seed_node<W>(a.e, sk, sl, sn);
+                    ready = rows_ready(a.img, sn, st.fwd);
+                }
+                if (!ready) suspended = true;
+                else {
+                    begun = true;
+                    active = strand_begin<W>(a, st, ls, st.s);
+                    rs.seed_pos = LDBG_RUN_NONE; rs.seen_marks = 0; rs.choices = 0; rs.anchor_at = 0; rs.period = 0;
+                    if (!active) walk_finish(a, st);
+                }
+            }
+            if (active && begun && !suspended && st.status == ST_OK) {
+                const bool ready = (a.e.cursor_on && st.cu.has) ? rows_ready(a.img, st.cu.nxt, st.fwd) : rows_ready(a.img, st.cv, st.fwd);
+                if (!ready) suspended = true;
+            }
+        }
+        const bool running = active && begun && !suspended;
+        wave_grow_tables(a, st, running);
         // ---- run step: a whole unbranched stretch at once (runstep.h)
         bool stepped = false;
-        if (runs_on && active) {
+        if (runs_on && running) {
             const bool ma = run_mode_a(a, st, rs);
             const bool mb = !ma && run_mode_b(a, st, rs);
             if (ma || mb) {
@@ -176,7 +220,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
                 if (run_step<W>(a, st, ls, rs, ma)) { walk_finish(a, st); active = false; }
             }
         }
-        const bool lean = active && !stepped && lean_ok(a, st) && !(runs_on && run_entry_a(a.e, st, rs));
+        const bool lean = running && active && !stepped && lean_ok(a, st) && !(runs_on && run_entry_a(a.e, st, rs));
         if (lean) {
             // a short run of lean steps without going round the outer loop (its ballots, refill and regrowth checks): every lean
             // step claims at most one table slot, and the regrowth check above leaves room for eight
@@ -187,12 +231,12 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             rs.seen_marks += st.vt.used - used0;
             st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
-        if (wave_ballot(active && !lean && !stepped) == 0ull) continue;          // the whole wavefront took a lean or a run step
+        if (wave_ballot(running && active && !lean && !stepped) == 0ull) continue;          // the whole wavefront took a lean or a run step (or waits for rows)
 #ifndef LDBG_HOSTSIM
         const unsigned long long t_general = a.st_gen ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
-        const bool general = active && !lean && !stepped;
+        const bool general = running && active && !lean && !stepped;
         const bool cur_mode = general && st.status == ST_OK && a.e.cursor_on && st.cu.has;
         StepPre pre;
         const uint32_t used1 = st.vt.used;
@@ -208,6 +252,17 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             rs.seen_marks += st.vt.used - used1;
             if (!ended && a.snap && pre.choice_done && st.status == ST_OK) ended = periodic_check(a, st, ls, rs, a.snap + (size_t)slot * LDBG_SNAP_CAP);
             if (ended) { walk_finish(a, st); active = false; }
+        }
+    }
+    if (a.save) {
+        StrandSave& sv = a.save[slot];
+        sv.active = active ? 1 : 0;
+        if (active) {
+            sv.st = st; sv.rs = rs; sv.begun = begun ? 1 : 0;
+            sv.ls_n = ls.n; sv.ls_java_cap = ls.java_cap; sv.ls_nkeys = ls.nkeys; sv.ls_next_seq = ls.next_seq; sv.ls_age = ls.age; sv.ls_n_new = ls.n_new;
+            sv.ls_overflow = ls.overflow ? 1 : 0;
+            for (uint32_t i = 0; i < LDBG_LS_FAST && i < ls.n; i++) sv.fast[i] = ls_get(ls, i);
+            atomic_add_u64(a.unfinished, 1ull);
         }
     }
 #ifndef LDBG_HOSTSIM
@@ -524,7 +579,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
 }
 
-Engine::~Engine() { clear_batch(); drop_spares(); rt::hfree_pinned(h_log_); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
+Engine::~Engine() { sharded_abort(); clear_batch(); drop_spares(); rt::hfree_pinned(h_log_); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
 
 // ROI hits of the walks of the last batch: offsets[n+1] into hits (ROI record numbers, order within a walk arbitrary),
 // has_null[i] = the dfs graph of seed i holds a vertex without a record
@@ -742,16 +797,65 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
     if (traversed) *traversed = trav;
 }
 
-// returns false when the path pool was exhausted (nothing is kept; the caller splits the chunk)
-bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed) {
-    const int W = graph->hdr.W, k = graph->hdr.k;
-    rt::stream_t s = graph->stream;
-    const int64_t ns = 2 * n;
-    out.first = first; out.n = n;
+// One prepared walk launch: the arguments and the device buffers a batch (or one chunk of it) lives in.  walk_prepare sets it up,
+// walk_launch runs the kernel (once for a table that is resident; once per bulk-synchronous round over a sharded table's image),
+// walk_finish assembles the results.
+struct WalkRun {
+    WalkArgs a;
+    int W = 0, k = 0, block = 64, grid = 1, max_blocks = 0;
+    int64_t first = 0, n = 0, ns = 0;
+    uint32_t vcap_max = 0;
+    bool want_times = false;
+    double walk_ms = 0;
+    uint32_t *d_strand_n = nullptr, *d_strand_c = nullptr, *d_retry = nullptr, *d_status = nullptr, *d_iters = nullptr;
+    uint8_t *d_quirk = nullptr, *d_seed_valid = nullptr;
+    unsigned long long* d_ctr = nullptr;
+    void* d_save = nullptr;
+    WalkChunk out;
+    void free_tmp() {
+        rt::dfree(d_strand_n); rt::dfree(d_strand_c); rt::dfree(d_retry); rt::dfree(d_seed_valid); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk);
+        rt::dfree(d_save);
+        d_strand_n = d_strand_c = d_retry = d_status = d_iters = nullptr; d_quirk = d_seed_valid = nullptr; d_ctr = nullptr; d_save = nullptr;
+    }
+};
+#define WALKRUN_ALIASES(r) \
+    WalkArgs& a = (r).a; WalkChunk& out = (r).out; const int W = (r).W, k = (r).k; (void)k; const int64_t first = (r).first, n = (r).n, ns = (r).ns; (void)first; \
+    const int max_blocks = (r).max_blocks; const uint32_t vcap_max = (r).vcap_max; (void)vcap_max; \
+    uint32_t*& d_strand_n = (r).d_strand_n; uint32_t*& d_strand_c = (r).d_strand_c; uint32_t*& d_retry = (r).d_retry; uint32_t*& d_status = (r).d_status; \
+    uint32_t*& d_iters = (r).d_iters; uint8_t*& d_quirk = (r).d_quirk; uint8_t*& d_seed_valid = (r).d_seed_valid; unsigned long long*& d_ctr = (r).d_ctr; \
+    (void)d_retry; (void)d_seed_valid; rt::stream_t s = graph->stream; auto free_tmp = [&] { (r).free_tmp(); }; (void)free_tmp
 
+static void launch_k_walk(const WalkRun& r, const WalkArgs& a, rt::stream_t s) {
+    const int block = r.block, grid = r.grid;
+#define LDBG_WALK_CASE(WW) \
+    if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, a); \
+    else if (block == 64) LDBG_LAUNCH((k_walk<WW, 64>), grid, 64, s, a); \
+    else LDBG_LAUNCH((k_walk<WW, 32>), grid, 32, s, a)
+    switch (r.W) {
+        case 1: LDBG_WALK_CASE(1); break;
+        case 2: LDBG_WALK_CASE(2); break;
+        case 3: LDBG_WALK_CASE(3); break;
+        default: LDBG_WALK_CASE(4); break;
+    }
+#undef LDBG_WALK_CASE
+}
+
+// strands of this rank that are not done: those a lane holds (suspended) + those still in the queue; and the requests of the round
+LDBG_KERNEL void k_round_stats(const unsigned long long* ctr, int64_t ns, const unsigned long long* n_req, int64_t* stats) {
+    if (global_tid() != 0) return;
+    const int64_t handed = (int64_t)ctr[0] < ns ? (int64_t)ctr[0] : ns;
+    stats[0] = (int64_t)ctr[4] + (ns - handed);
+    stats[1] = (int64_t)*n_req;
+}
+
+// img: the walk runs on the local image of a sharded table (image.h): strands suspend where a row is missing, seeds come as image slots
+void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first_, int64_t n_, WalkRun& r, ShardImage* img, const int32_t* d_seed_slot) {
+    r.W = graph->hdr.W; r.k = graph->hdr.k; r.first = first_; r.n = n_; r.ns = 2 * n_;
+    r.out.first = first_; r.out.n = n_;
     // a strand's visited table never needs more than this (longest possible branch at load <= 1/2)
-    const uint32_t vcap_max = std::max<uint32_t>(64u, next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 12)));
-    const int max_blocks = (int)(((int64_t)cfg.max_branch_length + 2 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK);
+    r.vcap_max = std::max<uint32_t>(64u, next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 12)));
+    r.max_blocks = (int)(((int64_t)cfg.max_branch_length + 2 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK);
+    WALKRUN_ALIASES(r);
     HostLaps laps;
     ensure_scratch(ns, link_store_capacity, max_blocks);
     zero_dirty_tables(s);
@@ -759,32 +863,38 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
 
     out.d_seed_words = rt::dmalloc((size_t)n * W * 8);
     rt::h2d(out.d_seed_words, &seed_words[first * W], (size_t)n * W * 8, s);
-    uint8_t* d_seed_valid = (uint8_t*)rt::dmalloc((size_t)n);
+    d_seed_valid = (uint8_t*)rt::dmalloc((size_t)n);
     rt::h2d(d_seed_valid, &seed_valid_[first], (size_t)n, s);
     out.d_term = rt::dmalloc((size_t)ns * W * 8);
-    uint32_t* d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    uint32_t* d_strand_c = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    uint32_t* d_retry = nullptr;
-    uint32_t* d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    uint32_t* d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    uint8_t* d_quirk = (uint8_t*)rt::dmalloc((size_t)ns);
-    unsigned long long* d_ctr = (unsigned long long*)rt::dmalloc(32);
-    rt::dmemset(d_ctr, 0, 32, s);
+    d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    d_strand_c = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
+    d_quirk = (uint8_t*)rt::dmalloc((size_t)ns);
+    d_ctr = (unsigned long long*)rt::dmalloc(64);
+    rt::dmemset(d_ctr, 0, 64, s);
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
-    auto free_tmp = [&] { rt::dfree(d_strand_n); rt::dfree(d_strand_c); rt::dfree(d_retry); rt::dfree(d_seed_valid); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk); };
 
     laps.lap("small allocations");
-    WalkArgs a;
     a.e = view;
-    if (!runs_ && !getenv("LDBG_NO_RUNS") && (view.g.k & 1)) {       // the run index of this engine's colour masks (runs.h), built on first use
+    if (!img && !runs_ && !getenv("LDBG_NO_RUNS") && (view.g.k & 1)) {       // the run index of this engine's colour masks (runs.h), built on first use
         runs_.reset(new RunIndex(view, graph->device, s));
         profile_add("run_index", runs_->build_ms);
         if (getenv("LDBG_HOST_TIMES"))
             fprintf(stderr, "[ldbg] run index: %lld chains hold %lld of %lld records, built in %.1f ms\n", (long long)runs_->n_chains,
                     (long long)runs_->n_in_chains, (long long)view.g.N, runs_->build_ms);
     }
-    if (runs_) a.e.runs = runs_->view;
+    if (runs_ && !img) a.e.runs = runs_->view;
     a.retry = nullptr;
+    a.img_on = img ? 1 : 0;
+    a.seed_slot = d_seed_slot;
+    a.save = nullptr; a.unfinished = d_ctr + 4;
+    if (img) {
+        a.img = img->view((uint64_t*)view.links.rec_of);
+        r.d_save = rt::dmalloc((size_t)std::max<int64_t>(64, n_slots_) * sizeof(StrandSave));
+        rt::dmemset(r.d_save, 0, (size_t)std::max<int64_t>(64, n_slots_) * sizeof(StrandSave), s);
+        a.save = (StrandSave*)r.d_save;
+    }
     a.seeds = (const uint64_t*)out.d_seed_words;
     a.seed_valid = d_seed_valid;
     a.n_strands = ns;
@@ -812,7 +922,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.vpool = (uint64_t*)d_vpool_; a.vnext = d_ctr + 2; a.vpool_entries = vpool_entries_; a.vcap_max = vcap_max;
     a.vcap_init = vt_initial_entries();
     if (!getenv("LDBG_VT_INITIAL")) {
-        if (runs_) {
+        if (runs_ && !img) {
             // with the run index a strand's table holds the fringes of the stretches it crosses and the junction vertices between
             // them: a few entries per thousand k-mers.  Small tables = little to zero between batches (C3: 8.5 ms -> 0.3 ms)
             a.vcap_init = std::min<uint32_t>(2048u, vcap_max);
@@ -827,14 +937,13 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.snap = getenv("LDBG_NO_REPEAT") ? nullptr : (LsSnap*)d_snap_;
 
     a.wg_times = nullptr; a.st_times = nullptr; a.st_gen = nullptr;
-    const bool want_times = getenv("LDBG_WG_TIMES") != nullptr;
-    rt::Event e0, e1;
-    e0.record(s);
+    const bool want_times = r.want_times = getenv("LDBG_WG_TIMES") != nullptr && !img;
     // one (partial) wavefront per workgroup; every workgroup must be resident (lanes refill from the strand queue):
     // LDBG_LS_FAST x block x 24 B of LDS each, at most 32 wavefronts per CU
     // (measured at C3, profiles/r01_exp_block.log: 64 lanes 0.51 s, 32 lanes 0.60 s, 16 lanes 0.63 s per launch — smaller
     // wavefronts finish the bulk sooner but the longest strands run slower with more wavefronts per CU)
-    int block = 64;
+    int& block = r.block;
+    block = 64;
     if (const char* ev = getenv("LDBG_WALK_BLOCK")) block = atoi(ev) == 16 ? 16 : (atoi(ev) == 32 ? 32 : 64);   // tuning knob
     // residency: LDS per workgroup, and 152 VGPRs per lane leave 3 wavefronts per SIMD = 12 per CU
     int wg_per_cu = std::min<int>(12, (int)(160 * 1024 / (LDBG_LS_FAST * (size_t)block * sizeof(LsElem))));
@@ -842,7 +951,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     a.n_slots = std::min<int64_t>(a.n_slots, (int64_t)wg_per_cu * rt::cu_count(graph->device) * block);
     a.n_slots = (a.n_slots / block) * block;
     if (a.n_slots < block) a.n_slots = block;
-    const int grid = (int)((a.n_slots + block - 1) / block);
+    const int grid = r.grid = (int)((a.n_slots + block - 1) / block);
     if (want_times) {
         a.wg_times = (unsigned long long*)rt::dmalloc((size_t)grid * 16); rt::dmemset(a.wg_times, 0, (size_t)grid * 16, s);
         a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
@@ -851,24 +960,30 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         a.st_prof = (unsigned long long*)rt::dmalloc((size_t)ns * 32); rt::dmemset(a.st_prof, 0, (size_t)ns * 32, s);
 #endif
     }
-#define LDBG_WALK_CASE(WW) \
-    if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, a); \
-    else if (block == 64) LDBG_LAUNCH((k_walk<WW, 64>), grid, 64, s, a); \
-    else LDBG_LAUNCH((k_walk<WW, 32>), grid, 32, s, a)
-    switch (W) {
-        case 1: LDBG_WALK_CASE(1); break;
-        case 2: LDBG_WALK_CASE(2); break;
-        case 3: LDBG_WALK_CASE(3); break;
-        default: LDBG_WALK_CASE(4); break;
-    }
-#undef LDBG_WALK_CASE
+}
+
+// one launch of the walk kernel: the whole batch for a resident table, one bulk-synchronous round on an image
+void Engine::walk_launch(WalkRun& r) {
+    rt::stream_t s = graph->stream;
+    rt::Event e0, e1;
+    e0.record(s);
+    launch_k_walk(r, r.a, s);
     e1.record(s);
+    r.walk_ms += rt::Event::elapsed_ms(e0, e1);
+}
+
+// returns false when the path pool was exhausted (nothing is kept; the caller splits the chunk)
+bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
+    WALKRUN_ALIASES(r);
+    const bool want_times = r.want_times;
+    const int grid = r.grid, block = r.block; (void)block;
+    HostLaps laps;
 
     // strands the run steps handed back (ST_RETRY_PLAIN) are walked again k-mer by k-mer, without the run index
     out.status.resize(ns);
     rt::d2h(out.status.data(), d_status, (size_t)ns * 4, s);
     rt::stream_sync(s);
-    if (runs_) {
+    if (runs_ && !a.img_on) {
         std::vector<uint32_t> again;
         for (int64_t i = 0; i < ns; i++) if (out.status[i] == ST_RETRY_PLAIN) again.push_back((uint32_t)i);
         if (!again.empty()) {
@@ -880,17 +995,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
             b.retry = d_retry;
             b.n_strands = (int64_t)again.size();
             retried_strands_ += (int64_t)again.size();
-#define LDBG_WALK_CASE(WW) \
-    if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, b); \
-    else if (block == 64) LDBG_LAUNCH((k_walk<WW, 64>), grid, 64, s, b); \
-    else LDBG_LAUNCH((k_walk<WW, 32>), grid, 32, s, b)
-            switch (W) {
-                case 1: LDBG_WALK_CASE(1); break;
-                case 2: LDBG_WALK_CASE(2); break;
-                case 3: LDBG_WALK_CASE(3); break;
-                default: LDBG_WALK_CASE(4); break;
-            }
-#undef LDBG_WALK_CASE
+            launch_k_walk(r, b, s);
         }
     }
 
@@ -978,7 +1083,7 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
         rt::dfree(a.st_times);
     }
     vpool_dirty_ = ctr[2];
-    profile_add("walk", rt::Event::elapsed_ms(e0, e1));
+    profile_add("walk", r.walk_ms);
     laps.lap("launch .. results on host");
 
     bool pool_full = false;
@@ -1042,6 +1147,82 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
             throw StatusError(LDBG_ERR_UNSUPPORTED, "a vertex was visited more than 32767 times in one walk");
     }
     return true;
+}
+
+
+// ---- walk_batch_run over the image of a hash-sharded table (image.h): the same preparation and result assembly, the kernel once
+// per bulk-synchronous round
+void Engine::sharded_walk_begin(ShardImage& img, const char* seeds, int64_t n, const int32_t* d_seed_slot, rt::stream_t round_stream) {
+    if (cfg.stopping_rule != LDBG_STOP_CONTIG || cfg.connect_all_neighbors || cfg.n_secondary > 0)
+        throw StatusError(LDBG_ERR_UNSUPPORTED, "walks over a sharded table run ContigStopper without connectAllNeighbors / secondary colours");
+    if (&img.graph() != graph) throw StatusError(LDBG_ERR_ARG, "the engine was not created on this image's graph");
+    rt::set_device(graph->device);
+    sharded_abort();
+    clear_batch();
+    const int k = graph->hdr.k, W = graph->hdr.W;
+    std::vector<uint64_t> words((size_t)n * W);
+    seed_valid_.resize((size_t)std::max<int64_t>(1, n));
+    ascii_batch_to_words(seeds, n, k, W, words.data(), seed_valid_.data());
+    batch_n = n;
+    sharded_run_ = new WalkRun;
+    sharded_img_ = &img;
+    sharded_stream_ = round_stream ? round_stream : graph->stream;
+    try {
+        walk_prepare(words, 0, n, *sharded_run_, &img, d_seed_slot);
+        rt::stream_sync(graph->stream);
+    } catch (...) { sharded_abort(); throw; }
+}
+void Engine::sharded_abort() {
+    if (sharded_run_) {
+        sharded_run_->free_tmp();
+        rt::dfree(sharded_run_->out.d_seed_words); rt::dfree(sharded_run_->out.d_term);
+        delete sharded_run_;
+        sharded_run_ = nullptr;
+    }
+    sharded_img_ = nullptr;
+}
+// d_stats (device, 2 x int64): strands of this rank still in progress after the round (suspended or not yet handed out), requests filed
+void Engine::sharded_walk_round(int64_t* d_stats) {
+    if (!sharded_run_) throw StatusError(LDBG_ERR_ARG, "sharded_walk_round without sharded_walk_begin");
+    rt::set_device(graph->device);
+    WalkRun& r = *sharded_run_;
+    rt::stream_t s = sharded_stream_;
+    rt::dmemset(r.d_ctr + 4, 0, 8, s);
+    sharded_img_->reset_requests(s);
+    launch_k_walk(r, r.a, s);
+    LDBG_LAUNCH(k_round_stats, 1, 64, s, (const unsigned long long*)r.d_ctr, r.ns, (const unsigned long long*)r.a.img.n_req, d_stats);
+    sharded_rounds_++;
+}
+void Engine::sharded_walk_finish(int64_t* total_bytes, int64_t* traversed) {
+    if (!sharded_run_) throw StatusError(LDBG_ERR_ARG, "sharded_walk_finish without sharded_walk_begin");
+    rt::set_device(graph->device);
+    WalkRun& r = *sharded_run_;
+    rt::stream_sync(sharded_stream_);
+    profile_add("walk_rounds", (double)sharded_rounds_);
+    sharded_rounds_ = 0;
+    int64_t trav = 0;
+    bool ok = false;
+    try { ok = walk_finish(r, &trav); } catch (...) { sharded_abort(); throw; }
+    if (!ok) { sharded_abort(); throw StatusError(LDBG_ERR_CAPACITY, "path pool exhausted during a walk over a sharded table: use smaller batches"); }
+    chunks.push_back(std::move(r.out));
+    r.out = WalkChunk();
+    sharded_abort();
+    batch_traversed = trav;
+    batch_bytes = chunks.back().contig_off.back();
+    if (total_bytes) *total_bytes = batch_bytes;
+    if (traversed) *traversed = trav;
+}
+
+bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed) {
+    WalkRun r;
+    try {
+        walk_prepare(seed_words, first, n, r, nullptr, nullptr);
+        walk_launch(r);
+        const bool ok = walk_finish(r, traversed);
+        if (ok) out = std::move(r.out);
+        r.free_tmp();
+        return ok;
+    } catch (...) { r.free_tmp(); throw; }
 }
 
 void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len) {

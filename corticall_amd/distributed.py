@@ -4,9 +4,15 @@
 * replicas — the table fits one GPU (configs C2-C4 are ~2 GB): every rank loads the graph, the seeds are
   partitioned, there is NO data-path collective; `partition()` / `gather_strings()` below are all it needs.
 * hash-sharded table — `ShardedCortexGraph`: rank r keeps the records whose canonical k-mer hashes to r (still
-  sorted, so the per-shard lookup is the unchanged HIP find kernel).  A batch of findRecord queries is routed
-  with ONE exchange each way: canonicalise + owner on the device (ldbg_shard_owner_dev), bucket by owner,
-  all-to-all the queries, local find (ldbg_graph_find_dev), all-to-all the answers back.
+  sorted, so the per-shard lookup is the unchanged HIP find kernel).  Loading: every rank scans 1/G of the file and the
+  records travel to their owners in one all-to-all.  A batch of findRecord queries is routed with ONE exchange each
+  way: canonicalise + owner on the device (ldbg_shard_owner_dev), bucket by owner, all-to-all the queries, local find
+  (ldbg_graph_find_dev), all-to-all the answers back.
+* traversals over the sharded table — `ShardedTraversalEngine`: every rank keeps a local IMAGE of the rows it has
+  been sent (csrc/image.h) and runs the unchanged walk kernel on it; strands suspend where a row is missing.  One
+  bulk-synchronous round = kernel launch -> requests bucketed by owner on the device -> all-to-all -> owners serve
+  rows -> all-to-all -> insert, all queued on one stream without a host synchronisation; the host looks at the
+  "anyone still walking" count only every few rounds.
 
 torch is plumbing here (device buffers, process group, collectives); every computation on k-mers is a kernel
 behind the C ABI.
@@ -64,9 +70,9 @@ for _i, _c in enumerate(b"ACGT"):
     _LUT[ord(chr(_c).lower())] = _i
 
 
-def pack_kmers(ascii_kmers, k):
-    """ASCII u8[n,k] -> packed words u64[n,W] (word 0 most significant); a non-ACGT k-mer gets all-ones words,
-    which every kernel treats as "not a k-mer" (Q4)"""
+def pack_kmers(ascii_kmers, k, return_valid=False):
+    """ASCII u8[n,k] -> packed words u64[n,W] (word 0 most significant).  A string with a non-ACGT byte is not a k-mer (Q4): its
+    words are zero and valid[i] is False — validity travels beside the words (at k = 32, 64, ... no bit pattern is free)"""
     a = np.ascontiguousarray(ascii_kmers, dtype=np.uint8).reshape(-1, k)
     W = (k + 31) // 32
     codes = _LUT[a]
@@ -76,8 +82,8 @@ def pack_kmers(ascii_kmers, k):
     for i in range(k):
         bit = 2 * (k - 1 - i)
         words[:, W - 1 - (bit >> 6)] |= codes[:, i] << np.uint64(bit & 63)
-    words[bad] = np.uint64(0xFFFFFFFFFFFFFFFF)
-    return words
+    words[bad] = 0
+    return (words, ~bad) if return_valid else words
 
 
 class ShardedCortexGraph:
@@ -91,29 +97,48 @@ class ShardedCortexGraph:
         self._lib = lib or _native.default_lib()
         self._d = self._lib.dll
         self.path = str(path)
+        self.device = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
         raw = np.memmap(self.path, dtype=np.uint8, mode="r")
         h = ctx_header(raw)
         self.k, self.W, self.C = h["k"], h["W"], h["C"]
         rec = 8 * self.W + 5 * self.C
         n_all = (raw.size - h["data_offset"]) // rec
-        records = raw[h["data_offset"]:h["data_offset"] + n_all * rec].reshape(n_all, rec)
-        # cut this rank's shard: owner of every record's k-mer, a chunk at a time (the rule lives in the library)
-        mine = []
-        for lo in range(0, n_all, chunk_records):
-            blk = records[lo:lo + chunk_records]
+        # every rank scans ONE slice of the file (1/world of the records) and sends each record to its owner: one all-to-all.
+        # A slice is sorted and bucketing keeps the order, so a shard receives `world` sorted runs, which it merges.
+        first, cnt = partition(n_all, self.rank, self.world)
+        records = raw[h["data_offset"] + first * rec:h["data_offset"] + (first + cnt) * rec].reshape(cnt, rec)
+        buckets = [[] for _ in range(self.world)]
+        for lo in range(0, cnt, chunk_records):
+            blk = np.ascontiguousarray(records[lo:lo + chunk_records])
             keys = np.ascontiguousarray(blk[:, :8 * self.W]).view("<u8").reshape(-1, self.W)
             owner = np.empty(len(blk), dtype=np.int32)
             self._lib.check(self._d.ldbg_shard_owner(self.k, keys.ctypes.data_as(C.c_void_p), C.c_int64(len(blk)), self.world,
                                                      int(device), owner.ctypes.data_as(C.c_void_p)))
-            mine.append(np.ascontiguousarray(blk[owner == self.rank]))
-        shard = np.concatenate(mine) if mine else np.zeros((0, rec), dtype=np.uint8)
-        image = np.concatenate([np.asarray(raw[:h["data_offset"]]), shard.reshape(-1)])
+            for r in range(self.world):
+                buckets[r].append(blk[owner == r])
+        send = [np.concatenate(b) if b else np.zeros((0, rec), dtype=np.uint8) for b in buckets]
+        send_counts = torch.tensor([len(x) for x in send], dtype=torch.int64)
+        recv_counts = torch.empty_like(send_counts)
+        dev_counts = send_counts.to(self.device)
+        dev_recv = torch.empty_like(dev_counts)
+        dist.all_to_all_single(dev_recv, dev_counts, group=group)
+        recv_counts = dev_recv.cpu()
+        flat = torch.from_numpy(np.concatenate(send).reshape(-1) if cnt else np.zeros(0, dtype=np.uint8)).to(self.device)
+        got = torch.empty(int(recv_counts.sum().item()) * rec, dtype=torch.uint8, device=self.device)
+        dist.all_to_all_single(got, flat, output_split_sizes=[int(c) * rec for c in recv_counts.tolist()],
+                               input_split_sizes=[int(c) * rec for c in send_counts.tolist()], group=group)
+        shard = got.cpu().numpy().reshape(-1, rec)
+        if len(shard) > 1:                                   # merge the sorted runs (k-mer words, most significant first)
+            keys = np.ascontiguousarray(shard[:, :8 * self.W]).view("<u8").reshape(-1, self.W)
+            order = np.lexsort(tuple(keys[:, w] for w in range(self.W - 1, -1, -1)))
+            shard = shard[order]
+        image = np.concatenate([np.asarray(raw[:h["data_offset"]]), np.ascontiguousarray(shard).reshape(-1)])
         self.shard = CortexGraph(self.path + "#shard%d" % self.rank, device=device, lib=self._lib, image=image)
         self._lib.check(self._d.ldbg_graph_set_shard(self.shard._h, 1))
-        self.device = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
         n = torch.tensor([self.shard.getNumRecords()], dtype=torch.int64, device=self.device)
         dist.all_reduce(n, group=group)
         self.numRecords = int(n.item())
+        self.has_neighbour_index = False
 
     def getNumRecords(self): return self.numRecords
     def getKmerSize(self): return self.k
@@ -132,14 +157,15 @@ class ShardedCortexGraph:
         torch = self._torch
         if not isinstance(kmers, np.ndarray):
             kmers = np.frombuffer(b"".join(x.encode() if isinstance(x, str) else bytes(x) for x in kmers), dtype=np.uint8)
-        q = torch.from_numpy(pack_kmers(kmers, self.k).view(np.int64)).to(self.device)
-        found, l_cov, l_edges, owner, l_idx = self.find_packed_dev(q)
+        words, valid = pack_kmers(kmers, self.k, return_valid=True)
+        q = torch.from_numpy(words.view(np.int64)).to(self.device)
+        found, l_cov, l_edges, owner, l_idx = self.find_packed_dev(q, valid=torch.from_numpy(valid).to(self.device))
         return (found.cpu().numpy(), l_cov.cpu().numpy(), l_edges.cpu().numpy(), owner.cpu().numpy(), l_idx.cpu().numpy())
 
-    def find_packed_dev(self, q, return_canonical=False):
-        """device form: q = packed k-mer words, int64[n, W] on this rank's device (all-ones words = not a k-mer)
-        -> (found, cov, edges, owner, local_idx) as device tensors (+ the canonical words when asked); nothing touches
-        the host but the split sizes"""
+    def find_packed_dev(self, q, return_canonical=False, valid=None):
+        """device form: q = packed k-mer words, int64[n, W] on this rank's device; valid (bool[n], optional): False = not a k-mer,
+        the query misses (Q4).  -> (found, cov, edges, owner, local_idx) as device tensors (+ the canonical words when asked);
+        nothing touches the host but the split sizes"""
         torch, dist = self._torch, self._dist
         n, W, Cc, world = q.shape[0], self.W, self.C, self.world
         canon = torch.empty_like(q)
@@ -172,6 +198,11 @@ class ShardedCortexGraph:
         inv = torch.empty_like(order)
         inv[order] = torch.arange(n, device=self.device)
         l_idx, l_cov, l_edges = r_idx[inv], r_cov[inv], r_edges[inv]
+        if valid is not None and n:
+            bad = ~valid.to(torch.bool)
+            l_idx = torch.where(bad, torch.full_like(l_idx, -1), l_idx)
+            l_cov = torch.where(bad[:, None], torch.zeros_like(l_cov), l_cov)
+            l_edges = torch.where(bad[:, None], torch.zeros_like(l_edges), l_edges)
         found = l_idx >= 0
         if self.numRecords <= 2:       # Q1 is a property of the whole graph (CortexGraph.java:274-282)
             found = torch.zeros_like(found)
@@ -181,7 +212,7 @@ class ShardedCortexGraph:
             return found, l_cov, l_edges, owner, l_idx, canon
         return found, l_cov, l_edges, owner, l_idx
 
-    # ---- walks over the partitioned table (csrc/shard.cpp)
+    # ---- the global neighbour index (csrc/shard.cpp)
     def build_neighbour_index(self, chunk_records=1 << 18):
         """global neighbour index of this shard: for every local record and each of its 8 possible neighbours the owner,
         the record number in the owner's shard and the orientation — one routed findRecord per edge, done once.
@@ -190,133 +221,151 @@ class ShardedCortexGraph:
         n_local = self.shard.getNumRecords()
         rounds = torch.tensor([(n_local + chunk_records - 1) // chunk_records], dtype=torch.int64, device=self.device)
         dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=self._group)
-        for r in range(int(rounds.item())):
-            first = min(n_local, r * chunk_records)
-            n = max(0, min(chunk_records, n_local - first))
-            words = torch.empty((max(1, 8 * n), self.W), dtype=torch.int64, device=self.device)[:8 * n]
-            flips = torch.empty(max(1, 8 * n), dtype=torch.uint8, device=self.device)[:8 * n]
-            if n:
-                self._lib.check(self._d.ldbg_shard_nbr_queries(self.shard._h, C.c_int64(first), C.c_int64(n), self._ptr(words), self._ptr(flips)))
-            _, _, _, owner, lidx = self.find_packed_dev(words)
-            if n:
-                owner, lidx = owner.contiguous(), lidx.contiguous()
-                self._lib.check(self._d.ldbg_shard_set_nbr(self.shard._h, C.c_int64(first), C.c_int64(n), self._ptr(owner), self._ptr(lidx), self._ptr(flips)))
-        rb = C.c_int()
-        self._lib.check(self._d.ldbg_shard_row_bytes(self.shard._h, C.byref(rb)))
-        self.row_bytes = rb.value
+        saved_n = self.numRecords
+        self.numRecords = max(self.numRecords, 3)       # (Q1 concerns findRecord's callers, not the index of what is stored)
+        try:
+            for r in range(int(rounds.item())):
+                first = min(n_local, r * chunk_records)
+                n = max(0, min(chunk_records, n_local - first))
+                words = torch.zeros((max(1, 8 * n), self.W), dtype=torch.int64, device=self.device)[:8 * n]
+                flips = torch.zeros(max(1, 8 * n), dtype=torch.uint8, device=self.device)[:8 * n]
+                have = torch.zeros(max(1, 8 * n), dtype=torch.uint8, device=self.device)[:8 * n]
+                if n:
+                    self._lib.check(self._d.ldbg_shard_nbr_queries(self.shard._h, C.c_int64(first), C.c_int64(n), self._ptr(words), self._ptr(flips), self._ptr(have)))
+                _, _, _, owner, lidx = self.find_packed_dev(words, valid=have.to(torch.bool))
+                if n:
+                    owner, lidx = owner.contiguous(), lidx.contiguous()
+                    self._lib.check(self._d.ldbg_shard_set_nbr(self.shard._h, C.c_int64(first), C.c_int64(n), self._ptr(owner), self._ptr(lidx), self._ptr(flips)))
+        finally:
+            self.numRecords = saved_n
         self.has_neighbour_index = True
-
-    def fetch_rows(self, req_owner, req_lidx):
-        """one exchange: req_owner int32[n] (-1 = no request), req_lidx int64[n] -> (rows uint8[n, row_bytes], have uint8[n]).
-        Collective: every rank calls it, possibly with no requests."""
-        torch, dist = self._torch, self._dist
-        n, world = req_owner.shape[0], self.world
-        sel = torch.nonzero(req_owner >= 0).flatten()
-        own = req_owner[sel].to(torch.int64)
-        order = torch.argsort(own, stable=True)
-        sel = sel[order]
-        send = req_lidx[sel].contiguous()
-        send_counts = torch.bincount(own, minlength=world)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self._group)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()
-        m = int(sum(rc))
-        recv = torch.empty(m, dtype=torch.int64, device=self.device)
-        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=self._group)
-        served = torch.zeros((max(1, m), self.row_bytes), dtype=torch.uint8, device=self.device)[:m]
-        if m:
-            self._lib.check(self._d.ldbg_shard_rows(self.shard._h, self._ptr(recv), C.c_int64(m), self._ptr(served)))
-        back = torch.empty((int(sel.shape[0]), self.row_bytes), dtype=torch.uint8, device=self.device)
-        dist.all_to_all_single(back, served.contiguous(), output_split_sizes=sc, input_split_sizes=rc, group=self._group)
-        rows = torch.zeros((max(1, n), self.row_bytes), dtype=torch.uint8, device=self.device)[:n]
-        have = torch.zeros(max(1, n), dtype=torch.uint8, device=self.device)[:n]
-        rows[sel] = back
-        have[sel] = 1
-        return rows, have
 
     def close(self):
         self.shard.close()
 
 
 class ShardedTraversalEngine:
-    """TraversalEngine.walk over a ShardedCortexGraph (ContigStopper, no link annotations, odd k): bulk-synchronous —
-    every step of all walks in flight on all ranks is one exchange of row requests and one of rows."""
+    """TraversalEngine.walk over a ShardedCortexGraph — ContigStopper with or without link annotations, any k: every rank runs the
+    walk kernel on its local image of the table (csrc/image.h); rows travel, walks do not.
+    links: CortexLinks objects opened on `sgraph.shard` (each rank opens the link file against its own shard)."""
 
-    def __init__(self, sgraph, traversal_colors, recruitment_colors=(), direction=0, op=0, max_branch_length=75000):
+    def __init__(self, sgraph, traversal_colors, links=(), recruitment_colors=(), direction=0, op=0, max_branch_length=75000,
+                 image_rows=None, rows_per_owner=4096, check_every=8, keep_image=False):
         from .traversal import ContigStopper, TraversalEngineFactory
         self.g = sgraph
-        if not getattr(sgraph, "has_neighbour_index", False):
+        if not sgraph.has_neighbour_index:
             sgraph.build_neighbour_index()
-        f = (TraversalEngineFactory(lib=sgraph._lib).traversalColors(*traversal_colors).graph(sgraph.shard).stoppingRule(ContigStopper)
+        lib, d = sgraph._lib, sgraph._d
+        self._lib, self._d = lib, d
+        cap = int(image_rows or min(max(sgraph.numRecords, 1024), 1 << 25))
+        self._img = C.c_void_p()
+        lib.check(d.ldbg_image_create(sgraph.shard._h, C.c_int64(cap), C.c_int64(sgraph.numRecords), C.byref(self._img)))
+        gh = C.c_void_p()
+        lib.check(d.ldbg_image_graph(self._img, C.byref(gh)))
+        self.image_graph = CortexGraph._from_handle(gh, lib, sgraph.path + "#image%d" % sgraph.rank, owner=self)
+        rb = C.c_int()
+        lib.check(d.ldbg_image_row_bytes(self._img, C.byref(rb)))
+        self.row_bytes = rb.value
+        f = (TraversalEngineFactory(lib=lib).traversalColors(*traversal_colors).graph(self.image_graph).stoppingRule(ContigStopper)
              .traversalDirection(direction).combinationOperator(op).maxBranchLength(max_branch_length))
         if recruitment_colors:
             f.recruitmentColors(*recruitment_colors)
+        if links:
+            f.links(*links)
         self.engine = f.make()
-        self._op_and = op == 1
-        self._first = list(traversal_colors)[0]
-        self._max_len = max_branch_length
-        self._w = C.c_void_p()
-        sgraph._lib.check(sgraph._d.ldbg_bsp_create(self.engine._h, C.byref(self._w)))
+        self.rows_per_owner = int(rows_per_owner)
+        self.check_every = int(check_every)
+        self.keep_image = keep_image
         self.kmers_traversed = 0
-        self.exchanges = 0
+        self.rounds = 0
+        torch = sgraph._torch
+        w, cap_o = sgraph.world, self.rows_per_owner
+        self._send = torch.zeros((w, cap_o), dtype=torch.int64, device=sgraph.device)
+        self._recv = torch.zeros((w, cap_o), dtype=torch.int64, device=sgraph.device)
+        self._rows_out = torch.zeros((w, cap_o, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
+        self._rows_in = torch.zeros((w, cap_o, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
+        self._stats = torch.zeros(2, dtype=torch.int64, device=sgraph.device)
+
+    def _stream(self):
+        t = self.g._torch
+        return C.c_void_p(t.cuda.current_stream(self.g.device).cuda_stream) if self.g.device.type == "cuda" else None
+
+    def _exchange(self, stream):
+        """requests of this round -> rows in the image: bucket, all-to-all, serve, all-to-all, insert — all on one stream"""
+        g, d, lib, dist = self.g, self._d, self._lib, self.g._dist
+        P = lambda t: C.c_void_p(t.data_ptr())
+        n = g.world * self.rows_per_owner
+        lib.check(d.ldbg_image_bucket(self._img, g.world, C.c_uint32(self.rows_per_owner), P(self._send), stream))
+        dist.all_to_all_single(self._recv.view(-1), self._send.view(-1), group=g._group)
+        lib.check(d.ldbg_image_serve(self._img, g.rank, P(self._recv), C.c_int64(n), P(self._rows_out), stream))
+        dist.all_to_all_single(self._rows_in.view(-1), self._rows_out.view(-1), group=g._group)
+        lib.check(d.ldbg_image_insert(self._img, self.engine._h, P(self._rows_in), C.c_int64(n), stream))
+
+    def _all_done(self, local_count):
+        t = local_count.clone().reshape(1)
+        self.g._dist.all_reduce(t, group=self.g._group)
+        return int(t.item()) == 0
 
     def walk_batch(self, seeds):
         """contigs of this rank's seeds (list of str); collective: every rank calls it (possibly with no seeds)"""
         g, torch, dist = self.g, self.g._torch, self.g._dist
-        lib, d, P = g._lib, g._d, g._ptr
+        lib, d = self._lib, self._d
+        P = lambda t: C.c_void_p(t.data_ptr())
         k = g.k
-        seeds = list(seeds)
+        seeds = [x if isinstance(x, str) else bytes(x).decode() for x in seeds]
         n = len(seeds)
         ascii_ = np.frombuffer("".join(seeds).encode(), dtype=np.uint8).reshape(n, k) if n else np.zeros((0, k), dtype=np.uint8)
-        q = torch.from_numpy(pack_kmers(ascii_, k).view(np.int64)).to(g.device)
-        found, cov, _, owner, lidx, canon = g.find_packed_dev(q, return_canonical=True)
-        flip = (canon != q).any(dim=1).to(torch.uint8).contiguous() if n else torch.zeros(0, dtype=torch.uint8, device=g.device)
-        ns = 2 * n
-        req_owner = torch.full((max(1, ns),), -1, dtype=torch.int32, device=g.device)[:ns]
-        req_lidx = torch.full((max(1, ns),), -1, dtype=torch.int64, device=g.device)[:ns]
-        owner, lidx = owner.contiguous(), lidx.contiguous()
-        lib.check(d.ldbg_bsp_start(self._w, C.c_int64(n), P(owner), P(lidx), P(flip), P(req_owner), P(req_lidx)))
+        words, valid = pack_kmers(ascii_, k, return_valid=True)
+        q = torch.from_numpy(words.view(np.int64)).to(g.device)
+        found, _, _, owner, lidx = g.find_packed_dev(q, valid=torch.from_numpy(valid).to(g.device))
+        keys = torch.where(found, (lidx + 1) | (owner.to(torch.int64) << 40), torch.zeros_like(lidx)).contiguous()
+        stream = self._stream()
+        if not self.keep_image:
+            lib.check(d.ldbg_image_clear(self._img))
+        # the seeds' own rows first: explicit requests, as many rounds as the per-owner blocks need
+        slots = torch.full((max(1, n),), -1, dtype=torch.int32, device=g.device)[:n]
         while True:
-            pending = (req_owner >= 0).sum().to(torch.int64).reshape(1)
-            dist.all_reduce(pending, group=g._group)
-            if int(pending.item()) == 0:
+            missing = keys[(slots < 0) & (keys != 0)].contiguous() if n else keys
+            if self._all_done(torch.tensor(int(missing.shape[0]), dtype=torch.int64, device=g.device)):
                 break
-            rows, have = g.fetch_rows(req_owner, req_lidx)
-            self.exchanges += 1
-            lib.check(d.ldbg_bsp_step(self._w, P(have), P(rows.contiguous()), P(req_owner), P(req_lidx)))
-        stride = self._max_len + 4
-        strand_n = np.zeros(max(1, ns), dtype=np.uint32)
-        status = np.zeros(max(1, ns), dtype=np.uint32)
-        iters = np.zeros(max(1, ns), dtype=np.uint32)
-        bases = np.zeros((max(1, ns), stride), dtype=np.uint8)
-        if ns:
-            lib.check(d.ldbg_bsp_results(self._w, strand_n.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
-                                         iters.ctypes.data_as(C.c_void_p), bases.ctypes.data_as(C.c_void_p), C.c_int64(stride)))
-        self.kmers_traversed = int(iters[:ns].sum())
-        for s_ in range(ns):
-            if status[s_] == 1:
-                raise _native.JavaNullPointerException("getNextVertices: record missing while recruitment colours are set (seed %d)" % (s_ // 2))
-            if status[s_] == 8:
-                raise _native.LdbgError(7, "a walk outgrew its visited table / path buffer")
-            if status[s_] == 11:
-                raise _native.LdbgError(4, "a walk met a quirk-Q6 vertex: not supported over a sharded table")
-        found_h, cov_h = found.cpu().numpy(), cov.cpu().numpy()
-        alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
-        out = []
-        for i in range(n):
-            nr, nf = int(strand_n[2 * i]), int(strand_n[2 * i + 1])
-            null_r, null_f = status[2 * i] == 3, status[2 * i + 1] == 3
-            is_null = (null_r or null_f) if self._op_and else (null_r and null_f)
-            seed_ok = bool(found_h[i]) and int(cov_h[i][self._first]) > 0          # toWalk's seed test, TraversalUtils.java:392-397
-            if is_null or nr + nf == 0 or not seed_ok:
-                out.append("")
-                continue
-            rev = alpha[bases[2 * i][1:nr]][::-1].tobytes().decode() if nr > 1 else ""
-            fwd = alpha[bases[2 * i + 1][1:nf]].tobytes().decode() if nf > 1 else ""
-            out.append(rev + seeds[i] + fwd)
-        return out
+            lib.check(d.ldbg_image_request(self._img, P(missing), C.c_int64(int(missing.shape[0])), stream))
+            self._exchange(stream)
+            lib.check(d.ldbg_image_reset_requests(self._img, stream))
+            if n:
+                lib.check(d.ldbg_image_lookup(self._img, P(keys), C.c_int64(n), P(slots), stream))
+        seed_buf = np.ascontiguousarray(ascii_).reshape(-1)
+        lib.check(d.ldbg_engine_sharded_walk_begin(self.engine._h, self._img, seed_buf.ctypes.data_as(C.c_char_p), C.c_int64(n), P(slots), stream))
+        rounds, gap = 0, 1
+        while True:
+            for _ in range(gap):
+                lib.check(d.ldbg_engine_sharded_walk_round(self.engine._h, P(self._stats)))
+                self._exchange(stream)
+                rounds += 1
+            if self._all_done(self._stats[0]):
+                break
+            gap = min(self.check_every, gap * 2)
+        self.rounds = rounds
+        nrows, nreq, ovf = C.c_int64(), C.c_int64(), C.c_int()
+        lib.check(d.ldbg_image_counters(self._img, C.byref(nrows), C.byref(nreq), C.byref(ovf)))
+        self.image_rows_used = nrows.value
+        if ovf.value:
+            raise _native.LdbgError(7, "the image of the sharded table is full (%d rows): create the engine with a larger image_rows" % nrows.value)
+        total, trav = C.c_int64(), C.c_int64()
+        lib.check(d.ldbg_engine_sharded_walk_finish(self.engine._h, C.byref(total), C.byref(trav)))
+        self.kmers_traversed = trav.value
+        arena = np.empty(max(1, total.value), dtype=np.uint8)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        wl = np.zeros(max(1, n), dtype=np.int64)
+        lib.check(d.ldbg_engine_walk_batch_fetch(self.engine._h, arena.ctypes.data_as(C.c_char_p), C.c_int64(total.value),
+                                                 offs.ctypes.data_as(C.c_void_p), wl.ctypes.data_as(C.c_void_p)))
+        raw = arena.tobytes()
+        self.walk_lengths = wl[:n]
+        return [raw[offs[i]:offs[i + 1]].decode() for i in range(n)]
 
     def close(self):
-        if self._w:
-            self.g._d.ldbg_bsp_destroy(self._w)
-            self._w = None
+        if getattr(self, "engine", None):
+            self.engine.close()
+            self.engine = None
+        if getattr(self, "_img", None):
+            self._d.ldbg_image_destroy(self._img)
+            self._img = None

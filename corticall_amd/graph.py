@@ -102,6 +102,17 @@ class CortexGraph:
         self._k, self._W, self._C, self._N, self._version = k.value, W.value, Cc.value, N.value, v.value
         self._pos = 0
 
+    @classmethod
+    def _from_handle(cls, handle, lib, name, owner=None):
+        """a view of a graph handle owned by something else (the image of a sharded table): close() leaves the handle alone"""
+        g = cls.__new__(cls)
+        g._lib, g._d, g.path, g._h, g._owner, g._borrowed = lib, lib.dll, str(name), handle, owner, True
+        k, W, Cc, N, v = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        lib.check(lib.dll.ldbg_graph_info(handle, C.byref(k), C.byref(W), C.byref(Cc), C.byref(N), C.byref(v)))
+        g._k, g._W, g._C, g._N, g._version = k.value, W.value, Cc.value, N.value, v.value
+        g._pos = 0
+        return g
+
     # ---- header getters (CortexGraph.java:323-336)
     def getFile(self): return self.path
     def getVersion(self): return self._version
@@ -217,7 +228,8 @@ class CortexGraph:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.check(self._d.ldbg_graph_close(self._h))
+            if not getattr(self, "_borrowed", False):
+                self._lib.check(self._d.ldbg_graph_close(self._h))
             self._h = None
 
     def __del__(self):

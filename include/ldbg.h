@@ -120,27 +120,47 @@ ldbg_status ldbg_graph_find_dev(const ldbg_graph* g, const uint64_t* d_packed, i
 ldbg_status ldbg_shard_owner_dev(int k, const uint64_t* d_packed, int64_t n, int world, uint64_t* d_canon, int32_t* d_owner, void* stream);
 ldbg_status ldbg_shard_owner(int k, const uint64_t* packed, int64_t n, int world, int device, int32_t* owner);
 
-/* Walks over the partitioned table (corticall_amd/csrc/shard.cpp; ContigStopper, no links, odd k in round 1).
- * A walk stays on the rank that holds its seed; per traversed k-mer it fetches ONE row from the owner of the vertex it
- * steps onto: 8 global neighbour ids (owner, record, orientation — a routed findRecord memoised at load) | flags |
- * C edge bytes.  All buffers are device buffers of the calling rank; calls return when the work is done. */
-ldbg_status ldbg_shard_nbr_queries(const ldbg_graph* shard, int64_t first, int64_t n, uint64_t* d_words /* [8n][W] */, uint8_t* d_flips /* [8n] */);
+/* The GLOBAL neighbour index of a shard (corticall_amd/csrc/shard.cpp): for each record and each of its 8 possible neighbours the
+ * owner, the record number in the owner's shard and the orientation — one routed findRecord per edge, memoised at load.
+ * All buffers are device buffers of the calling rank; calls return when the work is done. */
+ldbg_status ldbg_shard_nbr_queries(const ldbg_graph* shard, int64_t first, int64_t n, uint64_t* d_words /* [8n][W] */, uint8_t* d_flips /* [8n] */,
+                                   uint8_t* d_have /* [8n] 0 = no colour carries that edge: no query */);
 ldbg_status ldbg_shard_set_nbr(ldbg_graph* shard, int64_t first, int64_t n, const int32_t* d_owner, const int64_t* d_local_idx, const uint8_t* d_flips);
-ldbg_status ldbg_shard_row_bytes(const ldbg_graph* shard, int* bytes);
-ldbg_status ldbg_shard_rows(const ldbg_graph* shard, const int64_t* d_local_idx, int64_t n, uint8_t* d_rows);
-typedef struct ldbg_bsp_walker ldbg_bsp_walker;
+
+/* Traversals over the hash-sharded table: the local IMAGE (corticall_amd/csrc/image.h).
+ * A walk lives on the rank that was given its seed (visited set, link store, path, stopping rule never move).  The rank keeps an
+ * image — the rows it has been sent so far, laid out like a shard's probe table, with the neighbour index rewritten to image
+ * slots — and the unchanged traversal kernels run on it: link-guided steps, junction choices, every quirk, even k.  A strand that
+ * is about to read a row that is not there suspends and files a request.  One bulk-synchronous round =
+ *   ldbg_engine_sharded_walk_round   every strand runs until it suspends or ends
+ *   ldbg_image_bucket                requests -> one block per owner  [world][cap] of global id keys
+ *   (all-to-all)                     RCCL over xGMI: torch.distributed in corticall_amd/distributed.py
+ *   ldbg_image_serve                 the owners write the rows asked for: global id key | 8 global neighbour ids | probe row
+ *   (all-to-all)
+ *   ldbg_image_insert                arrivals enter the image; rows fetched for one strand serve all strands of the rank
+ * `stream`: a HIP stream (e.g. torch's current stream) all calls of a round are queued on — none of them synchronises with the
+ * host; NULL = the library's own stream.  A global id key is  (record number in the owner's shard + 1) | owner << 40. */
+typedef struct ldbg_image ldbg_image;
 struct ldbg_engine;
-ldbg_status ldbg_bsp_create(const struct ldbg_engine* engine_over_shard, ldbg_bsp_walker** out);
-ldbg_status ldbg_bsp_destroy(ldbg_bsp_walker* w);
-/* n seeds -> 2n strands (2i reverse, 2i+1 forward); req_owner[s] >= 0: strand s asks owner req_owner[s] for row req_local_idx[s] */
-ldbg_status ldbg_bsp_start(ldbg_bsp_walker* w, int64_t n_seeds, const int32_t* d_seed_owner, const int64_t* d_seed_local_idx,
-                           const uint8_t* d_seed_flip, int32_t* d_req_owner, int64_t* d_req_local_idx);
-/* have_row[s] != 0: the row strand s asked for is at d_rows + s * row_bytes; every such strand performs one iteration of the
- * loop TraversalEngine.java:373-481 and files its next request */
-ldbg_status ldbg_bsp_step(ldbg_bsp_walker* w, const uint8_t* d_have_row, const uint8_t* d_rows, int32_t* d_req_owner, int64_t* d_req_local_idx);
-/* host outputs: vertices per strand, status (0 ok, 1 NullPointerException, 3 branch returned null, 8 table full, 11 quirk-Q6
- * vertex: unsupported here), loop iterations, appended bases [strand][bases_stride] (entry 0 = the seed, unused) */
-ldbg_status ldbg_bsp_results(ldbg_bsp_walker* w, uint32_t* strand_n, uint32_t* status, uint32_t* iters, uint8_t* bases, int64_t bases_stride);
+ldbg_status ldbg_image_create(const ldbg_graph* shard_with_neighbour_index, int64_t capacity_rows, int64_t global_records, ldbg_image** out);
+ldbg_status ldbg_image_destroy(ldbg_image* im);
+/* the image as a graph handle: engines over the sharded table are created on it (owned by the image; do not close it) */
+ldbg_status ldbg_image_graph(ldbg_image* im, ldbg_graph** image_graph);
+ldbg_status ldbg_image_row_bytes(const ldbg_image* im, int* bytes);
+ldbg_status ldbg_image_clear(ldbg_image* im);
+ldbg_status ldbg_image_request(ldbg_image* im, const uint64_t* d_keys, int64_t n, void* stream);      /* explicit requests: seeds, sinks */
+ldbg_status ldbg_image_reset_requests(ldbg_image* im, void* stream);
+ldbg_status ldbg_image_bucket(ldbg_image* im, int world, uint32_t cap_per_owner, uint64_t* d_send /* [world][cap_per_owner], 0 = unused */, void* stream);
+ldbg_status ldbg_image_serve(const ldbg_image* im, int my_rank, const uint64_t* d_keys, int64_t n, uint8_t* d_rows_out, void* stream);
+ldbg_status ldbg_image_insert(ldbg_image* im, const struct ldbg_engine* engine_or_null, const uint8_t* d_rows, int64_t n, void* stream);
+ldbg_status ldbg_image_lookup(const ldbg_image* im, const uint64_t* d_keys, int64_t n, int32_t* d_slots /* -1 = not in the image */, void* stream);
+ldbg_status ldbg_image_counters(const ldbg_image* im, int64_t* n_rows, int64_t* n_requests, int* overflow);   /* synchronises */
+/* TraversalEngine.walk over the image (ContigStopper; links bound to the shard graph).  begin: seeds (n x k ASCII, host) with the
+ * image slots of their records (device, -1 = none; their rows are already in the image); round: d_stats (device, 2 x int64) =
+ * {strands of this rank not done yet, requests filed}; finish: results as after ldbg_engine_walk_batch_run. */
+ldbg_status ldbg_engine_sharded_walk_begin(struct ldbg_engine* e, ldbg_image* im, const char* seeds, int64_t n, const int32_t* d_seed_slot, void* stream);
+ldbg_status ldbg_engine_sharded_walk_round(struct ldbg_engine* e, int64_t* d_stats);
+ldbg_status ldbg_engine_sharded_walk_finish(struct ldbg_engine* e, int64_t* total_contig_bytes, int64_t* kmers_traversed);
 
 /* ------------------------------------------------------------------ links: L3-L4
  * new CortexLinks(path) -> CortexLinksMap        J/utils/io/graph/links/CortexLinks.java:16-25,

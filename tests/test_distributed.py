@@ -113,7 +113,8 @@ def test_pack_kmers_matches_library(orc):
         w = pack_kmers(a, k)
         for i, s in enumerate(ks):
             assert [int(x) for x in w[i]] == orc.encode_kmer(s)
-    assert (pack_kmers(np.frombuffer(b"ACNGT", dtype=np.uint8).reshape(1, 5), 5) == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    w, valid = pack_kmers(np.frombuffer(b"ACNGTACGTT", dtype=np.uint8).reshape(2, 5), 5, return_valid=True)
+    assert list(valid) == [False, True] and int(w[0][0]) == 0                   # validity travels beside the words (Q4)
 
 
 @pytest.mark.timeout(300)
@@ -148,53 +149,83 @@ def test_replicas_two_ranks(orc, tmp_path):
     _spawn(_replica_worker, (cs.path, str(tmp_path / "rep.a.ctp.gz"), seeds, expected))
 
 
-def _sharded_walk_worker(rank, world, port, path, seeds, cfgs, expected):
+def _sharded_walk_worker(rank, world, port, path, link_path, seeds, cfgs, expected):
     dist = _init(rank, world, port)
     try:
+        from corticall_amd import CortexLinks
         from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine, gather_strings, partition
         from tests import hostsim
         lib = hostsim.load(rebuild=False)
         sg = ShardedCortexGraph(path, lib=lib, chunk_records=700)
         sg.build_neighbour_index(chunk_records=300)
+        links = CortexLinks(link_path, sg.shard, lib=lib) if link_path else None      # every rank: the link file against its own shard
         first, cnt = partition(len(seeds), rank, world)
-        for ci, (trav, direction, op, max_len) in enumerate(cfgs):
-            e = ShardedTraversalEngine(sg, trav, direction=direction, op=op, max_branch_length=max_len)
-            mine = e.walk_batch(seeds[first:first + cnt])
-            got = gather_strings(mine)
-            for i, s in enumerate(seeds):
-                assert got[i] == expected[ci][0][i], (cfgs[ci], s, got[i], expected[ci][0][i])
-            import torch
-            t = torch.tensor([e.kmers_traversed])
-            dist.all_reduce(t)
-            assert int(t.item()) == expected[ci][1], (int(t.item()), expected[ci][1])
-            assert e.exchanges > 0
+        for ci, (trav, direction, op, max_len, with_links) in enumerate(cfgs):
+            e = ShardedTraversalEngine(sg, trav, links=[links] if (with_links and links) else (), direction=direction, op=op,
+                                       max_branch_length=max_len, rows_per_owner=64 if ci % 2 else 4096, check_every=4)
+            for rep in range(2):                                # the second batch starts from an empty image again
+                mine = e.walk_batch(seeds[first:first + cnt])
+                got = gather_strings(mine)
+                for i, s in enumerate(seeds):
+                    assert got[i] == expected[ci][0][i], (cfgs[ci], s, got[i], expected[ci][0][i])
+                import torch
+                t = torch.tensor([e.kmers_traversed])
+                dist.all_reduce(t)
+                assert int(t.item()) == expected[ci][1], (int(t.item()), expected[ci][1])
+                assert e.rounds > 0
             e.close()
         sg.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("k", [21, 47])
-def test_sharded_walks_two_ranks(orc, tmp_path, k):
-    """ContigStopper walks over a table hash-sharded over two ranks (one row exchange per step) == the oracle's walks
-    on the whole graph: contigs and the number of k-mers traversed"""
+def _sharded_walk_case(orc, tmp_path, k, with_links, world=2):
     from tests import parity_cases as pc
-    rng = random.Random(100 + k)
+    rng = random.Random(100 + k + (7 if with_links else 0))
     base = pc.genome_with_repeats(rng, 900, n_rep=5, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
     kid = pc.mutate(rng, base, snv=0.01, indel=0.003)
     dad = pc.mutate(rng, base, snv=0.02, indel=0.003)
     path = str(tmp_path / "sw.ctx")
     orc.build_graph(path, [("kid", [kid]), ("mom", [base]), ("dad", [dad])], k)
     og = orc.Graph(path, tuned=True)
+    link_path, ol = None, None
+    if with_links:
+        rl = max(3 * k, 60)
+        reads = [kid[i:i + rl] for i in range(0, max(1, len(kid) - rl + 1), max(1, rl // 4))] + [kid[-rl:]]
+        link_path = str(tmp_path / "sw.kid.ctp.gz")
+        orc.build_links(og, link_path, "kid", reads)
+        ol = orc.Links(link_path)
     kmers = [og.record_string(i).split()[0] for i in range(og.N)]
     seeds = rng.sample(kmers, 60)
     seeds = [s if rng.random() < 0.5 else orc.revcomp(s) for s in seeds] + [pc.rand_seq(rng, k), "N" * k, kid[:k], kid[-k:]]
-    cfgs = [([0], 0, 0, 75000), ([0], 1, 1, 75000), ([1], 2, 0, 75000), ([0, 2], 0, 0, 75000), ([0], 0, 0, 9)]
+    ML = 400 if with_links else 75000       # (a link-guided walk circles a tandem repeat until maxLength)
+    cfgs = [([0], 0, 0, ML, with_links), ([0], 1, 1, ML, with_links), ([1], 2, 0, ML, with_links), ([0, 2], 0, 0, ML, with_links), ([0], 0, 0, 9, with_links),
+            ([0], 0, 0, ML, False)]
     expected = []
-    for trav, direction, op, max_len in cfgs:
-        oe = orc.Engine(og, trav, op_and=(op == 1), direction=direction, max_length=max_len, stopper="ContigStopper")
+    for trav, direction, op, max_len, wl in cfgs:
+        oe = orc.Engine(og, trav, links=[ol] if (wl and ol) else [], op_and=(op == 1), direction=direction, max_length=max_len, stopper="ContigStopper")
         it0 = oe.kmers_traversed()
         contigs = [oe.walk(s)[0] for s in seeds]
         expected.append((contigs, oe.kmers_traversed() - it0))
-    _spawn(_sharded_walk_worker, (path, seeds, cfgs, expected))
+    _spawn(_sharded_walk_worker, (path, link_path, seeds, cfgs, expected), world=world)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("k", [21, 32, 47])
+def test_sharded_walks_two_ranks(orc, tmp_path, k):
+    """ContigStopper walks over a table hash-sharded over two ranks == the oracle's walks on the whole graph: contigs and the
+    number of k-mers traversed (odd and even k: palindromic k-mers, all-bits k-mers)"""
+    _sharded_walk_case(orc, tmp_path, k, with_links=False)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("k", [21, 47, 64])
+def test_sharded_link_walks_two_ranks(orc, tmp_path, k):
+    """link-guided walks (TraversalEngine.java:241-279, 548-597: link store, junction choices, copies of revisited vertices, the
+    walk that circles a repeat until maxLength) over the sharded table, rows fetched from the owning rank on demand"""
+    _sharded_walk_case(orc, tmp_path, k, with_links=True)
+
+
+@pytest.mark.timeout(900)
+def test_sharded_link_walks_three_ranks(orc, tmp_path):
+    _sharded_walk_case(orc, tmp_path, 31, with_links=True, world=3)
