@@ -200,18 +200,22 @@ def bench_c2(args, ca, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
-def bench_c5s(args, ca, prefix, seeds, rank, local_rank, world, dist):
-    """configs[4]'s path at a size that fits this image: the same 3-colour k=47 table HASH-SHARDED over the ranks,
-    ContigStopper walks without link annotations (links are not routed yet), one row exchange per traversed k-mer
-    (corticall_amd/distributed.py::ShardedTraversalEngine)."""
+def bench_c3_sharded(args, ca, prefix, st, seeds, rank, local_rank, world, dist):
+    """configs[2]'s workload (and configs[4]'s path) over the HASH-SHARDED table: link-guided ContigStopper walks; every rank holds
+    1/world of the records, keeps a local image of the rows it is sent and runs the walk kernel on it
+    (corticall_amd/distributed.py::ShardedTraversalEngine, csrc/image.h).  The image starts empty in every step."""
     import numpy as np
     import torch
+    from corticall_amd import CortexLinks
     from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine
     t0 = time.time()
     sg = ShardedCortexGraph(prefix + ".ctx", device=local_rank)
+    t_shard = time.time() - t0
     sg.build_neighbour_index()
     t_load = time.time() - t0
-    eng = ShardedTraversalEngine(sg, [0], max_branch_length=args.max_len)
+    links = [] if args.no_links else [CortexLinks(prefix + ".ctp.gz", sg.shard)]
+    eng = ShardedTraversalEngine(sg, [0], links=links, max_branch_length=args.max_len, rows_per_owner=args.rows_per_owner,
+                                 check_every=args.check_every)
     mine = [s.tobytes().decode() for s in seeds[:args.sharded_seeds]]
 
     def sync():
@@ -220,52 +224,56 @@ def bench_c5s(args, ca, prefix, seeds, rank, local_rank, world, dist):
 
     for _ in range(args.warmup):
         eng.walk_batch(mine)
-    ca.profile_reset()
-    eng.exchanges = 0
     sync()
     t1 = time.time()
-    traversed = 0
+    traversed = rounds = 0
     for _ in range(args.steps):
         contigs = eng.walk_batch(mine)
         traversed += eng.kmers_traversed
+        rounds += eng.rounds
     sync()
     dt = time.time() - t1
-    step_ms, launches = ca.profile_get("bsp_step")
     t = torch.tensor([float(traversed), float(len(mine) * args.steps)], dtype=torch.float64, device="cuda")
     dist.all_reduce(t)
     m = torch.tensor([dt], dtype=torch.float64, device="cuda")
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     if rank == 0:
         N, W, C = sg.getNumRecords(), sg.W, sg.C
+        M = max(2, links[0].numKmersWithLinks) if links else 2
         b_find = math.ceil(math.log2(N)) * 8 * W + 5 * C
+        b_link = math.ceil(math.log2(M)) * 8 * W if links else 0
+        per_round_ms = m[0].item() / max(1, rounds) * 1e3
+        achieved = t[0].item() * (b_find + b_link) / m[0].item() / 1e9 / max(1, world)
         out = {
             "metric": "k-mers traversed/sec (whole node) + contigs/sec, k=47 3-color LdBG", "value": t[0].item() / m[0].item(),
             "unit": "k-mers traversed/s", "contigs_per_s": t[1].item() / m[0].item(), "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": m[0].item() / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[4]'s path on the %.1f Mb 3-colour k=%d table hash-sharded over %d rank(s): ContigStopper walks "
-                                   "WITHOUT links from %d seeds per GPU, one row exchange (2 all-to-alls) per traversed k-mer"
-                                   % (args.genome_len / 1e6, args.k, world, len(mine)),
-                       "records": N, "row_bytes": sg.row_bytes, "exchanges_per_step": eng.exchanges // max(1, args.steps),
-                       "kmers_traversed_per_step": traversed // max(1, args.steps), "load_seconds_incl_neighbour_index": round(t_load, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_bsp_step", "achieved": (traversed / max(1, launches)) * b_find / (max(1e-9, step_ms / max(1, launches)) * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "algorithmic_bytes_per_kmer": b_find,
-                         "avg_launch_ms": step_ms / max(1, launches), "launches": launches,
-                         "note": "the exchanges, not this kernel, bound the sharded path: see ms_per_step / exchanges_per_step"},
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic", "library": ca.default_lib().dll.ldbg_version().decode(),
+            "config": {"workload": "configs[2] over the HASH-SHARDED table (configs[4]'s path): synthetic %.1f Mb 3-colour k=%d LdBG%s, table split over %d rank(s) by "
+                                   "mix64(canonical k-mer), link-guided ContigStopper walks BOTH/OR from %d seeds per GPU, maxLength %d; rows fetched from their "
+                                   "owners on demand into a local image (empty at the start of every step), RCCL all-to-all per bulk-synchronous round"
+                                   % (args.genome_len / 1e6, args.k, "" if args.no_links else " with child links (replicated on every rank)", world, len(mine), args.max_len),
+                       "records": N, "records_per_rank": N // max(1, world), "rounds_per_step": rounds // max(1, args.steps), "ms_per_round": per_round_ms,
+                       "rows_per_owner_and_round": args.rows_per_owner, "image_rows_used": eng.image_rows_used,
+                       "kmers_traversed_per_step": traversed // max(1, args.steps), "multi_gpu": "hash-sharded table, rows exchanged, walks stay on the rank of their seed",
+                       "load_seconds": round(t_load, 2), "shard_cut_seconds": round(t_shard, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_walk<%d> on the image, one launch per round" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_kmer": b_find + b_link,
+                         "note": "per GPU; the bulk-synchronous rounds (launch + two all-to-alls each), not HBM, bound this regime: see ms_per_round"},
         }
-        out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
         if not args.no_cpu_baseline:
             from oracle import pyoracle as orc
             og = orc.Graph(prefix + ".ctx", use_cache=True, tuned=False)
-            oe = orc.Engine(og, [0], stopper="ContigStopper", max_length=args.max_len)
+            oe = orc.Engine(og, [0], links=[] if args.no_links else [orc.Links(prefix + ".ctp.gz")], stopper="ContigStopper", max_length=args.max_len)
+            pick = np.random.default_rng(20261004).permutation(len(mine))
             t2 = time.time()
             i = mism = 0
             while i < len(mine) and time.time() - t2 < args.cpu_seconds:
-                mism += 0 if oe.walk(mine[i])[0] == contigs[i] else 1
+                mism += 0 if oe.walk(mine[pick[i]])[0] == contigs[pick[i]] else 1
                 i += 1
             dtc = time.time() - t2
             out["cpu_baseline"] = {"value": oe.kmers_traversed() / dtc, "unit": "k-mers traversed/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d seeds (%d k-mers traversed in %.1f s), oracle in faithful mode" % (i, oe.kmers_traversed(), dtc)}
+                                   "sample": "%d seeds drawn at random from rank 0's (%d k-mers traversed in %.1f s), oracle in faithful mode" % (i, oe.kmers_traversed(), dtc)}
             out["parity"] = "%d/%d sampled contigs bit-exact vs oracle" % (i - mism, i)
         print(json.dumps(out))
     dist.barrier()
@@ -381,9 +389,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lookups", type=int, default=100000, help="c2: lookups per step (configs[1] says 100k)")
-    ap.add_argument("--sharded", action="store_true", help="c2: hash-shard the table over the ranks and route lookups with all-to-all")
-    ap.add_argument("--sharded-seeds", type=int, default=2048, help="c5s: seeds per GPU and step")
-    ap.add_argument("--workload", choices=["c3", "c4", "c2", "c5s"], default="c3",
+    ap.add_argument("--sharded", action="store_true", help="hash-shard the table over the ranks: c2 routes lookups with all-to-all, c3 walks over local images of the table")
+    ap.add_argument("--sharded-seeds", type=int, default=8192, help="--sharded: seeds per GPU and step")
+    ap.add_argument("--rows-per-owner", type=int, default=8192, help="--sharded: rows one rank may ask of one owner per round")
+    ap.add_argument("--check-every", type=int, default=16, help="--sharded: rounds between two looks at the 'anyone still walking' count")
+    ap.add_argument("--workload", choices=["c3", "c4", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
     ap.add_argument("--use-seeds", type=int, default=0, help="experiment: walk only the first N seeds")
     ap.add_argument("--no-links", action="store_true", help="experiment: walk without the link annotations")
@@ -396,7 +406,7 @@ def main():
     import numpy as np
     import torch
     dist = None
-    if world > 1 or args.sharded or args.workload == "c5s" or os.environ.get("LDBG_FORCE_DIST"):      # LDBG_FORCE_DIST: rehearse the N > 1 code path on one GPU
+    if world > 1 or args.sharded or os.environ.get("LDBG_FORCE_DIST"):      # LDBG_FORCE_DIST: rehearse the N > 1 code path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -425,8 +435,8 @@ def main():
     if args.use_seeds:
         seeds = seeds[np.random.default_rng(7).permutation(len(seeds))[:args.use_seeds]]
 
-    if args.workload == "c5s":
-        return bench_c5s(args, ca, prefix, seeds, rank, local_rank, world, dist)
+    if args.workload == "c3" and args.sharded:
+        return bench_c3_sharded(args, ca, prefix, st, seeds, rank, local_rank, world, dist)
 
     t_load = time.time()
     g = CortexGraph(prefix + ".ctx", device=local_rank)

@@ -231,7 +231,15 @@ ldbg_status ldbg_engine_sharded_walk_begin(ldbg_engine* e, ldbg_image* im, const
 }
 ldbg_status ldbg_engine_sharded_walk_round(ldbg_engine* e, int64_t* d_stats) { return guard([&] { e->e.sharded_walk_round(d_stats); }); }
 ldbg_status ldbg_engine_sharded_walk_finish(ldbg_engine* e, int64_t* total_bytes, int64_t* traversed) {
-    return guard([&] { e->e.sharded_walk_finish(total_bytes, traversed); });
+    return guard([&] {
+        try { e->e.sharded_walk_finish(total_bytes, traversed); }
+        catch (const StatusError& se) {
+            // a full per-walk link store: the next batch of this engine gets a larger one (the caller walks the batch again — exactness
+            // is never traded away; ldbg_engine_walk_batch_run does the same retry inside the call)
+            if (se.status == LDBG_ERR_CAPACITY && std::string(se.what()) == "LINKSTORE_FULL") e->e.link_store_capacity *= 4;
+            throw;
+        }
+    });
 }
 
 ldbg_status ldbg_graph_find(const ldbg_graph* g, const uint64_t* packed, int64_t n, int64_t* idx_out, uint32_t* cov_out, uint8_t* edges_out) {

@@ -285,10 +285,12 @@ class ShardedTraversalEngine:
         self._rows_out = torch.zeros((w, cap_o, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
         self._rows_in = torch.zeros((w, cap_o, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
         self._stats = torch.zeros(2, dtype=torch.int64, device=sgraph.device)
+        self._tstream = torch.cuda.Stream(device=sgraph.device) if sgraph.device.type == "cuda" else None
 
     def _stream(self):
-        t = self.g._torch
-        return C.c_void_p(t.cuda.current_stream(self.g.device).cuda_stream) if self.g.device.type == "cuda" else None
+        """the HIP stream every call of a round is queued on: the engine's own torch stream (a real stream handle — torch's default
+        stream has handle 0, which the C ABI reads as "the library's stream", and nothing would order the kernels with the collectives)"""
+        return C.c_void_p(self._tstream.cuda_stream) if self._tstream is not None else None
 
     def _exchange(self, stream):
         """requests of this round -> rows in the image: bucket, all-to-all, serve, all-to-all, insert — all on one stream"""
@@ -308,6 +310,30 @@ class ShardedTraversalEngine:
 
     def walk_batch(self, seeds):
         """contigs of this rank's seeds (list of str); collective: every rank calls it (possibly with no seeds)"""
+        torch, dist = self.g._torch, self.g._dist
+        for attempt in range(6):
+            again = 0
+            try:
+                out = self._walk_batch_once(seeds)
+            except _native.LdbgError as ex:
+                if "LINKSTORE_FULL" not in str(ex) or attempt == 5:
+                    raise
+                again = 1                       # the library has enlarged this engine's link stores: every rank walks the batch again
+            t = torch.tensor([again], dtype=torch.int64, device=self.g.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.g._group)
+            if int(t.item()) == 0:
+                return out
+
+    def _walk_batch_once(self, seeds):
+        if self._tstream is None:
+            return self._walk_batch_on_stream(seeds)
+        self._tstream.wait_stream(self.g._torch.cuda.current_stream(self.g.device))
+        with self.g._torch.cuda.stream(self._tstream):          # collectives issued here are ordered with this stream too
+            out = self._walk_batch_on_stream(seeds)
+        self._tstream.synchronize()
+        return out
+
+    def _walk_batch_on_stream(self, seeds):
         g, torch, dist = self.g, self.g._torch, self.g._dist
         lib, d = self._lib, self._d
         P = lambda t: C.c_void_p(t.data_ptr())

@@ -113,36 +113,46 @@ def test_sharded_find_one_rank_rccl(orc, lib, tmp_path):
         dist.destroy_process_group()
 
 
-def test_sharded_walks_one_rank_rccl(orc, lib, tmp_path):
-    """the bulk-synchronous walker over a sharded table with device buffers and RCCL collectives (one rank here; two
-    ranks on gloo in tests/test_distributed.py)"""
+@pytest.mark.parametrize("k,with_links", [(47, False), (47, True), (32, True), (63, True)])
+def test_sharded_walks_one_rank_rccl(orc, lib, tmp_path, k, with_links):
+    """walks over a sharded table's local image with device buffers and RCCL collectives, every call of a round queued on torch's
+    stream (one rank here; two and three ranks on gloo in tests/test_distributed.py): link-guided and plain, odd and even k"""
     import os
     import random
     import torch.distributed as dist
+    from corticall_amd import CortexLinks
     from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29519")
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
-        rng = random.Random(8)
-        k = 47
+        rng = random.Random(8 + k)
         base = pc.genome_with_repeats(rng, 2500, n_rep=6, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
         kid = pc.mutate(rng, base, snv=0.01, indel=0.003)
         p = str(tmp_path / "sw.ctx")
         orc.build_graph(p, [("kid", [kid]), ("mom", [base])], k)
         og = orc.Graph(p, tuned=True)
+        ol, lp = None, None
+        if with_links:
+            rl = max(3 * k, 60)
+            lp = str(tmp_path / "sw.kid.ctp.gz")
+            orc.build_links(og, lp, "kid", [kid[i:i + rl] for i in range(0, max(1, len(kid) - rl + 1), max(1, rl // 4))] + [kid[-rl:]])
+            ol = orc.Links(lp)
         sg = ShardedCortexGraph(p, lib=lib)
+        links = [CortexLinks(lp, sg.shard, lib=lib)] if with_links else []
         kmers = [og.record_string(i).split()[0] for i in range(og.N)]
         seeds = rng.sample(kmers, 200)
         seeds = [s if rng.random() < 0.5 else orc.revcomp(s) for s in seeds] + [pc.rand_seq(rng, k), "N" * k]
+        ML = 600 if with_links else 75000
         for trav, direction, op in (([0], 0, 0), ([1], 1, 1), ([0, 1], 2, 0)):
-            oe = orc.Engine(og, trav, op_and=(op == 1), direction=direction, stopper="ContigStopper")
+            oe = orc.Engine(og, trav, links=[ol] if ol else [], op_and=(op == 1), direction=direction, stopper="ContigStopper", max_length=ML)
             it0 = oe.kmers_traversed()
             exp = [oe.walk(s)[0] for s in seeds]
-            e = ShardedTraversalEngine(sg, trav, direction=direction, op=op)
+            e = ShardedTraversalEngine(sg, trav, links=links, direction=direction, op=op, max_branch_length=ML, rows_per_owner=256)
             got = e.walk_batch(seeds)
             assert got == exp
             assert e.kmers_traversed == oe.kmers_traversed() - it0
+            assert e.walk_batch(seeds) == exp and e.rounds > 0       # again, from an empty image
             e.close()
         sg.close()
     finally:
