@@ -398,6 +398,29 @@ ldbg_status ldbg_engine_dfs_batch(ldbg_engine* e, const char* sources, int64_t n
         }
     });
 }
+// dfs_batch over the local image of a hash-sharded table: the library runs the bulk-synchronous rounds and calls `round_done` after
+// each (the caller exchanges requests and rows there, and returns non-zero once no rank has a search in progress)
+ldbg_status ldbg_engine_sharded_dfs_batch(ldbg_engine* e, ldbg_image* im, const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets,
+                                          const int32_t* d_seed_slot, const int32_t* d_sink_slot, int (*round_done)(void*), void* user,
+                                          int64_t* d_stats, void* stream, ldbg_dfs_result** out) {
+    return guard([&] {
+        *out = nullptr;
+        if (&im->img.graph() != e->e.graph) throw StatusError(LDBG_ERR_ARG, "the engine was not created on this image's graph");
+        ShardedRun sr{&im->img, d_seed_slot, d_sink_slot, round_done, user, d_stats, (rt::stream_t)stream};
+        try {
+            std::unique_ptr<DfsBatch> b(e->e.dfs_batch(sources, n, sinks, sink_offsets, &sr));
+            b->materialize();                         // the vertices' k-mers and coverages live in the image: read them before it changes
+            *out = new ldbg_dfs_result{std::move(b)};
+        } catch (const StatusError& se) {
+            // capacities grow for the next attempt (the caller runs the batch again on every rank: exactness is never traded away)
+            const std::string what = se.what();
+            if (se.status == LDBG_ERR_CAPACITY && what == "LINKSTORE_FULL") e->e.link_store_capacity *= 4;
+            if (se.status == LDBG_ERR_CAPACITY && what == "LOG_FULL" && e->e.dfs_log_blocks < (1 << 20)) e->e.dfs_log_blocks *= 8;
+            if (se.status == LDBG_ERR_CAPACITY && what == "DEPTH_OVERFLOW" && e->e.dfs_max_depth < 4096) e->e.dfs_max_depth *= 4;
+            throw;
+        }
+    });
+}
 static const DfsGraphHost& dfs_at(const ldbg_dfs_result* r, int64_t i) {
     if (!r || !r->b) throw StatusError(LDBG_ERR_ARG, "no dfs result");
     if (i < 0 || i >= (int64_t)r->b->results.size()) throw StatusError(LDBG_ERR_ARG, "dfs result index out of range");

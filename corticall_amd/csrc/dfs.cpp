@@ -27,6 +27,7 @@
 
 #include "lscoop.h"
 #include "stoppers.h"
+#include "shard.h"
 #include "strand.h"
 
 namespace ldbg {
@@ -57,6 +58,7 @@ struct DfsArgs {
     uint32_t iter_limit;           // loop iterations one seed and direction may take
     int n_trav;
     uint8_t trav_order[LDBG_MAX_COLORS];   // traversal colours in LinkedHashSet order
+    void* lane_save;               // over a sharded table's image (image.h): [n_slots] DfsSave<W>, the search a lane keeps from round to round
 };
 
 template <int W>
@@ -69,6 +71,14 @@ struct DfsLane {
     uint32_t undo_pos, undo_left;
     uint8_t phase;
     bool result, last_prev;
+};
+
+template <int W>
+struct DfsSave {
+    DfsLane<W> L;
+    uint32_t ls_n, ls_java_cap, ls_nkeys, ls_next_seq, ls_age, ls_n_new;
+    uint8_t ls_overflow, active, begun, pad;
+    LsElem fast[LDBG_LS_FAST];
 };
 
 // ---- Java iteration order of the neighbour vertices (TraversalEngine.getNextVertices/getPrevVertices :147-239):
@@ -376,8 +386,11 @@ LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64
 #pragma unroll
     for (int i = 0; i < W; i++) sk.w[i] = sw[i];
     Node v;
-    if (a.w.seed_valid[s >> 1]) { node_find<W>(e, sk, v); node_locate(st.vt, v); }
-    else node_null(e, v);
+    if (a.w.seed_valid[s >> 1]) {
+        if (a.w.img_on) seed_node<W>(e, sk, a.w.seed_slot[s >> 1], v);       // (the routed findRecord of the source was done before the first round)
+        else node_find<W>(e, sk, v);
+        node_locate(st.vt, v);
+    } else node_null(e, v);
     if (v.npe) { st.status = ST_NULLPTR; return false; }
     open_branch<W>(a, L, ls, v, sk, 0);
     return st.status == ST_OK;
@@ -408,7 +421,21 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
     L.st.vt.tab = nullptr; L.st.vt.mask = 0; L.st.vt.used = 0; L.st.status = ST_OK;
     L.phase = PH_ITER;
     bool active = false, exhausted = false;
-    while (wave_ballot(active || !exhausted) != 0ull) {
+    // over an image (image.h): a search that needs a row that has not been sent yet suspends for the rest of this launch; the one a
+    // lane was working on when the previous round ended is taken up again
+    bool suspended = false, begun = true;
+    DfsSave<W>* save = (DfsSave<W>*)a.lane_save;
+    if (save) {
+        const DfsSave<W>& sv = save[slot];
+        if (sv.active) {
+            L = sv.L;
+            ls.n = sv.ls_n; ls.java_cap = sv.ls_java_cap; ls.nkeys = sv.ls_nkeys; ls.next_seq = sv.ls_next_seq; ls.age = sv.ls_age; ls.n_new = sv.ls_n_new;
+            ls.overflow = sv.ls_overflow != 0;
+            for (uint32_t i = 0; i < LDBG_LS_FAST && i < sv.ls_n; i++) ls_set(ls, i, sv.fast[i]);
+            active = true; begun = sv.begun != 0;
+        }
+    }
+    while (wave_ballot((active && !suspended) || (!active && !exhausted)) != 0ull) {
         if (!active && !exhausted) {
             const int64_t fi = (int64_t)atomic_add_u64(a.w.next_strand, 1ull);
             if (fi >= a.w.n_strands) exhausted = true;
@@ -417,19 +444,100 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
                 const bool fwd = (s & 1) != 0;
                 if ((fwd && !a.w.run_fwd) || (!fwd && !a.w.run_rev)) {
                     a.w.strand_n[s] = 0; a.w.status[s] = ST_BRANCH_NULL; a.w.iters[s] = 0; a.w.quirk[s] = 0;
+                } else if (a.w.img_on) {
+                    L.st.s = s; L.st.fwd = fwd; active = true; begun = false;
                 } else {
                     active = dfs_begin<W>(a, L, ls, s);
                     if (!active) strand_finish(a.w, L.st);
                 }
             }
         }
-        wave_grow_tables(a.w, L.st, active);
-        const bool lean = active && L.phase == PH_ITER && lean_cursor_ok(a.w.e, L.st);
-        const bool cur_mode = active && !lean && L.st.status == ST_OK && L.phase == PH_ITER && a.w.e.cursor_on && L.st.cu.has;
+        if (a.w.img_on && active && !suspended) {
+            StrandState& st = L.st;
+            if (!begun) {
+                const int32_t sl = a.w.seed_valid[st.s >> 1] ? a.w.seed_slot[st.s >> 1] : -1;
+                bool ready = true;
+                if (sl >= 0) {
+                    Kmer<W> sk;
+                    const uint64_t* sw = a.w.seeds + (st.s >> 1) * W;
+#pragma unroll
+                    for (int i = 0; i < W; i++) sk.w[i] = sw[i];
+                    Node sn;
+                    seed_node<W>(a.w.e, sk, sl, sn);
+                    ready = rows_ready(a.w.img, sn, st.fwd);
+                }
+                if (!ready) suspended = true;
+                else {
+                    begun = true;
+                    active = dfs_begin<W>(a, L, ls, st.s);
+                    if (!active) strand_finish(a.w, L.st);
+                }
+            }
+            if (active && begun && !suspended && st.status == ST_OK) {
+                bool ready = true;
+                if (L.phase == PH_ITER) {
+                    // the iteration materialises the neighbours of cv in the direction of travel (:374-377, children order :441) and, with
+                    // the cursor, those of the vertex the cursor is about to step onto (:379-407)
+                    ready = rows_ready(a.w.img, st.cv, st.fwd);
+                    if (a.w.e.cursor_on && st.cu.has) ready = rows_ready(a.w.img, st.cu.nxt, st.fwd) && ready;
+                } else if (L.phase == PH_CHILD) {
+                    // the next child's branch opens with seek(child) (:363-365): the child's own neighbours are looked at
+                    DfsFrame& F = a.frames[(size_t)slot * a.max_depth + L.depth];
+                    if (F.next < F.nchild) {
+                        Node av;
+                        node_child(a.w.e, F.cv, st.fwd, F.child[F.next], av);
+                        ready = rows_ready(a.w.img, av, st.fwd);
+                    }
+                }
+                if (!ready) suspended = true;
+            }
+        }
+        const bool running = active && begun && !suspended;
+        wave_grow_tables(a.w, L.st, running);
+        const bool lean = running && L.phase == PH_ITER && lean_cursor_ok(a.w.e, L.st);
+        const bool cur_mode = running && !lean && L.st.status == ST_OK && L.phase == PH_ITER && a.w.e.cursor_on && L.st.cu.has;
         StepPre pre;
         pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0; pre.has_child = false;
-        if (wave_ballot(active && !lean) != 0ull) coop_step_prepare<W>(a.w.e, L.st, ls, lw, cur_mode, pre);
-        if (active && dfs_step<W>(a, L, ls, slot, pre, lean)) { strand_finish(a.w, L.st); active = false; }
+        if (wave_ballot(running && !lean) != 0ull) coop_step_prepare<W>(a.w.e, L.st, ls, lw, cur_mode, pre);
+        if (running && dfs_step<W>(a, L, ls, slot, pre, lean)) { strand_finish(a.w, L.st); active = false; }
+    }
+    if (save) {
+        DfsSave<W>& sv = save[slot];
+        sv.active = active ? 1 : 0;
+        if (active) {
+            sv.L = L; sv.begun = begun ? 1 : 0;
+            sv.ls_n = ls.n; sv.ls_java_cap = ls.java_cap; sv.ls_nkeys = ls.nkeys; sv.ls_next_seq = ls.next_seq; sv.ls_age = ls.age; sv.ls_n_new = ls.n_new;
+            sv.ls_overflow = ls.overflow ? 1 : 0;
+            for (uint32_t i = 0; i < LDBG_LS_FAST && i < ls.n; i++) sv.fast[i] = ls_get(ls, i);
+            atomic_add_u64(a.w.unfinished, 1ull);
+        }
+    }
+}
+
+LDBG_KERNEL void k_dfs_round_stats(const unsigned long long* ctr, int64_t ns, const unsigned long long* n_req, int64_t* stats) {
+    if (global_tid() != 0) return;
+    const int64_t handed = (int64_t)ctr[0] < ns ? (int64_t)ctr[0] : ns;
+    stats[0] = (int64_t)ctr[4] + (ns - handed);
+    stats[1] = (int64_t)*n_req;
+}
+
+// sink keys over an image: the sink's record is known by its image slot (-1 = none; -2 = the string is not a k-mer)
+template <int W>
+LDBG_KERNEL void k_sink_nodes_image(EngineView e, const uint64_t* words, const uint8_t* valid, const int32_t* slots, int64_t n, uint64_t* keys) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        uint64_t key = ~0ull;
+        if (valid[i]) {
+            key = 0;
+            Kmer<W> sk;
+            for (int w = 0; w < W; w++) sk.w[w] = words[i * W + w];
+            Node v;
+            seed_node<W>(e, sk, slots[i], v);
+            if (v.idx >= 0) {
+                if (graph_row(e.g, v.idx)[e.g.flags_off] & LDBG_ROW_PALINDROME) v.flip = 0;
+                key = vt_key(v.idx, v.flip != 0);
+            }
+        }
+        keys[i] = key;
     }
 }
 
@@ -680,7 +788,7 @@ void Engine::build_roi_bits() {
     rt::stream_sync(s);
 }
 
-DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets) {
+DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets, const ShardedRun* sharded) {
     if (cfg.connect_all_neighbors) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: connectAllNeighbors is not supported on the device path");
     rt::set_device(graph->device);
     build_roi_bits();
@@ -702,7 +810,8 @@ DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, c
         auto [first, cnt] = todo.back();
         todo.pop_back();
         if (cnt <= 0) continue;
-        if (!dfs_chunk(words, sink_words, sink_offsets, first, cnt, *out)) {
+        if (!dfs_chunk(words, sink_words, sink_offsets, first, cnt, *out, sharded)) {
+            if (sharded) throw StatusError(LDBG_ERR_CAPACITY, "dfs over a sharded table: a device pool ran dry: use smaller batches");
             if (cnt == 1) throw StatusError(LDBG_ERR_HIP, "dfs: pools too small for a single seed: not enough device memory");
             todo.push_back({first + cnt / 2, cnt - cnt / 2});
             todo.push_back({first, cnt / 2});
@@ -714,7 +823,7 @@ DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, c
 
 // returns false when a pool ran dry (the caller splits the chunk)
 bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
-                       int64_t first, int64_t n, DfsBatch& out) {
+                       int64_t first, int64_t n, DfsBatch& out, const ShardedRun* sharded) {
     const int W = graph->hdr.W, C = graph->hdr.C;
     rt::stream_t s = graph->stream;
     const int64_t ns = 2 * n;
@@ -725,7 +834,8 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     const int max_blocks = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(dfs_log_blocks, (((int64_t)cfg.max_branch_length + 2) * 8 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK + 1));
     // the pool follows the walks' table sizes (a chain of branches is rarely longer than a few branches' worth); what it always holds is
     // one seed's two strands at their largest, so that splitting a batch that ran the pool dry ends in chunks that fit
-    ensure_scratch(ns, link_store_capacity, max_blocks, 2 * vt_series(vt_initial_entries(), vcap_max));
+    // (over a sharded table the batch is not split — every rank must stay in step —, so the pool is sized for all of its searches)
+    ensure_scratch(ns, link_store_capacity, max_blocks, (sharded ? (uint64_t)ns : 2ull) * vt_series(vt_initial_entries(), vcap_max));
     zero_dirty_tables(s);
 
     struct Tmp { std::vector<void*> p; ~Tmp() { for (void* x : p) rt::dfree(x); } void* get(size_t nbytes) { void* x = rt::dmalloc(nbytes); p.push_back(x); return x; } } tmp;
@@ -749,6 +859,15 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             rt::h2d(d_sink_words, &sink_words[sink_lo * W], (size_t)nsk * W * 8, s);
             rt::h2d(d_sink_valid, &sink_valid_[sink_lo], (size_t)nsk, s);
             const int g = grid_of(nsk, 256, 1024);
+            if (sharded) {
+                const int32_t* sl = sharded->d_sink_slot + sink_lo;
+                switch (W) {
+                    case 1: LDBG_LAUNCH(k_sink_nodes_image<1>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, sl, nsk, d_sink_keys); break;
+                    case 2: LDBG_LAUNCH(k_sink_nodes_image<2>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, sl, nsk, d_sink_keys); break;
+                    case 3: LDBG_LAUNCH(k_sink_nodes_image<3>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, sl, nsk, d_sink_keys); break;
+                    default: LDBG_LAUNCH(k_sink_nodes_image<4>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, sl, nsk, d_sink_keys); break;
+                }
+            } else
             switch (W) {
                 case 1: LDBG_LAUNCH(k_sink_nodes<1>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, nsk, d_sink_keys); break;
                 case 2: LDBG_LAUNCH(k_sink_nodes<2>, g, 256, s, view, (const uint64_t*)d_sink_words, (const uint8_t*)d_sink_valid, nsk, d_sink_keys); break;
@@ -762,8 +881,8 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     uint32_t* d_status = (uint32_t*)tmp.get((size_t)ns * 4);
     uint32_t* d_iters = (uint32_t*)tmp.get((size_t)ns * 4);
     uint8_t* d_quirk = (uint8_t*)tmp.get((size_t)ns);
-    unsigned long long* d_ctr = (unsigned long long*)tmp.get(32);
-    rt::dmemset(d_ctr, 0, 32, s);
+    unsigned long long* d_ctr = (unsigned long long*)tmp.get(64);
+    rt::dmemset(d_ctr, 0, 64, s);
 
     DfsArgs a;
     memset(&a, 0, sizeof(a));
@@ -791,6 +910,13 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     a.w.vpool = (uint64_t*)d_vpool_; a.w.vpool_entries = vpool_entries_; a.w.vcap_max = vcap_max; a.w.vcap_init = vt_initial_entries();
     a.w.ls = (LsElem*)d_ls_; a.w.ecap = ecap_;
     a.w.strand_c = nullptr; a.w.retry = nullptr; a.w.snap = nullptr;
+    a.w.unfinished = d_ctr + 4;
+    if (sharded) {
+        if (rois) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs over a sharded table: stopping rules that consult a ROI graph are not routed yet");
+        a.w.img_on = 1;
+        a.w.img = sharded->img->view((uint64_t*)view.links.rec_of);
+        a.w.seed_slot = sharded->d_seed_slot + first;
+    }
     a.env.rois = rois ? rois->view : GraphView{};
     if (!rois) a.env.rois.N = -1;
     a.env.roi_bits = (const uint32_t*)d_roi_bits_;
@@ -808,15 +934,37 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     const size_t frame_bytes = (size_t)a.w.n_slots * (size_t)a.max_depth * sizeof(DfsFrame);
     if (frame_bytes > d_frames_bytes_) { rt::dfree(d_frames_); d_frames_ = rt::dmalloc(frame_bytes); d_frames_bytes_ = frame_bytes; }
     a.frames = (DfsFrame*)d_frames_;
+    if (sharded) {
+        const size_t one = W == 1 ? sizeof(DfsSave<1>) : (W == 2 ? sizeof(DfsSave<2>) : (W == 3 ? sizeof(DfsSave<3>) : sizeof(DfsSave<4>)));
+        a.lane_save = tmp.get((size_t)a.w.n_slots * one);
+        rt::dmemset(a.lane_save, 0, (size_t)a.w.n_slots * one, s);
+    }
 
     rt::Event e0, e1;
     e0.record(s);
     const int grid = (int)(a.w.n_slots / 64);
-    switch (W) {
-        case 1: LDBG_LAUNCH(k_dfs<1>, grid, 64, s, a); break;
-        case 2: LDBG_LAUNCH(k_dfs<2>, grid, 64, s, a); break;
-        case 3: LDBG_LAUNCH(k_dfs<3>, grid, 64, s, a); break;
-        default: LDBG_LAUNCH(k_dfs<4>, grid, 64, s, a); break;
+    auto launch = [&](rt::stream_t ls) {
+        switch (W) {
+            case 1: LDBG_LAUNCH(k_dfs<1>, grid, 64, ls, a); break;
+            case 2: LDBG_LAUNCH(k_dfs<2>, grid, 64, ls, a); break;
+            case 3: LDBG_LAUNCH(k_dfs<3>, grid, 64, ls, a); break;
+            default: LDBG_LAUNCH(k_dfs<4>, grid, 64, ls, a); break;
+        }
+    };
+    if (!sharded) launch(s);
+    else {
+        // bulk-synchronous rounds (image.h): every search runs until it needs a row that is not in the image; the caller's callback
+        // carries the requests to their owners and the rows back, and says when no rank has a search left
+        rt::stream_sync(s);
+        rt::stream_t rs = sharded->stream ? sharded->stream : s;
+        for (int64_t round = 0;; round++) {
+            rt::dmemset(d_ctr + 4, 0, 8, rs);
+            sharded->img->reset_requests(rs);
+            launch(rs);
+            LDBG_LAUNCH(k_dfs_round_stats, 1, 64, rs, (const unsigned long long*)d_ctr, ns, (const unsigned long long*)a.w.img.n_req, sharded->d_stats);
+            if (sharded->round_done(sharded->user)) break;
+        }
+        rt::stream_sync(rs);
     }
     e1.record(s);
     std::vector<uint32_t> strand_n(ns), status(ns), iters(ns);
@@ -829,6 +977,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     vpool_dirty_ = ctr[2];
     profile_add("dfs", rt::Event::elapsed_ms(e0, e1));
 
+    if (getenv("LDBG_DEBUG_STATUS")) { fprintf(stderr, "[ldbg] dfs statuses:"); for (int64_t i = 0; i < ns && i < 64; i++) fprintf(stderr, " %u/%u/%u", status[i], strand_n[i], iters[i]); fprintf(stderr, " ctr %llu %llu %llu\n", ctr[0], ctr[1], ctr[2]); }
     for (int64_t i = 0; i < ns; i++) if (status[i] == ST_POOL_FULL) return false;
     // errors the reference raises as exceptions abort the call (first seed in input order)
     for (int64_t i = 0; i < ns; i++) {

@@ -48,6 +48,17 @@ struct DfsBatch {
 
 struct WalkRun;
 class ShardImage;
+// a dfs batch over the local image of a hash-sharded table (image.h): the library runs the rounds, the caller's callback makes the
+// exchange of every round (requests out, rows in) and returns non-zero once no rank has a search in progress
+struct ShardedRun {
+    ShardImage* img;
+    const int32_t* d_seed_slot;    // [n] image slot of every source's record (-1 = none): the rows are in the image already
+    const int32_t* d_sink_slot;    // [number of sinks] likewise
+    int (*round_done)(void* user);
+    void* user;
+    int64_t* d_stats;              // device, 2 x int64: searches of this rank not done yet, requests filed in the round
+    rt::stream_t stream;           // the stream the rounds are queued on (the callback's collectives use it too)
+};
 uint64_t vt_series(uint64_t init, uint64_t vmax);     // walk.cpp
 uint32_t vt_initial_entries();
 
@@ -73,7 +84,7 @@ public:
     void sharded_walk_finish(int64_t* total_contig_bytes, int64_t* kmers_traversed);
     void sharded_abort();
     // dfs(source, sinks...) for n sources; sinks as CSR over ASCII k-mers (sink_offsets may be nullptr)
-    DfsBatch* dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets);
+    DfsBatch* dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets, const ShardedRun* sharded = nullptr);
     int dfs_max_depth = 64;
     int dfs_log_blocks = 64;          // path blocks (1024 entries) one strand's dfs log may use
     int64_t dfs_traversed() const { return dfs_traversed_; }
@@ -102,7 +113,7 @@ private:
     std::vector<uint8_t> seed_valid_;          // per seed of the current walk batch: is the string a k-mer over ACGT (Q4)              // strands the run steps handed back to the k-mer-by-k-mer code (diagnostics)
     void build_roi_bits();
     bool dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
-                   int64_t first, int64_t n, DfsBatch& out);
+                   int64_t first, int64_t n, DfsBatch& out, const ShardedRun* sharded);
     void launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks);
     void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks, uint64_t table_floor = 0);   // table_floor: entries the table pool holds at least
     uint64_t table_floor_ = 0;

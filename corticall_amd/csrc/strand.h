@@ -130,7 +130,12 @@ LDBG_DEV void path_truncate(const WalkArgs& a, int64_t s, PathWriter& pw, uint32
 // carve a zeroed table of `cap` entries out of the pool
 LDBG_DEV bool vt_alloc(const WalkArgs& a, VisitedTable& vt, uint32_t cap) {
     const uint64_t o = (uint64_t)atomic_add_u64(a.vnext, (unsigned long long)cap);
-    if (o + cap > a.vpool_entries) return false;
+    if (o + cap > a.vpool_entries) {
+#ifdef LDBG_HOSTSIM
+        if (getenv("LDBG_DEBUG_STATUS")) fprintf(stderr, "[ldbg] vt_alloc fails: o %llu cap %u pool %llu\n", (unsigned long long)o, cap, (unsigned long long)a.vpool_entries);
+#endif
+        return false;
+    }
     vt.tab = a.vpool + o;
     vt.mask = cap - 1;
     vt.used = 0;

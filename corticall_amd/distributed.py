@@ -249,8 +249,8 @@ class ShardedTraversalEngine:
     walk kernel on its local image of the table (csrc/image.h); rows travel, walks do not.
     links: CortexLinks objects opened on `sgraph.shard` (each rank opens the link file against its own shard)."""
 
-    def __init__(self, sgraph, traversal_colors, links=(), recruitment_colors=(), direction=0, op=0, max_branch_length=75000,
-                 image_rows=None, rows_per_owner=4096, check_every=8, keep_image=False):
+    def __init__(self, sgraph, traversal_colors, links=(), recruitment_colors=(), joining_colors=(), direction=0, op=0, max_branch_length=75000,
+                 stopping_rule=None, image_rows=None, rows_per_owner=4096, check_every=8, keep_image=False):
         from .traversal import ContigStopper, TraversalEngineFactory
         self.g = sgraph
         if not sgraph.has_neighbour_index:
@@ -266,10 +266,12 @@ class ShardedTraversalEngine:
         rb = C.c_int()
         lib.check(d.ldbg_image_row_bytes(self._img, C.byref(rb)))
         self.row_bytes = rb.value
-        f = (TraversalEngineFactory(lib=lib).traversalColors(*traversal_colors).graph(self.image_graph).stoppingRule(ContigStopper)
+        f = (TraversalEngineFactory(lib=lib).traversalColors(*traversal_colors).graph(self.image_graph).stoppingRule(stopping_rule or ContigStopper)
              .traversalDirection(direction).combinationOperator(op).maxBranchLength(max_branch_length))
         if recruitment_colors:
             f.recruitmentColors(*recruitment_colors)
+        if joining_colors:
+            f.joiningColors(*joining_colors)
         if links:
             f.links(*links)
         self.engine = f.make()
@@ -333,24 +335,19 @@ class ShardedTraversalEngine:
         self._tstream.synchronize()
         return out
 
-    def _walk_batch_on_stream(self, seeds):
-        g, torch, dist = self.g, self.g._torch, self.g._dist
+    def _resolve(self, kmers_ascii, stream):
+        """routed findRecord of this rank's k-mers (ASCII u8[n,k]) and their rows into the image -> image slots int32[n] on the device
+        (-1 = no record).  Collective."""
+        g, torch = self.g, self.g._torch
         lib, d = self._lib, self._d
         P = lambda t: C.c_void_p(t.data_ptr())
-        k = g.k
-        seeds = [x if isinstance(x, str) else bytes(x).decode() for x in seeds]
-        n = len(seeds)
-        ascii_ = np.frombuffer("".join(seeds).encode(), dtype=np.uint8).reshape(n, k) if n else np.zeros((0, k), dtype=np.uint8)
-        words, valid = pack_kmers(ascii_, k, return_valid=True)
+        n = kmers_ascii.shape[0]
+        words, valid = pack_kmers(kmers_ascii, g.k, return_valid=True)
         q = torch.from_numpy(words.view(np.int64)).to(g.device)
         found, _, _, owner, lidx = g.find_packed_dev(q, valid=torch.from_numpy(valid).to(g.device))
         keys = torch.where(found, (lidx + 1) | (owner.to(torch.int64) << 40), torch.zeros_like(lidx)).contiguous()
-        stream = self._stream()
-        if not self.keep_image:
-            lib.check(d.ldbg_image_clear(self._img))
-        # the seeds' own rows first: explicit requests, as many rounds as the per-owner blocks need
         slots = torch.full((max(1, n),), -1, dtype=torch.int32, device=g.device)[:n]
-        while True:
+        while True:          # explicit requests, as many rounds as the per-owner blocks need
             missing = keys[(slots < 0) & (keys != 0)].contiguous() if n else keys
             if self._all_done(torch.tensor(int(missing.shape[0]), dtype=torch.int64, device=g.device)):
                 break
@@ -359,6 +356,24 @@ class ShardedTraversalEngine:
             lib.check(d.ldbg_image_reset_requests(self._img, stream))
             if n:
                 lib.check(d.ldbg_image_lookup(self._img, P(keys), C.c_int64(n), P(slots), stream))
+        return slots
+
+    @staticmethod
+    def _ascii(kmers, k):
+        kmers = [x if isinstance(x, str) else bytes(x).decode() for x in kmers]
+        n = len(kmers)
+        return kmers, (np.frombuffer("".join(kmers).encode(), dtype=np.uint8).reshape(n, k) if n else np.zeros((0, k), dtype=np.uint8))
+
+    def _walk_batch_on_stream(self, seeds):
+        g, torch, dist = self.g, self.g._torch, self.g._dist
+        lib, d = self._lib, self._d
+        P = lambda t: C.c_void_p(t.data_ptr())
+        seeds, ascii_ = self._ascii(seeds, g.k)
+        n = len(seeds)
+        stream = self._stream()
+        if not self.keep_image:
+            lib.check(d.ldbg_image_clear(self._img))
+        slots = self._resolve(ascii_, stream)
         seed_buf = np.ascontiguousarray(ascii_).reshape(-1)
         lib.check(d.ldbg_engine_sharded_walk_begin(self.engine._h, self._img, seed_buf.ctypes.data_as(C.c_char_p), C.c_int64(n), P(slots), stream))
         rounds, gap = 0, 1
@@ -387,6 +402,83 @@ class ShardedTraversalEngine:
         raw = arena.tobytes()
         self.walk_lengths = wl[:n]
         return [raw[offs[i]:offs[i + 1]].decode() for i in range(n)]
+
+    def dfs_batch(self, sources, sinks=None):
+        """TraversalEngine.dfs(source, sinks...) for this rank's sources (the engine's stopping rule); sinks: per source a list of
+        k-mers.  -> list of DfsGraph / None (a vertex's record index is its image slot: >= 0 means "has a record").  Collective."""
+        from .traversal import _DfsBatch
+        torch, dist = self.g._torch, self.g._dist
+        for attempt in range(8):
+            again, out = 0, None
+            try:
+                out = self._dfs_batch_once(sources, sinks)
+            except _native.LdbgError as ex:
+                if not any(w in str(ex) for w in ("LINKSTORE_FULL", "LOG_FULL", "DEPTH_OVERFLOW")) or attempt == 7:
+                    raise
+                again = 1
+            t = torch.tensor([again], dtype=torch.int64, device=self.g.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.g._group)
+            if int(t.item()) == 0:
+                return out
+
+    def _dfs_batch_once(self, sources, sinks):
+        from .traversal import _DfsBatch
+        g, torch = self.g, self.g._torch
+        lib, d = self._lib, self._d
+        P = lambda t: C.c_void_p(t.data_ptr())
+        ctx = torch.cuda.stream(self._tstream) if self._tstream is not None else None
+        if ctx is not None:
+            self._tstream.wait_stream(torch.cuda.current_stream(g.device))
+            ctx.__enter__()
+        try:
+            sources, src_ascii = self._ascii(sources, g.k)
+            n = len(sources)
+            sinks = sinks if sinks is not None else [[] for _ in sources]
+            flat, sink_ascii = self._ascii([x for ss in sinks for x in ss], g.k)
+            off = np.zeros(n + 1, dtype=np.int64)
+            off[1:] = np.cumsum([len(ss) for ss in sinks])
+            stream = self._stream()
+            if not self.keep_image:
+                lib.check(d.ldbg_image_clear(self._img))
+            seed_slots = self._resolve(src_ascii, stream)
+            sink_slots = self._resolve(sink_ascii, stream)
+            state = {"rounds": 0, "gap": 1, "since": 0, "error": None}
+
+            def round_done(_user):
+                try:
+                    self._exchange(stream)
+                    state["rounds"] += 1
+                    state["since"] += 1
+                    if state["since"] < state["gap"]:
+                        return 0
+                    state["since"] = 0
+                    state["gap"] = min(self.check_every, state["gap"] * 2)
+                    return 1 if self._all_done(self._stats[0]) else 0
+                except BaseException as ex:        # never let an exception cross the C boundary
+                    state["error"] = ex
+                    return 1
+            cb = C.CFUNCTYPE(C.c_int, C.c_void_p)(round_done)
+            res = C.c_void_p()
+            t0 = C.c_int64()
+            eng = self.engine
+            lib.check(d.ldbg_engine_dfs_kmers_traversed(eng._h, C.byref(t0)))
+            src_buf = np.ascontiguousarray(src_ascii).reshape(-1)
+            sink_buf = np.ascontiguousarray(sink_ascii).reshape(-1) if len(flat) else np.zeros(1, dtype=np.uint8)
+            st = d.ldbg_engine_sharded_dfs_batch(eng._h, self._img, src_buf.ctypes.data_as(C.c_char_p), C.c_int64(n), sink_buf.ctypes.data_as(C.c_char_p),
+                                                 off.ctypes.data_as(C.c_void_p), P(seed_slots), P(sink_slots), cb, None, P(self._stats), stream, C.byref(res))
+            if state["error"] is not None:
+                raise state["error"]
+            lib.check(st)
+            self.rounds = state["rounds"]
+            t1 = C.c_int64()
+            lib.check(d.ldbg_engine_dfs_kmers_traversed(eng._h, C.byref(t1)))
+            self.dfs_kmers_traversed = t1.value - t0.value
+            batch = _DfsBatch(eng, res)
+            return [batch.graph(i) for i in range(n)]
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+                self._tstream.synchronize()
 
     def close(self):
         if getattr(self, "engine", None):

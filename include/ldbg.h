@@ -161,6 +161,16 @@ ldbg_status ldbg_image_counters(const ldbg_image* im, int64_t* n_rows, int64_t* 
 ldbg_status ldbg_engine_sharded_walk_begin(struct ldbg_engine* e, ldbg_image* im, const char* seeds, int64_t n, const int32_t* d_seed_slot, void* stream);
 ldbg_status ldbg_engine_sharded_walk_round(struct ldbg_engine* e, int64_t* d_stats);
 ldbg_status ldbg_engine_sharded_walk_finish(struct ldbg_engine* e, int64_t* total_contig_bytes, int64_t* kmers_traversed);
+/* TraversalEngine.dfs(source, sinks...) over the image, any stopping rule that does not consult a ROI graph.  The library runs the
+ * rounds and calls round_done(user) after each: the caller makes the round's exchange there (bucket, all-to-all, serve, all-to-all,
+ * insert) and returns non-zero once no rank has a search in progress (d_stats as above).  d_seed_slot / d_sink_slot: image slots of the
+ * sources' and sinks' records (-1 = none), their rows already in the image.  Capacity errors ("LINKSTORE_FULL", "LOG_FULL",
+ * "DEPTH_OVERFLOW") enlarge the engine's stores: run the batch again on every rank.  Result: as ldbg_engine_dfs_batch; `rec` of a
+ * vertex is its image slot (>= 0: the vertex has a record). */
+struct ldbg_dfs_result;
+ldbg_status ldbg_engine_sharded_dfs_batch(struct ldbg_engine* e, ldbg_image* im, const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets,
+                                          const int32_t* d_seed_slot, const int32_t* d_sink_slot, int (*round_done)(void* user), void* user,
+                                          int64_t* d_stats, void* stream, struct ldbg_dfs_result** out);
 
 /* ------------------------------------------------------------------ links: L3-L4
  * new CortexLinks(path) -> CortexLinksMap        J/utils/io/graph/links/CortexLinks.java:16-25,

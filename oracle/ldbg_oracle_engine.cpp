@@ -491,6 +491,7 @@ std::unique_ptr<PGraph> TraversalEngine::dfs_branch(Vertex cv, bool fwd, int gra
     std::vector<Vertex> avs, rvs;
     do {
         dfs_iterations++;
+        if (getenv("ORC_TRACE")) fprintf(stderr, "O %d %s\n", depth, cv.sk.c_str());
         std::vector<Vertex> pvs = prev_vertices(cv.sk);
         std::vector<Vertex> nvs = next_vertices(cv.sk);
         avs = fwd ? nvs : pvs;
@@ -520,6 +521,7 @@ std::unique_ptr<PGraph> TraversalEngine::dfs_branch(Vertex cv, bool fwd, int gra
         visited.insert(cv);
 
         int gv = (int)g->verts.size();
+        if (getenv("ORC_TRACE")) fprintf(stderr, "O   adj %d prev %d gv %d size %d rvs %d\n", (int)avs.size(), (int)previously, gv, graph_size + gv, (int)rvs.size());
         TraversalState ts{&cv, fwd, graph_size + gv, depth, gv, (int)avs.size(), (int)rvs.size(), false, gv > ec_.max_length, &sinks};
         if (!previously && stopper.keep_going(ts)) {
             if (avs.size() == 1) {

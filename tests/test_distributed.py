@@ -229,3 +229,80 @@ def test_sharded_link_walks_two_ranks(orc, tmp_path, k):
 @pytest.mark.timeout(900)
 def test_sharded_link_walks_three_ranks(orc, tmp_path):
     _sharded_walk_case(orc, tmp_path, 31, with_links=True, world=3)
+
+
+def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs, expected):
+    dist = _init(rank, world, port)
+    try:
+        import corticall_amd as ca
+        from corticall_amd import CortexLinks
+        from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine, partition
+        from tests import hostsim
+        lib = hostsim.load(rebuild=False)
+        sg = ShardedCortexGraph(path, lib=lib, chunk_records=700)
+        links = CortexLinks(link_path, sg.shard, lib=lib) if link_path else None
+        first, cnt = partition(len(sources), rank, world)
+        for ci, (stopper, trav, direction, max_len, with_links) in enumerate(cfgs):
+            e = ShardedTraversalEngine(sg, trav, links=[links] if (with_links and links) else (), direction=direction, max_branch_length=max_len,
+                                       stopping_rule=stopper, rows_per_owner=64 if ci % 2 else 2048, check_every=4)
+            got = e.dfs_batch(sources[first:first + cnt], sinks[first:first + cnt])
+            for j, gi in enumerate(got):
+                exp = expected[ci][first + j]
+                if exp is None:
+                    assert gi is None, (cfgs[ci], sources[first + j])
+                    continue
+                assert gi is not None, (cfgs[ci], sources[first + j])
+                vt = [(km, rec >= 0, ci_, ix) for km, rec, ci_, ix in gi.vertex_tuples()]
+                assert vt == exp[0] and gi.edge_tuples() == exp[1], (cfgs[ci], sources[first + j], len(vt), len(exp[0]))
+                assert gi.walk_contig(sources[first + j], trav[0]) == exp[2]
+            import torch
+            t = torch.tensor([e.dfs_kmers_traversed])
+            dist.all_reduce(t)
+            assert int(t.item()) == expected[ci][-1], (cfgs[ci], int(t.item()), expected[ci][-1])
+            assert e.rounds > 0
+            e.close()
+        sg.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("k", [21, 32])
+def test_sharded_dfs_two_ranks(orc, tmp_path, k):
+    """dfs(source, sinks) with a stopping rule over the sharded table (TraversalEngine.java:64-106, 356-482): DestinationStopper towards a
+    sink downstream (the gap-closing configuration, Call.java:759-779), ExplorationStopper, ContigStopper — graphs (vertices and edges in
+    insertion order), toWalk/toContig of them, and the k-mers traversed against the oracle on the whole graph"""
+    from tests import parity_cases as pc
+    rng = random.Random(300 + k)
+    base = pc.genome_with_repeats(rng, 900, n_rep=5, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+    kid = pc.mutate(rng, base, snv=0.01, indel=0.003)
+    dad = pc.mutate(rng, base, snv=0.02, indel=0.003)
+    path = str(tmp_path / "sd.ctx")
+    orc.build_graph(path, [("kid", [kid]), ("mom", [base]), ("dad", [dad])], k)
+    og = orc.Graph(path, tuned=True)
+    rl = max(3 * k, 60)
+    link_path = str(tmp_path / "sd.kid.ctp.gz")
+    orc.build_links(og, link_path, "kid", [kid[i:i + rl] for i in range(0, max(1, len(kid) - rl + 1), max(1, rl // 4))] + [kid[-rl:]])
+    ol = orc.Links(link_path)
+    pos = rng.sample(range(0, len(kid) - k - 200), 36)
+    sources = [kid[p:p + k] for p in pos] + [pc.rand_seq(rng, k), "N" * k]
+    sinks = [[kid[p + d:p + d + k]] for p, d in ((p, rng.randint(20, 180)) for p in pos)] + [[kid[5:5 + k]], []]
+    sources[3] = orc.revcomp(sources[3])
+    sinks[5] = [sinks[5][0], "N" * k, pc.rand_seq(rng, k)]
+    cfgs = [("DestinationStopper", [0], 1, 400, True), ("DestinationStopper", [0], 0, 400, False), ("ExplorationStopper", [0], 0, 150, True),
+            ("ContigStopper", [0, 1], 0, 300, True), ("DestinationStopper", [1], 2, 120, True)]
+    expected = []
+    for stopper, trav, direction, max_len, wl in cfgs:
+        oe = orc.Engine(og, trav, links=[ol] if wl else [], direction=direction, max_length=max_len, stopper=stopper)
+        it0 = oe.kmers_traversed()
+        per = []
+        for s_, sk in zip(sources, sinks):
+            r = oe.dfs(s_, sk)
+            if r.is_null:
+                per.append(None)
+            else:
+                per.append(([(km, rec >= 0, ci, ix) for km, rec, ci, ix in r.vertices()], r.edges(), r.walk(s_, trav[0])))
+            r.free()
+        per.append(oe.kmers_traversed() - it0)
+        expected.append(per)
+    _spawn(_sharded_dfs_worker, (path, link_path, sources, sinks, cfgs, expected))
