@@ -225,8 +225,8 @@ ldbg_status ldbg_engine_destroy(ldbg_engine* e);
 /* walk(seed) + TraversalUtils.toContig, for n seeds at once       TraversalEngine.java:108-110,
  * TraversalUtils.java:367-488.  seeds: n × k ASCII.  The contigs are written back to back into
  * contig_arena (ASCII); offsets[n+1]; walk_len[i] = number of vertices of walk i (0: empty walk,
- * empty contig).  kmers_traversed (may be NULL) receives the number of dfs loop iterations + cursor
- * steps the batch performed (SURVEY §8d's unit).  If the arena is too small, LDBG_ERR_CAPACITY is
+ * empty contig).  kmers_traversed (may be NULL) receives the number of dfs loop iterations
+ * (TraversalEngine.java:373: one per vertex a branch stands on) the batch performed (SURVEY §8d's unit).  If the arena is too small, LDBG_ERR_CAPACITY is
  * returned and offsets[n] holds the required size. */
 ldbg_status ldbg_engine_walk_batch(ldbg_engine* e, const char* seeds, int64_t n,
                                    char* contig_arena, int64_t arena_capacity, int64_t* offsets,
