@@ -280,6 +280,95 @@ def bench_c3_sharded(args, ca, prefix, st, seeds, rank, local_rank, world, dist)
     dist.destroy_process_group()
 
 
+def bench_c4_sharded(args, ca, g, links, walk_eng, seeds, st, prefix, rank, local_rank, world, dist, sync):
+    """configs[3] as BASELINE names it: DestinationStopper dfs over the HASH-SHARDED table.  Sinks are drawn as in bench_c4 (from the
+    seeds' own contigs, computed on a replica of the graph: a benchmark convenience); the searches then run over local images of the
+    sharded table, rows fetched from their owners per bulk-synchronous round (corticall_amd/distributed.py)."""
+    import numpy as np
+    import torch
+    from corticall_amd import CortexLinks, DestinationStopper
+    from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine
+    k = args.k
+    n = min(len(seeds), args.sharded_seeds)
+    seeds = seeds[:n]
+    arena, offs, wl = walk_eng.walk_batch_arrays(seeds)
+    rng = np.random.default_rng(0xC0FFEE05 + rank)
+    sinks = []
+    for i in range(n):
+        c = arena[offs[i]:offs[i + 1]]
+        p = c.tobytes().find(seeds[i].tobytes()) if len(c) >= k else -1
+        if p < 0:
+            sinks.append([seeds[(i + 1) % n].tobytes().decode()])
+            continue
+        q = min(len(c) - k, p + int(rng.integers(200, 2001)))
+        sinks.append([c[q:q + k].tobytes().decode()])
+    sources = [s.tobytes().decode() for s in seeds]
+    t0 = time.time()
+    sg = ShardedCortexGraph(prefix + ".ctx", device=local_rank)
+    sg.build_neighbour_index()
+    t_load = time.time() - t0
+    slinks = [CortexLinks(prefix + ".ctp.gz", sg.shard)]
+    eng = ShardedTraversalEngine(sg, [0], links=slinks, direction=1, max_branch_length=args.max_len, stopping_rule=DestinationStopper,
+                                 rows_per_owner=args.rows_per_owner, check_every=args.check_every)
+    for _ in range(args.warmup):
+        eng.dfs_batch(sources, sinks)
+    sync()
+    t1 = time.time()
+    traversed = rounds = 0
+    for _ in range(args.steps):
+        graphs = eng.dfs_batch(sources, sinks)
+        traversed += eng.dfs_kmers_traversed
+        rounds += eng.rounds
+    sync()
+    dt = time.time() - t1
+    t = torch.tensor([float(traversed), float(n * args.steps)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t)
+    m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        N, W, C = sg.getNumRecords(), sg.W, sg.C
+        b = math.ceil(math.log2(N)) * 8 * W + 5 * C + math.ceil(math.log2(max(2, slinks[0].numKmersWithLinks))) * 8 * W
+        achieved = t[0].item() * b / m[0].item() / 1e9 / max(1, world)
+        out = {
+            "metric": "k-mers traversed/sec (whole node) + contigs/sec, k=47 3-color LdBG", "value": t[0].item() / m[0].item(),
+            "unit": "k-mers traversed/s", "contigs_per_s": t[1].item() / m[0].item(), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m[0].item() / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic", "library": ca.default_lib().dll.ldbg_version().decode(),
+            "config": {"workload": "configs[3]: same %.1f Mb 3-colour k=%d LdBG with child links, dfs with DestinationStopper (FORWARD) from %d seeds per GPU to the child "
+                                   "k-mer 200-2000 bp downstream, table HASH-SHARDED over %d rank(s), rows fetched on demand into local images, RCCL all-to-all per round"
+                                   % (args.genome_len / 1e6, k, n, world),
+                       "records": N, "rounds_per_step": rounds // max(1, args.steps), "ms_per_round": m[0].item() / max(1, rounds) * 1e3,
+                       "sinks_reached": sum(1 for x in graphs if x is not None), "kmers_traversed_per_step": traversed // max(1, args.steps),
+                       "multi_gpu": "hash-sharded table, rows exchanged, searches stay on the rank of their source", "load_seconds": round(t_load, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_dfs<%d> on the image, one launch per round" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_kmer": b,
+                         "note": "per GPU; the bulk-synchronous rounds, not HBM, bound this regime: see ms_per_round"},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import pyoracle as orc
+            og = orc.Graph(prefix + ".ctx", use_cache=True, tuned=False)
+            oe = orc.Engine(og, [0], links=[orc.Links(prefix + ".ctp.gz")], stopper="DestinationStopper", max_length=args.max_len, direction=orc.FORWARD)
+            pick = np.random.default_rng(20261004).permutation(n)
+            t2 = time.time()
+            i = mism = 0
+            while i < n and time.time() - t2 < args.cpu_seconds:
+                j = int(pick[i])
+                r = oe.dfs(sources[j], sinks[j])
+                gi = graphs[j]
+                same = (gi is None) == r.is_null and (r.is_null or ([(a_, b_ >= 0, c_, d_) for a_, b_, c_, d_ in gi.vertex_tuples()] == [(a_, b_ >= 0, c_, d_) for a_, b_, c_, d_ in r.vertices()]
+                                                                  and gi.edge_tuples() == r.edges()))
+                mism += 0 if same else 1
+                r.free()
+                i += 1
+            dtc = time.time() - t2
+            out["cpu_baseline"] = {"value": oe.kmers_traversed() / dtc, "unit": "k-mers traversed/s", "cores": 1, "kind": "port",
+                                   "sample": "%d searches drawn at random (%d k-mers traversed in %.1f s), oracle in faithful mode" % (i, oe.kmers_traversed(), dtc)}
+            out["parity"] = "%d/%d sampled dfs graphs bit-exact vs oracle (vertices and edges in insertion order)" % (i - mism, i)
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist, sync, t_load):
     """configs[3]: dfs with DestinationStopper (the gap-closing configuration of Call.java:759-779) from every seed
     towards the child k-mer 200-2000 bp downstream on the seed's own link-guided contig."""
@@ -453,6 +542,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if args.workload == "c4" and args.sharded:
+        return bench_c4_sharded(args, ca, g, links, eng, seeds, st, prefix, rank, local_rank, world, dist, sync)
     if args.workload == "c4":
         return bench_c4(args, ca, g, links, eng, seeds, st, prefix, rank, world, dist, sync, t_load)
 

@@ -791,6 +791,7 @@ void Engine::build_roi_bits() {
 DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets, const ShardedRun* sharded) {
     if (cfg.connect_all_neighbors) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: connectAllNeighbors is not supported on the device path");
     rt::set_device(graph->device);
+    materialize_pending();            // (the path pool is about to be reused: walks of the last batch keep their vertex lists)
     build_roi_bits();
     const int k = graph->hdr.k, W = graph->hdr.W;
     std::vector<uint64_t> words((size_t)n * W);

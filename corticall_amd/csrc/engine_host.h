@@ -21,6 +21,13 @@ struct WalkChunk {
     void* d_seed_words = nullptr;          // [n][W]
     void* d_term = nullptr;                // [2n][W] k-mer of a trailing null-record vertex
     std::vector<uint8_t> seed_ok;          // toWalk seed test: record present and coverage > 0
+    // the walks as the kernel stored them (vertex entries and run / repeat descriptors in the engine's path pool): d_path is expanded
+    // from them by Engine::ensure_dense the first time vertex lists are asked for — contigs do not need it
+    void* d_strand_c = nullptr;            // [2n] stored entries per strand
+    void* d_strand_off = nullptr;          // [2n+1] device copy of strand_off
+    int max_blocks = 0;
+    RunIndexView runs{};
+    bool dense_pending = false;
 };
 
 // ---- dfs results (dfs.cpp): the DirectedWeightedPseudograph<CortexVertex, CortexEdge> of every seed
@@ -127,6 +134,8 @@ private:
     void drop_spares();
     void zero_dirty_tables(rt::stream_t s);      // the part of the table pool the last launch handed out
     bool run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);
+    void ensure_dense(WalkChunk& c);
+    void materialize_pending();
     void walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkRun& r, ShardImage* img, const int32_t* d_seed_slot);
     void walk_launch(WalkRun& r);
     bool walk_finish(WalkRun& r, int64_t* traversed);

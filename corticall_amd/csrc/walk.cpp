@@ -327,7 +327,7 @@ struct ExpandArgs {
     int64_t n_strands;
     RunIndexView runs;
     uint64_t* dense;
-    uint32_t* status;                  // a REPEAT that takes a copyIndex out of range reports ST_COPY_OVERFLOW here
+    unsigned* overflow;                // a REPEAT that takes a copyIndex out of its range sets this
 };
 LDBG_DEV uint64_t expand_stored(const ExpandArgs& a, int64_t s, uint32_t j) {
     return a.pool[(uint64_t)a.block_table[s * a.max_blocks + j / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK + (j & (LDBG_PATH_BLOCK - 1))];
@@ -380,7 +380,7 @@ LDBG_KERNEL void k_expand_paths(ExpandArgs a) {
                         const uint32_t o = i % period;
                         const uint64_t s1 = LDBG_GLOBAL(const uint64_t, out)[first + o], s2 = LDBG_GLOBAL(const uint64_t, out)[first + period + o];
                         const int c = path_copy(s2) + (int)(i / period + 1u) * (path_copy(s2) - path_copy(s1));
-                        if (c > 32767 || c < -32767) a.status[s] = ST_COPY_OVERFLOW;     // as the k-mer-by-k-mer walk reports it (:383-389 never ends; ours does)
+                        if (c > 32767 || c < -32767) *a.overflow = 1u;     // reported as the k-mer-by-k-mer walk reports it (ST_COPY_OVERFLOW)
                         out[hat + i] = (s2 & ~(0xFFFFFFull << 36)) | (((uint64_t)(uint32_t)c & 0xFFFFFFull) << 36);
                     }
                 }
@@ -446,6 +446,82 @@ LDBG_KERNEL void k_contigs(ContigArgs a) {
             else if (p < nrev + k) b = kmer_base<W>(sk, k, (int)(p - nrev));
             else b = path_base(a.dense[fo + (p - nrev - k + 1)]);
             o[p] = "ACGT"[b];
+        }
+    }
+}
+
+// Contigs straight from the STORED paths (vertex entries and descriptors, strand.h): a contig needs one base per vertex, and for the
+// vertices of a run that base is in ubase — 1 byte read and 1 written per k-mer instead of expanding 8-byte vertex entries first.
+// One wavefront per seed; the dense vertex entries are produced only when somebody asks for vertex lists (Engine::ensure_dense).
+struct ContigRleArgs {
+    GraphView g;
+    RunIndexView runs;
+    int64_t n;
+    const uint64_t* seeds;
+    const uint64_t* pool; const uint32_t* block_table; int max_blocks;
+    const uint32_t* strand_c; const uint32_t* strand_n;
+    const int64_t* walk_len; const int64_t* contig_off;
+    char* out;
+};
+LDBG_DEV uint64_t rle_stored(const ContigRleArgs& a, int64_t s, uint32_t j) {
+    return a.pool[(uint64_t)a.block_table[s * a.max_blocks + j / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK + (j & (LDBG_PATH_BLOCK - 1))];
+}
+template <int W>
+LDBG_KERNEL void k_contigs_rle(ContigRleArgs a) {
+    const int k = a.g.k;
+    const int64_t wave = global_tid() / wave_size(), nwaves = (global_nthreads() + wave_size() - 1) / wave_size();
+    const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
+    for (int64_t i = wave; i < a.n; i += nwaves) {
+        if (a.walk_len[i] == 0) continue;
+        char* o = a.out + a.contig_off[i];
+        const int64_t nr = a.strand_n[2 * i], nrev = nr > 0 ? nr - 1 : 0;
+        Kmer<W> sk;
+#pragma unroll
+        for (int w = 0; w < W; w++) sk.w[w] = a.seeds[i * W + w];
+        for (uint32_t p = lane; p < (uint32_t)k; p += WS) o[nrev + p] = "ACGT"[kmer_base<W>(sk, k, (int)p)];
+        for (int dir = 0; dir < 2; dir++) {
+            const int64_t s = 2 * i + dir;
+            const bool fwd = dir == 1;
+            const uint32_t nc = a.strand_c[s];
+            // place of vertex v >= 1 of this strand in the contig: the reverse strand runs backwards from the seed
+            auto place = [&](uint32_t v) -> int64_t { return fwd ? nrev + k - 1 + (int64_t)v : nrev - (int64_t)v; };
+            uint32_t base_v = 0;
+            for (uint32_t j0 = 0; j0 < nc; j0 += WS) {
+                const uint32_t j = j0 + lane;
+                uint64_t e = 0, prev = 0;
+                if (j < nc) {
+                    e = rle_stored(a, s, j);
+                    if (j & (LDBG_PATH_BLOCK - 1)) prev = rle_stored(a, s, j - 1);
+                }
+                const uint32_t cnt = j < nc ? pd_expanded(prev, e) : 0u;
+                const uint32_t incl = wave_incl_scan_u32(cnt);
+                const uint32_t at = base_v + incl - cnt;
+                const bool head = cnt > 0u && (e & LDBG_PD_TAG) != 0ull;
+                if (cnt == 1u && !head && at >= 1u) o[place(at)] = "ACGT"[path_base(e)];
+                unsigned long long hb = wave_ballot(head);
+                while (hb) {
+                    const int L = __builtin_ctzll(hb);
+                    hb &= hb - 1;
+                    const uint64_t he = wave_bcast_u64(e, L);
+                    const uint32_t hat = wave_bcast_u32(at, L), len = wave_bcast_u32(cnt, L);
+                    const uint64_t payload = rle_stored(a, s, j0 + (uint32_t)L + 1);
+                    if (LDBG_PD_KIND(he) == LDBG_PD_RUN) {
+                        const bool asc = (he >> 36) & 1ull, inv = (he >> 37) & 1ull;
+                        const uint32_t first = (uint32_t)payload;
+                        for (uint32_t t = lane; t < len; t += WS) {
+                            const unsigned bb = a.runs.ubase[asc ? first + t : first - t];
+                            const unsigned b0 = !inv ? (bb & 3u) : 3u - ((bb >> 2) & 3u), b1 = !inv ? ((bb >> 2) & 3u) : 3u - (bb & 3u);
+                            o[place(hat + t)] = "ACGT"[fwd ? b1 : b0];
+                        }
+                    } else {                                   // REPEAT: the bases of the last recorded revolution, again and again
+                        wave_fence();
+                        const uint32_t first = (uint32_t)payload, period = (uint32_t)(payload >> 32);
+                        for (uint32_t t = lane; t < len; t += WS)
+                            o[place(hat + t)] = LDBG_GLOBAL(const char, o)[place(first + period + t % period)];
+                    }
+                }
+                base_v += wave_bcast_u32(incl, (int)WS - 1);
+            }
         }
     }
 }
@@ -610,6 +686,7 @@ void Engine::walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, u
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         WalkChunk& c = chunks[ci];
         RoiHitArgs a;
+        ensure_dense(c);
         a.roi_of = (const uint32_t*)d_roi_of_; a.n = c.n; a.dense = (const uint64_t*)c.d_path;
         int64_t* d_soff = (int64_t*)rt::dmalloc((size_t)(2 * c.n + 1) * 8);
         int64_t* d_wl = (int64_t*)rt::dmalloc((size_t)std::max<int64_t>(1, c.n) * 8);
@@ -645,6 +722,30 @@ void Engine::walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, u
     }
     if (total > capacity) throw StatusError(LDBG_ERR_CAPACITY, "hit buffer too small: need " + std::to_string(total));
 }
+
+// the dense 8-byte vertex entries of a chunk's walks, expanded from the stored paths the first time they are needed
+void Engine::ensure_dense(WalkChunk& c) {
+    if (!c.dense_pending) return;
+    rt::set_device(graph->device);
+    rt::stream_t s = graph->stream;
+    const int64_t ns = 2 * c.n;
+    c.d_path = result_alloc((size_t)std::max<int64_t>(1, c.strand_off[ns]) * 8, &c.path_cap);
+    unsigned* d_ovf = (unsigned*)rt::dmalloc(4);
+    rt::dmemset(d_ovf, 0, 4, s);
+    ExpandArgs xa;
+    xa.pool = (const uint64_t*)d_pool_; xa.block_table = (const uint32_t*)d_block_table_; xa.max_blocks = c.max_blocks;
+    xa.strand_c = (const uint32_t*)c.d_strand_c; xa.strand_off = (const int64_t*)c.d_strand_off; xa.n_strands = ns;
+    xa.runs = c.runs; xa.dense = (uint64_t*)c.d_path; xa.overflow = d_ovf;
+    LDBG_LAUNCH(k_expand_paths, grid_for(ns * 64, 64, 256 * 64), 64, s, xa);
+    unsigned ovf = 0;
+    rt::d2h(&ovf, d_ovf, 4, s);
+    rt::stream_sync(s);
+    rt::dfree(d_ovf);
+    c.dense_pending = false;
+    if (ovf) throw StatusError(LDBG_ERR_UNSUPPORTED, "a vertex was visited more than 32767 times in one walk");
+}
+// before the path pool is used for something else: the vertex entries of the walks still held
+void Engine::materialize_pending() { for (auto& c : chunks) ensure_dense(c); }
 
 void Engine::launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks) {
     LDBG_LAUNCH(k_compact_paths, grid_for(n_strands * 64, 256, 4096), 256, graph->stream, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
@@ -705,7 +806,10 @@ void Engine::drop_spares() {
 }
 
 void Engine::clear_batch() {
-    for (auto& c : chunks) { result_free(c.d_path, c.path_cap); result_free(c.d_contigs, c.contigs_cap); rt::dfree(c.d_seed_words); rt::dfree(c.d_term); }
+    for (auto& c : chunks) {
+        result_free(c.d_path, c.path_cap); result_free(c.d_contigs, c.contigs_cap); rt::dfree(c.d_seed_words); rt::dfree(c.d_term);
+        rt::dfree(c.d_strand_c); rt::dfree(c.d_strand_off);
+    }
     chunks.clear();
     batch_n = batch_bytes = batch_traversed = 0;
 }
@@ -1096,7 +1200,8 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
     }
     for (int64_t i = 0; i < ns; i++) *traversed += iters[i];
 
-    // dense paths + contigs
+    // contigs; the dense vertex entries now (a walk through a quirk-Q6 vertex is spelled k-mer by k-mer from them; a batch that was split
+    // reuses the path pool) or when somebody asks for vertex lists (ensure_dense)
     out.strand_off.assign(ns + 1, 0);
     for (int64_t i = 0; i < ns; i++) out.strand_off[i + 1] = out.strand_off[i] + strand_n[i];
     out.contig_off.assign(n + 1, 0);
@@ -1106,36 +1211,54 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
     rt::h2d(d_strand_off, out.strand_off.data(), (size_t)(ns + 1) * 8, s);
     rt::h2d(d_contig_off, out.contig_off.data(), (size_t)(n + 1) * 8, s);
     laps.lap("offsets");
-    out.d_path = result_alloc((size_t)out.strand_off[ns] * 8, &out.path_cap);
+    std::vector<uint8_t> quirks((size_t)ns);
+    rt::d2h(quirks.data(), d_quirk, (size_t)ns, s);
+    rt::stream_sync(s);
+    bool any_quirk = false;
+    for (int64_t i = 0; i < ns; i++) any_quirk |= quirks[i] != 0;
+    const bool lazy = !any_quirk && first == 0 && n == batch_n && !getenv("LDBG_EAGER_PATHS");
     out.d_contigs = result_alloc((size_t)out.contig_off[n], &out.contigs_cap);
+    out.d_strand_off = d_strand_off;
+    out.d_strand_c = d_strand_c; d_strand_c = nullptr;           // the chunk owns them now (clear_batch frees)
+    out.max_blocks = max_blocks;
+    out.runs = a.e.runs;
+    out.dense_pending = true;
     laps.lap("result buffers");
     rt::Event c0, c1;
     c0.record(s);
-    {
-        ExpandArgs xa;
-        xa.pool = (const uint64_t*)d_pool_; xa.block_table = (const uint32_t*)d_block_table_; xa.max_blocks = max_blocks;
-        xa.strand_c = d_strand_c; xa.strand_off = d_strand_off; xa.n_strands = ns;
-        xa.runs = a.e.runs; xa.dense = (uint64_t*)out.d_path; xa.status = d_status;
-        LDBG_LAUNCH(k_expand_paths, grid_for(ns * 64, 64, 256 * 64), 64, s, xa);
-    }
-    const int cg = grid_for(n * 64, 256, 4096);
-    ContigArgs ca;
-    ca.g = graph->view; ca.n = n; ca.seeds = a.seeds; ca.dense = (const uint64_t*)out.d_path; ca.strand_off = d_strand_off;
-    ca.walk_len = d_walk_len; ca.contig_off = d_contig_off; ca.quirk = d_quirk; ca.term = (const uint64_t*)out.d_term;
-    ca.out = (char*)out.d_contigs;
-    switch (W) {
-        case 1: LDBG_LAUNCH(k_contigs<1>, cg, 256, s, ca); break;
-        case 2: LDBG_LAUNCH(k_contigs<2>, cg, 256, s, ca); break;
-        case 3: LDBG_LAUNCH(k_contigs<3>, cg, 256, s, ca); break;
-        default: LDBG_LAUNCH(k_contigs<4>, cg, 256, s, ca); break;
+    if (lazy) {
+        ContigRleArgs ra;
+        ra.g = graph->view; ra.runs = a.e.runs; ra.n = n; ra.seeds = a.seeds;
+        ra.pool = (const uint64_t*)d_pool_; ra.block_table = (const uint32_t*)d_block_table_; ra.max_blocks = max_blocks;
+        ra.strand_c = (const uint32_t*)out.d_strand_c; ra.strand_n = d_strand_n; ra.walk_len = d_walk_len; ra.contig_off = d_contig_off;
+        ra.out = (char*)out.d_contigs;
+        const int rg = grid_for(n * 64, 64, 256 * 64);
+        switch (W) {
+            case 1: LDBG_LAUNCH(k_contigs_rle<1>, rg, 64, s, ra); break;
+            case 2: LDBG_LAUNCH(k_contigs_rle<2>, rg, 64, s, ra); break;
+            case 3: LDBG_LAUNCH(k_contigs_rle<3>, rg, 64, s, ra); break;
+            default: LDBG_LAUNCH(k_contigs_rle<4>, rg, 64, s, ra); break;
+        }
+    } else {
+        ensure_dense(out);
+        const int cg = grid_for(n * 64, 256, 4096);
+        ContigArgs ca;
+        ca.g = graph->view; ca.n = n; ca.seeds = a.seeds; ca.dense = (const uint64_t*)out.d_path; ca.strand_off = d_strand_off;
+        ca.walk_len = d_walk_len; ca.contig_off = d_contig_off; ca.quirk = d_quirk; ca.term = (const uint64_t*)out.d_term;
+        ca.out = (char*)out.d_contigs;
+        switch (W) {
+            case 1: LDBG_LAUNCH(k_contigs<1>, cg, 256, s, ca); break;
+            case 2: LDBG_LAUNCH(k_contigs<2>, cg, 256, s, ca); break;
+            case 3: LDBG_LAUNCH(k_contigs<3>, cg, 256, s, ca); break;
+            default: LDBG_LAUNCH(k_contigs<4>, cg, 256, s, ca); break;
+        }
     }
     c1.record(s);
-    rt::d2h(out.status.data(), d_status, (size_t)ns * 4, s);       // (the expansion reports copy counts that leave their range)
     rt::stream_sync(s);
     profile_add("contig", rt::Event::elapsed_ms(c0, c1));
-    laps.lap("compaction + contigs");
+    laps.lap("paths + contigs");
     free_tmp();
-    rt::dfree(d_walk_len); rt::dfree(d_seed_ok); rt::dfree(d_strand_off); rt::dfree(d_contig_off);
+    rt::dfree(d_walk_len); rt::dfree(d_seed_ok); rt::dfree(d_contig_off);
     laps.lap("frees");
 
     // errors the reference raises as exceptions abort the call
@@ -1256,6 +1379,7 @@ void Engine::walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_
         *len = L;
         if (L == 0) return;
         if (capacity < L) throw StatusError(LDBG_ERR_CAPACITY, "vertex buffers too small: need " + std::to_string(L));
+        ensure_dense(c);
         rt::stream_t s = graph->stream;
         uint64_t* d_words = (uint64_t*)rt::dmalloc((size_t)L * W * 8);
         int64_t* d_rec = (int64_t*)rt::dmalloc((size_t)L * 8);
