@@ -396,7 +396,7 @@ LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64
     return st.status == ST_OK;
 }
 
-template <int W>
+template <int W, bool IMG>
 LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
     const int64_t slot = global_tid();
     if (slot >= a.w.n_slots) return;
@@ -425,7 +425,7 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
     // lane was working on when the previous round ended is taken up again
     bool suspended = false, begun = true;
     DfsSave<W>* save = (DfsSave<W>*)a.lane_save;
-    if (save) {
+    if constexpr (IMG) {
         const DfsSave<W>& sv = save[slot];
         if (sv.active) {
             L = sv.L;
@@ -444,7 +444,7 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
                 const bool fwd = (s & 1) != 0;
                 if ((fwd && !a.w.run_fwd) || (!fwd && !a.w.run_rev)) {
                     a.w.strand_n[s] = 0; a.w.status[s] = ST_BRANCH_NULL; a.w.iters[s] = 0; a.w.quirk[s] = 0;
-                } else if (a.w.img_on) {
+                } else if (IMG) {
                     L.st.s = s; L.st.fwd = fwd; active = true; begun = false;
                 } else {
                     active = dfs_begin<W>(a, L, ls, s);
@@ -452,7 +452,7 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
                 }
             }
         }
-        if (a.w.img_on && active && !suspended) {
+        if (IMG && active && !suspended) {
             StrandState& st = L.st;
             if (!begun) {
                 const int32_t sl = a.w.seed_valid[st.s >> 1] ? a.w.seed_slot[st.s >> 1] : -1;
@@ -501,7 +501,7 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
         if (wave_ballot(running && !lean) != 0ull) coop_step_prepare<W>(a.w.e, L.st, ls, lw, cur_mode, pre);
         if (running && dfs_step<W>(a, L, ls, slot, pre, lean)) { strand_finish(a.w, L.st); active = false; }
     }
-    if (save) {
+    if constexpr (IMG) {
         DfsSave<W>& sv = save[slot];
         sv.active = active ? 1 : 0;
         if (active) {
@@ -893,7 +893,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     a.w.n_strands = ns;
     a.w.n_slots = std::min<int64_t>(n_slots_, ((ns + 63) / 64) * 64);
     // every workgroup resident: LDBG_LS_FAST x 64 x 24 B of LDS each; 194 VGPRs per lane leave 2 wavefronts per SIMD = 8 per CU
-    a.w.n_slots = std::min<int64_t>(a.w.n_slots, (int64_t)std::min<size_t>(8, 160 * 1024 / (LDBG_LS_FAST * 64 * sizeof(LsElem))) * rt::cu_count(graph->device) * 64);
+    a.w.n_slots = std::min<int64_t>(a.w.n_slots, (int64_t)std::min<size_t>(sharded ? 4 : 8, 160 * 1024 / (LDBG_LS_FAST * 64 * sizeof(LsElem))) * rt::cu_count(graph->device) * 64);
     a.w.n_slots = std::max<int64_t>(64, (a.w.n_slots / 64) * 64);
     {
         auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
@@ -945,11 +945,20 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     e0.record(s);
     const int grid = (int)(a.w.n_slots / 64);
     auto launch = [&](rt::stream_t ls) {
-        switch (W) {
-            case 1: LDBG_LAUNCH(k_dfs<1>, grid, 64, ls, a); break;
-            case 2: LDBG_LAUNCH(k_dfs<2>, grid, 64, ls, a); break;
-            case 3: LDBG_LAUNCH(k_dfs<3>, grid, 64, ls, a); break;
-            default: LDBG_LAUNCH(k_dfs<4>, grid, 64, ls, a); break;
+        if (sharded) {
+            switch (W) {
+                case 1: LDBG_LAUNCH((k_dfs<1, true>), grid, 64, ls, a); break;
+                case 2: LDBG_LAUNCH((k_dfs<2, true>), grid, 64, ls, a); break;
+                case 3: LDBG_LAUNCH((k_dfs<3, true>), grid, 64, ls, a); break;
+                default: LDBG_LAUNCH((k_dfs<4, true>), grid, 64, ls, a); break;
+            }
+        } else {
+            switch (W) {
+                case 1: LDBG_LAUNCH((k_dfs<1, false>), grid, 64, ls, a); break;
+                case 2: LDBG_LAUNCH((k_dfs<2, false>), grid, 64, ls, a); break;
+                case 3: LDBG_LAUNCH((k_dfs<3, false>), grid, 64, ls, a); break;
+                default: LDBG_LAUNCH((k_dfs<4, false>), grid, 64, ls, a); break;
+            }
         }
     };
     if (!sharded) launch(s);

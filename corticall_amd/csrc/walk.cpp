@@ -111,7 +111,9 @@ LDBG_DEV void lean_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, Ru
 
 // BS = lanes per workgroup (a full or partial wavefront).  Fewer lanes per wavefront = fewer strands whose link-store
 // work the wavefront has to carry out one after the other, and more wavefronts per CU to hide each other's latency.
-template <int W, int BS>
+// IMG: the walk runs over the local image of a sharded table (image.h) — suspension, state kept from launch to launch.  A separate
+// instantiation: the resident-table kernel does not pay for that code in registers (it cost 55 of them: 2 wavefronts per SIMD -> 1)
+template <int W, int BS, bool IMG>
 LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     const int64_t slot = global_tid();
     if (slot >= a.n_slots) return;
@@ -146,7 +148,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     // over an image (image.h): a strand that needs a row that has not been sent yet SUSPENDS for the rest of this launch; the
     // strand a lane was working on when the previous round ended is taken up again
     bool suspended = false, begun = true;
-    if (a.save) {
+    if constexpr (IMG) {
         const StrandSave& sv = a.save[slot];
         if (sv.active) {
             st = sv.st; rs = sv.rs;
@@ -171,7 +173,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
                 const bool fwd = (s & 1) != 0;
                 if ((fwd && !a.run_fwd) || (!fwd && !a.run_rev)) {
                     a.strand_n[s] = 0; a.strand_c[s] = 0; a.status[s] = ST_BRANCH_NULL; a.iters[s] = 0; a.quirk[s] = 0;
-                } else if (a.img_on) {
+                } else if (IMG) {
                     st.s = s; st.fwd = fwd; active = true; begun = false;       // begins below, once the rows around its seed are here
                 } else {
                     active = strand_begin<W>(a, st, ls, s);
@@ -181,7 +183,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
                 }
             }
         }
-        if (a.img_on && active && !suspended) {
+        if (IMG && active && !suspended) {
             if (!begun) {
                 // the first iteration looks at the seed's neighbours (cursor_seek :321-335, or the branch loop itself :373-376)
                 const int32_t sl = a.seed_valid[st.s >> 1] ? a.seed_slot[st.s >> 1] : -1;
@@ -254,7 +256,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             if (ended) { walk_finish(a, st); active = false; }
         }
     }
-    if (a.save) {
+    if constexpr (IMG) {
         StrandSave& sv = a.save[slot];
         sv.active = active ? 1 : 0;
         if (active) {
@@ -932,9 +934,10 @@ struct WalkRun {
 static void launch_k_walk(const WalkRun& r, const WalkArgs& a, rt::stream_t s) {
     const int block = r.block, grid = r.grid;
 #define LDBG_WALK_CASE(WW) \
-    if (block == 16) LDBG_LAUNCH((k_walk<WW, 16>), grid, 16, s, a); \
-    else if (block == 64) LDBG_LAUNCH((k_walk<WW, 64>), grid, 64, s, a); \
-    else LDBG_LAUNCH((k_walk<WW, 32>), grid, 32, s, a)
+    if (a.img_on) LDBG_LAUNCH((k_walk<WW, 64, true>), grid, 64, s, a); \
+    else if (block == 16) LDBG_LAUNCH((k_walk<WW, 16, false>), grid, 16, s, a); \
+    else if (block == 64) LDBG_LAUNCH((k_walk<WW, 64, false>), grid, 64, s, a); \
+    else LDBG_LAUNCH((k_walk<WW, 32, false>), grid, 32, s, a)
     switch (r.W) {
         case 1: LDBG_WALK_CASE(1); break;
         case 2: LDBG_WALK_CASE(2); break;
@@ -1051,6 +1054,7 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
     if (const char* ev = getenv("LDBG_WALK_BLOCK")) block = atoi(ev) == 16 ? 16 : (atoi(ev) == 32 ? 32 : 64);   // tuning knob
     // residency: LDS per workgroup, and 152 VGPRs per lane leave 3 wavefronts per SIMD = 12 per CU
     int wg_per_cu = std::min<int>(12, (int)(160 * 1024 / (LDBG_LS_FAST * (size_t)block * sizeof(LsElem))));
+    if (img) wg_per_cu = std::min(wg_per_cu, 4);        // the image variant of the kernel keeps one wavefront per SIMD (its state save / restore costs registers)
     if (const char* ev = getenv("LDBG_WG_PER_CU")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(ev)));   // tuning knob
     a.n_slots = std::min<int64_t>(a.n_slots, (int64_t)wg_per_cu * rt::cu_count(graph->device) * block);
     a.n_slots = (a.n_slots / block) * block;
