@@ -118,6 +118,7 @@ LDBG_DEV bool walk_same_store(const LinkStoreDev& ls, const LsSnap* snap) {
 LDBG_DEV bool periodic_check(const WalkArgs& a, StrandState& st, const LinkStoreDev& ls, RunState& rs, LsSnap* snap) {
     rs.choices++;
     if (rs.choices < LDBG_REPEAT_FROM || ls.n > LDBG_SNAP_CAP || !st.cu.has || st.cv.idx < 0 || st.cu.nxt.idx < 0) return false;
+    if (st.cv.copy == 0) return false;       // a state can only recur on a vertex the walk stands on for at least the second time
     const uint64_t sig = walk_signature(st, ls);
     const bool live = rs.anchor_at != 0u && rs.seen_marks == rs.anchor_marks;
     if (live && sig == rs.anchor_sig && ls.n == rs.anchor_n && ls.java_cap == rs.anchor_cap && node_key(st.cv) == rs.anchor_cv && node_key(st.cu.nxt) == rs.anchor_t &&

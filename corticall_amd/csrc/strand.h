@@ -52,6 +52,7 @@ struct WalkArgs {
     unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
     unsigned long long* st_gen;     // diagnostics: [n_strands][2] ticks spent before general steps (prepare + cooperative phases), their number
+    unsigned long long* wave_cat;   // diagnostics: [n_workgroups][8] per wavefront: loop iterations and 100 MHz ticks by kind (table regrowth, run steps, lean runs, general part)
 #ifdef LDBG_LEAN_PROFILE
     unsigned long long* st_prof;
 #endif

@@ -211,7 +211,15 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             }
         }
         const bool running = active && begun && !suspended;
+#ifndef LDBG_HOSTSIM
+        unsigned long long tc0 = 0;
+        if (a.wave_cat) tc0 = __builtin_amdgcn_s_memrealtime();
+#endif
         wave_grow_tables(a, st, running);
+#ifndef LDBG_HOSTSIM
+        unsigned long long tc1 = 0;
+        if (a.wave_cat) tc1 = __builtin_amdgcn_s_memrealtime();
+#endif
         // ---- run step: a whole unbranched stretch at once (runstep.h)
         bool stepped = false;
         if (runs_on && running) {
@@ -222,6 +230,10 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
                 if (run_step<W>(a, st, ls, rs, ma)) { walk_finish(a, st); active = false; }
             }
         }
+#ifndef LDBG_HOSTSIM
+        unsigned long long tc2 = 0;
+        if (a.wave_cat) tc2 = __builtin_amdgcn_s_memrealtime();
+#endif
         const bool lean = running && active && !stepped && lean_ok(a, st) && !(runs_on && run_entry_a(a.e, st, rs));
         if (lean) {
             // a short run of lean steps without going round the outer loop (its ballots, refill and regrowth checks): every lean
@@ -233,7 +245,18 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             rs.seen_marks += st.vt.used - used0;
             st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
+#ifndef LDBG_HOSTSIM
+        if (a.wave_cat && threadIdx.x == 0) {
+            const unsigned long long tc3 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* wc = a.wave_cat + 8 * blockIdx.x;
+            wc[0] += 1; wc[1] += tc1 - tc0; wc[2] += tc2 - tc1; wc[3] += tc3 - tc2;
+        }
+#endif
         if (wave_ballot(running && active && !lean && !stepped) == 0ull) continue;          // the whole wavefront took a lean or a run step (or waits for rows)
+#ifndef LDBG_HOSTSIM
+        unsigned long long tc4 = 0;
+        if (a.wave_cat) tc4 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifndef LDBG_HOSTSIM
         const unsigned long long t_general = a.st_gen ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
@@ -255,6 +278,9 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             if (!ended && a.snap && pre.choice_done && st.status == ST_OK) ended = periodic_check(a, st, ls, rs, a.snap + (size_t)slot * LDBG_SNAP_CAP);
             if (ended) { walk_finish(a, st); active = false; }
         }
+#ifndef LDBG_HOSTSIM
+        if (a.wave_cat && threadIdx.x == 0) { unsigned long long* wc = a.wave_cat + 8 * blockIdx.x; wc[4] += 1; wc[5] += __builtin_amdgcn_s_memrealtime() - tc4; }
+#endif
     }
     if constexpr (IMG) {
         StrandSave& sv = a.save[slot];
@@ -1043,7 +1069,7 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
     a.ls = (LsElem*)d_ls_; a.ecap = ecap_;
     a.snap = getenv("LDBG_NO_REPEAT") ? nullptr : (LsSnap*)d_snap_;
 
-    a.wg_times = nullptr; a.st_times = nullptr; a.st_gen = nullptr;
+    a.wg_times = nullptr; a.st_times = nullptr; a.st_gen = nullptr; a.wave_cat = nullptr;
     const bool want_times = r.want_times = getenv("LDBG_WG_TIMES") != nullptr && !img;
     // one (partial) wavefront per workgroup; every workgroup must be resident (lanes refill from the strand queue):
     // LDBG_LS_FAST x block x 24 B of LDS each, at most 32 wavefronts per CU
@@ -1064,6 +1090,7 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
         a.wg_times = (unsigned long long*)rt::dmalloc((size_t)grid * 16); rt::dmemset(a.wg_times, 0, (size_t)grid * 16, s);
         a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
         a.st_gen = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_gen, 0, (size_t)ns * 16, s);
+        a.wave_cat = (unsigned long long*)rt::dmalloc((size_t)grid * 64); rt::dmemset(a.wave_cat, 0, (size_t)grid * 64, s);
 #ifdef LDBG_LEAN_PROFILE
         a.st_prof = (unsigned long long*)rt::dmalloc((size_t)ns * 32); rt::dmemset(a.st_prof, 0, (size_t)ns * 32, s);
 #endif
@@ -1141,6 +1168,21 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
         fprintf(stderr, "[ldbg] k_walk workgroups=%d start ms p0/p50/p90/p100 = %.2f %.2f %.2f %.2f ; end ms p0/p50/p90/p100 = %.2f %.2f %.2f %.2f\n",
                 grid, ss[0], ss[grid / 2], ss[grid * 9 / 10], ss[grid - 1], ee[0], ee[grid / 2], ee[grid * 9 / 10], ee[grid - 1]);
         rt::dfree(a.wg_times);
+        {
+            std::vector<unsigned long long> wc((size_t)grid * 8);
+            rt::d2h(wc.data(), a.wave_cat, (size_t)grid * 64, s);
+            rt::stream_sync(s);
+            rt::dfree(a.wave_cat);
+            unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int slowest = 0;
+            for (int i = 0; i < grid; i++) { for (int q = 0; q < 8; q++) sum[q] += wc[8 * i + q]; if (en[i] > en[slowest]) slowest = i; }
+            auto line = [&](const char* who, const unsigned long long* w, double div) {
+                fprintf(stderr, "[ldbg] %s: %.0f loop iterations; table regrowth %.2f ms, run steps %.2f ms, lean runs %.2f ms; %.0f with a general part, %.2f ms (%.1f us each)\n", who,
+                        w[0] / div, w[1] / 1e5 / div, w[2] / 1e5 / div, w[3] / 1e5 / div, w[4] / div, w[5] / 1e5 / div, w[4] ? w[5] / 100.0 / w[4] : 0.0);
+            };
+            line("average wavefront", sum, (double)grid);
+            line("slowest wavefront", &wc[8 * (size_t)slowest], 1.0);
+        }
         std::vector<unsigned long long> tt((size_t)ns * 2);
         rt::d2h(tt.data(), a.st_times, (size_t)ns * 16, s);
         rt::stream_sync(s);
