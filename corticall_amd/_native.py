@@ -66,7 +66,7 @@ EXPORTS = [
     "ldbg_image_create", "ldbg_image_destroy", "ldbg_image_graph", "ldbg_image_row_bytes", "ldbg_image_clear", "ldbg_image_request", "ldbg_image_reset_requests", "ldbg_image_bucket",
     "ldbg_image_serve", "ldbg_image_insert", "ldbg_image_lookup", "ldbg_image_counters",
     "ldbg_engine_sharded_walk_begin", "ldbg_engine_sharded_walk_round", "ldbg_engine_sharded_walk_finish", "ldbg_engine_sharded_dfs_batch",
-    "ldbg_links_open", "ldbg_links_close", "ldbg_links_info", "ldbg_links_sample_name", "ldbg_links_get",
+    "ldbg_links_open", "ldbg_links_close", "ldbg_links_index", "ldbg_links_source", "ldbg_links_info", "ldbg_links_sample_name", "ldbg_links_get",
     "ldbg_engine_config_default", "ldbg_engine_create", "ldbg_engine_destroy",
     "ldbg_engine_walk_batch", "ldbg_engine_walk_batch_run", "ldbg_engine_walk_batch_fetch", "ldbg_engine_walk_vertices", "ldbg_engine_walk_roi_hits",
     "ldbg_engine_dfs_batch", "ldbg_dfs_result_sizes", "ldbg_dfs_result_get", "ldbg_dfs_result_walk", "ldbg_dfs_result_free",

@@ -291,6 +291,10 @@ ldbg_status ldbg_links_open(const char* path, const ldbg_graph* g, ldbg_links** 
     return guard([&] { *out = nullptr; *out = new ldbg_links(path, g->g); });
 }
 ldbg_status ldbg_links_close(ldbg_links* l) { return guard([&] { delete l; }); }
+ldbg_status ldbg_links_index(const char* in_path, const char* out_path, const char* source, int64_t* num_records) {
+    return guard([&] { const int64_t n = links_index_file(in_path, out_path, source ? source : ""); if (num_records) *num_records = n; });
+}
+ldbg_status ldbg_links_source(const ldbg_links* l, char* buf, int buflen) { return guard([&] { snprintf(buf, buflen, "%s", l->l.source().c_str()); }); }
 ldbg_status ldbg_links_info(const ldbg_links* l, int* version, int* num_colors, int* k, int64_t* nkg, int64_t* nkl, int64_t* nl) {
     return guard([&] {
         if (version) *version = l->l.version;

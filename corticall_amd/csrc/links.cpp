@@ -139,6 +139,153 @@ std::vector<std::string> split_fields(const std::string& s, bool commas) {
     return out;
 }
 
+// ---- BGZF (a series of gzip members of at most 64 KB, each carrying its compressed size in a "BC" extra field; SAM specification
+// §4.1) — the container of an indexed link file (.ctp.bgz): a virtual offset = compressed offset of a block << 16 | offset inside
+// its uncompressed data.  The reference reads and writes it through htsjdk's BlockCompressedInput/OutputStream.
+struct BgzfWriter {
+    FILE* f;
+    std::string buf;                 // uncompressed bytes of the block being filled
+    uint64_t block_addr = 0;         // compressed offset of that block
+    static constexpr size_t kBlock = 0xFF00;
+    explicit BgzfWriter(const std::string& path) : f(fopen(path.c_str(), "wb")) {
+        if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "cannot write '" + path + "'");
+    }
+    ~BgzfWriter() { if (f) fclose(f); }
+    uint64_t position() { if (buf.size() >= kBlock) flush(); return (block_addr << 16) | (uint64_t)buf.size(); }   // BlockCompressedOutputStream.getPosition
+    void write(const std::string& d) {
+        size_t o = 0;
+        while (o < d.size()) {
+            const size_t n = std::min(kBlock - buf.size(), d.size() - o);
+            buf.append(d, o, n);
+            o += n;
+            if (buf.size() >= kBlock) flush();
+        }
+    }
+    void flush() { if (!buf.empty()) { put_block(buf); buf.clear(); } }
+    void put_block(const std::string& data) {
+        std::vector<uint8_t> out(compressBound((uLong)data.size()) + 64);
+        z_stream z{};
+        if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw StatusError(LDBG_ERR_CORTEXJDK, "deflateInit2 failed");
+        z.next_in = (Bytef*)data.data(); z.avail_in = (uInt)data.size();
+        z.next_out = out.data() + 18; z.avail_out = (uInt)(out.size() - 26);
+        const int rc = deflate(&z, Z_FINISH);
+        const size_t clen = z.total_out;
+        deflateEnd(&z);
+        if (rc != Z_STREAM_END || clen + 26 > 65536) throw StatusError(LDBG_ERR_CORTEXJDK, "BGZF block does not fit");
+        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(out.data(), hdr, 16);
+        const uint16_t bsize = (uint16_t)(clen + 25);
+        out[16] = (uint8_t)(bsize & 0xff); out[17] = (uint8_t)(bsize >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)data.data(), (uInt)data.size()), isz = (uint32_t)data.size();
+        memcpy(out.data() + 18 + clen, &crc, 4);
+        memcpy(out.data() + 22 + clen, &isz, 4);
+        if (fwrite(out.data(), 1, clen + 26, f) != clen + 26) throw StatusError(LDBG_ERR_CORTEXJDK, "short write");
+        block_addr += clen + 26;
+    }
+    void close() {
+        flush();
+        put_block(std::string());        // the end-of-file marker: an empty block
+        fclose(f); f = nullptr;
+    }
+};
+struct BgzfReader {
+    FILE* f;
+    uint64_t cur_addr = ~0ull, cur_clen = 0;     // the block held in `data`
+    std::string data;
+    explicit BgzfReader(const std::string& path) : f(fopen(path.c_str(), "rb")) {
+        if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to load Cortex links file '" + path + "'");
+    }
+    ~BgzfReader() { if (f) fclose(f); }
+    bool load(uint64_t addr) {
+        if (addr == cur_addr) return true;
+        uint8_t h[18];
+        if (fseeko(f, (off_t)addr, SEEK_SET) != 0 || fread(h, 1, 18, f) != 18) return false;
+        if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C')
+            throw StatusError(LDBG_ERR_CORTEXJDK, "Failed to load links record from disk (not a BGZF block)");
+        const size_t bsize = (size_t)(h[16] | (h[17] << 8)) + 1, clen = bsize - 26;
+        std::vector<uint8_t> c(clen + 8);
+        if (fread(c.data(), 1, clen + 8, f) != clen + 8) throw StatusError(LDBG_ERR_CORTEXJDK, "Failed to load links record from disk (truncated block)");
+        uint32_t isz;
+        memcpy(&isz, c.data() + clen + 4, 4);
+        data.assign(isz, '\0');
+        z_stream z{};
+        if (inflateInit2(&z, -15) != Z_OK) throw StatusError(LDBG_ERR_CORTEXJDK, "inflateInit2 failed");
+        z.next_in = c.data(); z.avail_in = (uInt)clen;
+        z.next_out = (Bytef*)data.data(); z.avail_out = isz;
+        const int rc = isz ? inflate(&z, Z_FINISH) : Z_STREAM_END;
+        inflateEnd(&z);
+        if (rc != Z_STREAM_END) throw StatusError(LDBG_ERR_CORTEXJDK, "Failed to load links record from disk (corrupt block)");
+        cur_addr = addr; cur_clen = bsize;
+        return true;
+    }
+    // BlockCompressedInputStream.seek(virtual offset) + read(len bytes)
+    std::string read(uint64_t voff, size_t len) {
+        std::string out;
+        uint64_t addr = voff >> 16;
+        size_t off = (size_t)(voff & 0xFFFF);
+        while (out.size() < len) {
+            if (!load(addr)) throw StatusError(LDBG_ERR_CORTEXJDK, "Failed to load links record from disk");
+            if (data.empty() && off == 0) throw StatusError(LDBG_ERR_CORTEXJDK, "Failed to load links record from disk (past the end)");
+            const size_t n = std::min(len - out.size(), data.size() - std::min(off, data.size()));
+            out.append(data, off, n);
+            addr += cur_clen; off = 0;
+        }
+        return out;
+    }
+};
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+uint64_t be64(const uint8_t* p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+void put_be32(std::string& o, uint32_t v) { for (int i = 3; i >= 0; i--) o.push_back((char)(v >> (8 * i))); }
+void put_be64(std::string& o, uint64_t v) { put_be32(o, (uint32_t)(v >> 32)); put_be32(o, (uint32_t)v); }
+
+// the LNKIDX file (IndexLinks.java:62-135; read by CortexLinksRandomAccess.java:33-89): big-endian throughout
+struct LinkIndex {
+    int num_colors = 0, k = 0;
+    int64_t num_kmers_in_graph = 0, num_kmers_with_links = 0, link_bytes = 0;
+    std::string source;
+    std::vector<std::string> sample_names;
+    struct Entry { uint64_t voff; uint32_t len; };
+    std::vector<Entry> entries;          // in index order (the TreeMap order of the records' k-mer strings)
+};
+LinkIndex read_link_index(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "IOException: cannot open '" + path + "'");
+    std::vector<uint8_t> b;
+    { uint8_t tmp[1 << 16]; size_t n; while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) b.insert(b.end(), tmp, tmp + n); }
+    fclose(f);
+    size_t p = 0;
+    auto need = [&](size_t n) { if (p + n > b.size()) throw StatusError(LDBG_ERR_CORTEXJDK, "Error in decoding Cortex links index (truncated)"); };
+    LinkIndex ix;
+    need(6 + 4 + 4 + 24 + 4);
+    const std::string magic0((const char*)&b[0], 6);
+    p = 6;
+    ix.num_colors = (int)be32(&b[p]); p += 4;
+    ix.k = (int)be32(&b[p]); p += 4;
+    ix.num_kmers_in_graph = (int64_t)be64(&b[p]); p += 8;
+    ix.num_kmers_with_links = (int64_t)be64(&b[p]); p += 8;
+    ix.link_bytes = (int64_t)be64(&b[p]); p += 8;
+    if (ix.num_colors < 0 || ix.num_colors > 4096 || ix.k <= 0 || ix.num_kmers_with_links < 0) throw StatusError(LDBG_ERR_CORTEXJDK, "Error in decoding Cortex links index");
+    const uint32_t sl = be32(&b[p]); p += 4;
+    need(sl); ix.source.assign((const char*)&b[p], sl); p += sl;
+    for (int c = 0; c < ix.num_colors; c++) {
+        need(4); const uint32_t n = be32(&b[p]); p += 4;
+        need(n); ix.sample_names.emplace_back((const char*)&b[p], n); p += n;
+    }
+    need(6);
+    if (magic0 != std::string((const char*)&b[p], 6)) throw StatusError(LDBG_ERR_CORTEXJDK, "Error in decoding Cortex links index");
+    p += 6;
+    const int W = (ix.k + 31) / 32;
+    for (int64_t i = 0; i < ix.num_kmers_with_links; i++) {
+        need((size_t)8 * W + 12);
+        p += (size_t)8 * W;              // the binary k-mer: the record's own text names it again
+        LinkIndex::Entry e;
+        e.voff = be64(&b[p]); p += 8;
+        e.len = be32(&b[p]); p += 4;
+        ix.entries.push_back(e);
+    }
+    return ix;
+}
+
 }  // namespace
 
 // sets bit `slot` of the link-flags byte of every graph record that has a link record in this set
@@ -175,7 +322,32 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
     // CortexLinks.initialize (CortexLinks.java:16-25): an ".idx" file next to the links file selects the random-access back-end
     // (BGZF is a series of gzip members, so the whole file is read the same way; the index itself is not needed in HBM)
     const bool indexed = [&] { FILE* f = fopen((path + ".idx").c_str(), "rb"); if (f) fclose(f); return f != nullptr; }();
-    std::string text = gunzip_file(path);
+    std::string text;
+    if (indexed) {
+        // CortexLinksRandomAccess (:33-89, 104-118): the header comes from the LNKIDX file, every record is fetched through its BGZF
+        // virtual offset (seek + read of `length` bytes) — here all of them at once, in index order, into the text the parser below
+        // reads (the JSON header of the .ctp.bgz itself is not consulted by the reference's random-access back-end)
+        const LinkIndex ix = read_link_index(path + ".idx");
+        BgzfReader br(path);
+        std::string sn = "[";
+        for (size_t c = 0; c < ix.sample_names.size(); c++) {
+            std::string esc;
+            for (char ch : ix.sample_names[c]) { if (ch == '"' || ch == '\\') esc.push_back('\\'); esc.push_back(ch); }
+            sn += std::string(c ? "," : "") + "{\"colour\":" + std::to_string(c) + ",\"sample\":\"" + esc + "\"}";
+        }
+        sn += "]";
+        size_t n_links = 0;
+        std::string body;
+        for (const auto& en : ix.entries) {
+            const std::string rec = br.read(en.voff, en.len);
+            for (char ch : rec) n_links += ch == '\n';
+            body += rec + "\n";
+        }
+        text = "{\n\"format_version\":4,\"graph\":{\"num_colours\":" + std::to_string(ix.num_colors) + ",\"kmer_size\":" + std::to_string(ix.k) +
+               ",\"num_kmers_in_graph\":" + std::to_string(ix.num_kmers_in_graph) + ",\"colours\":" + sn + "},\"paths\":{\"num_kmers_with_paths\":" +
+               std::to_string(ix.num_kmers_with_links) + ",\"num_paths\":" + std::to_string(n_links) + ",\"path_bytes\":" + std::to_string(ix.link_bytes) + "}\n}\n\n" + body;
+        source_ = ix.source;
+    } else text = gunzip_file(path);
     // header = lines from "{" to "}" (CortexLinksIterable.java:58-67)
     size_t pos = 0;
     auto next_line = [&](std::string& line) -> bool {
@@ -319,6 +491,114 @@ void Links::mark_records(bool clear) {
         rt::stream_sync(g.stream);
         rt::dfree(d_keys);
     }
+}
+
+// IndexLinks (J/commands/index/links/IndexLinks.java:62-135): the records of a link file re-written as a BGZF file, each record's
+// virtual offset and text length in a big-endian LNKIDX file beside it, ordered by the records' k-mer strings
+int64_t links_index_file(const std::string& in_path, const std::string& out_path, const std::string& source) {
+    const std::string text = gunzip_file(in_path);
+    size_t pos = 0;
+    auto next_line = [&](std::string& line) -> bool {
+        if (pos >= text.size()) return false;
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        line.assign(text, pos, e - pos);
+        pos = e + 1;
+        return true;
+    };
+    std::string line, header, comments;
+    bool in_header = false;
+    while (next_line(line)) {
+        if (line == "{") in_header = true;
+        if (in_header) header += line + "\n";
+        if (line == "}") break;
+    }
+    JParser jp{header};
+    const JVal h = jp.parse();
+    const JVal* fv = h.get("formatVersion") ? h.get("formatVersion") : h.get("format_version");
+    if (!fv) throw StatusError(LDBG_ERR_CORTEXJDK, "Cannot parse CortexLinks format version field");
+    const int version = (int)fv->num;
+    if (version != 2 && version != 3 && version != 4) throw StatusError(LDBG_ERR_CORTEXJDK, "Cannot parse CortexLinks format version '" + std::to_string(version) + "'");
+    const JVal* gr = version == 2 ? &h : h.get("graph");
+    const JVal* pa = version == 2 ? &h : h.get("paths");
+    const int num_colors = (int)jnum(gr, version == 2 ? "ncols" : "num_colours"), k = (int)jnum(gr, "kmer_size");
+    const int64_t nkg = jnum(gr, "num_kmers_in_graph"), nkl = jnum(pa, "num_kmers_with_paths"), lb = jnum(pa, "path_bytes");
+    std::vector<std::string> samples;
+    if (const JVal* cols = gr->get("colours")) for (auto& c : cols->arr) { const JVal* sname = c.get("sample"); samples.push_back(sname ? sname->str : ""); }
+    samples.resize((size_t)num_colors);
+    bool have = false;
+    while (next_line(line)) {
+        if (line.empty()) continue;
+        if (line[0] == '#') { comments += line + "\n"; continue; }
+        have = true;
+        break;
+    }
+    BgzfWriter bw(out_path);
+    bw.write(header);                       // getJSONHeader() + "\n" + getComments() + "\n"  (:110-113)
+    bw.write("\n");
+    bw.write(comments);
+    bw.write("\n");
+    std::map<std::string, std::pair<uint64_t, uint32_t>> table;          // TreeMap<CortexByteKmer, (position, length)>
+    for (int64_t r = 0; r < nkl && have; r++) {
+        auto kl = split_fields(line, false);
+        if (kl.size() < 2) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record");
+        const int n = atoi(kl[1].c_str());
+        std::vector<HostJunction> js;
+        for (int i = 0; i < n; i++) {
+            if (!next_line(line)) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record");
+            auto f = split_fields(line, true);
+            const int off = version == 4 ? 2 : 3;
+            if ((int)f.size() < off + num_colors + 1) throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record");
+            HostJunction j;
+            j.is_fw = f[0] == "F";
+            j.num_kmers = version == 4 ? -1 : atoi(f[1].c_str());
+            j.num_junctions = version == 4 ? atoi(f[1].c_str()) : atoi(f[2].c_str());
+            for (int c = 0; c < num_colors; c++) j.cov.push_back(atoi(f[off + c].c_str()));
+            j.junctions = f[off + num_colors];
+            bool dup = false;
+            for (auto& o : js) dup |= junction_eq(o, j);
+            if (!dup) js.push_back(j);
+        }
+        hashset_order(js);                  // CortexLinksRecord.toString iterates its HashSet (:58-74)
+        std::string rec = kl[0] + " " + std::to_string(js.size()) + "\n";
+        for (size_t i = 0; i < js.size(); i++) {
+            rec += std::string(js[i].is_fw ? "F" : "R") + " " + std::to_string(js[i].num_junctions) + " ";
+            for (size_t c = 0; c < js[i].cov.size(); c++) rec += (c ? "," : "") + std::to_string(js[i].cov[c]);
+            rec += " " + js[i].junctions;
+            if (i + 1 < js.size()) rec += "\n";
+        }
+        table[kl[0]] = {bw.position(), (uint32_t)rec.size()};
+        bw.write(rec);
+        bw.write("\n");
+        have = next_line(line);
+        while (have && line.empty()) have = next_line(line);
+    }
+    bw.close();
+    // LNKIDX (:62-95, 122-133)
+    std::string ix = "LNKIDX";
+    put_be32(ix, (uint32_t)num_colors); put_be32(ix, (uint32_t)k);
+    put_be64(ix, (uint64_t)nkg); put_be64(ix, (uint64_t)nkl); put_be64(ix, (uint64_t)lb);
+    put_be32(ix, (uint32_t)source.size()); ix += source;
+    for (auto& sname : samples) { put_be32(ix, (uint32_t)sname.size()); ix += sname; }
+    ix += "LNKIDX";
+    const int W = (k + 31) / 32;
+    for (auto& kv : table) {
+        // new CortexBinaryKmer(byte[]) = the canonical orientation, 2 bits per base, each long byte-reversed (CortexRecord.java:313-334):
+        // written big-endian that is the packed words in little-endian byte order, most significant word first
+        std::vector<uint64_t> w(W), rc(W);
+        std::string rcs(k, 'A');
+        for (int i = 0; i < k; i++) rcs[i] = complement_ascii(std::string(1, kv.first[k - 1 - i]))[0];
+        if ((int)kv.first.size() != k || !ascii_to_words(kv.first.c_str(), k, w.data(), W) || !ascii_to_words(rcs.c_str(), k, rc.data(), W))
+            throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record: bad k-mer '" + kv.first + "'");
+        const std::vector<uint64_t>& cw = std::min(w, rc);
+        for (int i = 0; i < W; i++) ix.append((const char*)&cw[i], 8);
+        put_be64(ix, kv.second.first);
+        put_be32(ix, kv.second.second);
+    }
+    FILE* f = fopen((out_path + ".idx").c_str(), "wb");
+    if (!f || fwrite(ix.data(), 1, ix.size(), f) != ix.size()) { if (f) fclose(f); throw StatusError(LDBG_ERR_CORTEXJDK, "cannot write '" + out_path + ".idx'"); }
+    fclose(f);
+    return (int64_t)table.size();
 }
 
 Links::~Links() {

@@ -58,10 +58,15 @@ public:
     int device = 0;
     int slot = -1;                                   // bit of the probe rows' link-flags byte
     const HostLinksRecord* get(const std::string& kmer_ascii) const;   // containsKey / get
+    const std::string& source() const { return source_; }             // ConnectivityAnnotations.getSource(): the LNKIDX header's, "" without an index
 private:
     const Graph* graph_ = nullptr;
+    std::string source_;
     void mark_records(bool clear);
 };
+
+// IndexLinks: in_path (.ctp / .ctp.gz) -> out_path (BGZF) + out_path.idx; returns the number of records
+int64_t links_index_file(const std::string& in_path, const std::string& out_path, const std::string& source);
 
 // the link sets a traversal may use, merged into one device table
 class MergedLinks {

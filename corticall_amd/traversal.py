@@ -47,7 +47,20 @@ class CortexLinks:
     def getFile(self): return self.path
     def size(self): return self.numKmersWithLinks
     def isEmpty(self): return self.numKmersWithLinks == 0
-    def getSource(self): return "unknown"
+    def getSource(self):
+        """ConnectivityAnnotations.getSource(): the LNKIDX header's source of an indexed file, "unknown" otherwise (:29)"""
+        buf = C.create_string_buffer(4096)
+        self._lib.check(self._d.ldbg_links_source(self._h, buf, 4096))
+        return buf.value.decode() or "unknown"
+
+    @staticmethod
+    def index(in_path, out_path, source="", lib=None):
+        """IndexLinks (J/commands/index/links/IndexLinks.java:62-135): `in_path` (.ctp / .ctp.gz) -> `out_path` (BGZF, conventionally
+        .ctp.bgz) + `out_path`.idx; opening `out_path` then reads through the index.  -> number of records"""
+        lib = lib or _native.default_lib()
+        n = C.c_int64()
+        lib.check(lib.dll.ldbg_links_index(str(in_path).encode(), str(out_path).encode(), str(source).encode(), C.byref(n)))
+        return n.value
 
     def getSampleNameForColor(self, c):
         buf = C.create_string_buffer(4096)

@@ -177,6 +177,12 @@ ldbg_status ldbg_engine_sharded_dfs_batch(struct ldbg_engine* e, ldbg_image* im,
  * CortexLinksIterable.java:49-226 (.ctp.gz text, JSON header v2/3/4).  Bound to a graph for k / device. */
 ldbg_status ldbg_links_open(const char* path, const ldbg_graph* g, ldbg_links** out);
 ldbg_status ldbg_links_close(ldbg_links* l);
+/* IndexLinks: J/commands/index/links/IndexLinks.java:62-135.  The records of a link file (.ctp / .ctp.gz, v2-4) re-written as a BGZF file
+ * (out_path, conventionally .ctp.bgz) with the big-endian LNKIDX index beside it (out_path + ".idx": per record the BGZF virtual offset
+ * and the text length, ordered by k-mer string).  ldbg_links_open on out_path then reads every record through that index, as
+ * CortexLinksRandomAccess does (CortexLinksRandomAccess.java:33-118), with that back-end's record semantics. */
+ldbg_status ldbg_links_index(const char* in_path, const char* out_path, const char* source, int64_t* num_records);
+ldbg_status ldbg_links_source(const ldbg_links* l, char* buf, int buflen);       /* ConnectivityAnnotations.getSource() */
 ldbg_status ldbg_links_info(const ldbg_links* l, int* version, int* num_colors, int* k,
                             int64_t* num_kmers_in_graph, int64_t* num_kmers_with_links, int64_t* num_links);
 ldbg_status ldbg_links_sample_name(const ldbg_links* l, int color, char* buf, int buflen);

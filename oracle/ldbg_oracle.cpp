@@ -620,6 +620,27 @@ CortexLinks::CortexLinks(const std::string& path) {
     json_find_number(header, "num_paths", num_links);
     json_find_number(header, "path_bytes", link_bytes);
     sample_names = json_find_strings(header, "sample");
+    if (indexed) {
+        // CortexLinksRandomAccess.initialize :33-89 takes the header from the LNKIDX file (big-endian), not from the JSON text
+        std::vector<unsigned char> ix;
+        { FILE* f = fopen((path + ".idx").c_str(), "rb"); unsigned char b[4096]; size_t n; while ((n = fread(b, 1, sizeof b, f)) > 0) ix.insert(ix.end(), b, b + n); fclose(f); }
+        auto be32 = [&](size_t p) { return (int64_t)(((uint32_t)ix[p] << 24) | ((uint32_t)ix[p + 1] << 16) | ((uint32_t)ix[p + 2] << 8) | ix[p + 3]); };
+        auto be64 = [&](size_t p) { return (int64_t)(((uint64_t)be32(p) << 32) | (uint64_t)(uint32_t)be32(p + 4)); };
+        if (ix.size() < 42) throw CortexJDKException("Error in decoding Cortex links index");
+        size_t p = 6;
+        num_colors = (int)be32(p); p += 4;
+        k = (int)be32(p); p += 4;
+        num_kmers_in_graph = be64(p); p += 8;
+        num_kmers_with_links = be64(p); p += 8;
+        link_bytes = be64(p); p += 8;
+        const size_t sl = (size_t)be32(p); p += 4;
+        source = std::string((const char*)&ix[p], sl); p += sl;
+        sample_names.clear();
+        for (int c = 0; c < num_colors; c++) { const size_t n = (size_t)be32(p); p += 4; sample_names.emplace_back((const char*)&ix[p], n); p += n; }
+        if (std::string((const char*)&ix[0], 6) != std::string((const char*)&ix[p], 6)) throw CortexJDKException("Error in decoding Cortex links index");
+        version = 4;         // the records are CortexLinksRecord.toString() texts whatever the version of the indexed file was
+        num_links = 0;
+    }
     // skip comments / blank lines  (CortexLinksIterable.java:133-144)
     for (; li < lines.size(); li++) {
         if (lines[li].empty() || lines[li][0] == '#') continue;
@@ -637,8 +658,8 @@ CortexLinks::CortexLinks(const std::string& path) {
             if (indexed) {
                 // CortexLinksRandomAccess -> CortexLinksRecord(byte[]) :17-43: "orientation x coverages junctions" with
                 // numKmers := x and numJunctions := junctions.length() (quirk Q11: another hashCode, another set order)
-                if (version != 4) throw CortexJDKException("indexed link files are version 4 (IndexLinks.java:62-135)");
                 j.num_kmers = std::stoi(f[1]);
+                num_links++;
                 for (int c = 0; c < num_colors; c++) j.coverages.push_back(std::stoi(f[2 + c]));
                 j.junctions = f[2 + num_colors];
                 j.num_junctions = (int)j.junctions.size();

@@ -815,6 +815,51 @@ def _write_ctp(path, version, k, records, two_colours=False):
         f.write("\n".join(lines) + "\n")
 
 
+def _check_link_index(bgz_path, k, recs, two, source, orc):
+    """the LNKIDX file as CortexLinksRandomAccess reads it (CortexLinksRandomAccess.java:33-89): big-endian header between two magic words,
+    then per k-mer (in k-mer string order) the binary k-mer, the BGZF virtual offset and the text length; every record is fetched here
+    through its virtual offset with nothing but zlib (block at offset >> 16, byte offset & 0xFFFF inside its uncompressed data)"""
+    import struct
+    import zlib
+    raw = open(bgz_path + ".idx", "rb").read()
+    assert raw[:6] == b"LNKIDX"
+    ncol, kk, nkg, nkl, lb = struct.unpack(">iiqqq", raw[6:38])
+    assert (ncol, kk, nkg, nkl, lb) == (2 if two else 1, k, 77, len(recs), 99)
+    p = 38
+    (sl,) = struct.unpack(">i", raw[p:p + 4]); p += 4
+    assert raw[p:p + sl].decode() == source; p += sl
+    for c in range(ncol):
+        (n,) = struct.unpack(">i", raw[p:p + 4]); p += 4
+        assert raw[p:p + n].decode() == "s%d" % c; p += n
+    assert raw[p:p + 6] == b"LNKIDX"; p += 6
+    W = (k + 31) // 32
+    bgz = open(bgz_path, "rb").read()
+    assert bgz[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # the BGZF end-of-file marker
+
+    def block(addr):
+        assert bgz[addr:addr + 4] == b"\x1f\x8b\x08\x04" and bgz[addr + 12:addr + 14] == b"BC"
+        bsize = struct.unpack("<H", bgz[addr + 16:addr + 18])[0] + 1
+        return zlib.decompress(bgz[addr + 18:addr + bsize - 8], -15), bsize
+    by_kmer = {km: js for km, js in recs}
+    seen = []
+    for i in range(nkl):
+        words = struct.unpack("<%dQ" % W, raw[p:p + 8 * W]); p += 8 * W
+        voff, ln = struct.unpack(">qi", raw[p:p + 12]); p += 12
+        addr, off = voff >> 16, voff & 0xFFFF
+        text = b""
+        while len(text) < ln:
+            data, bsize = block(addr)
+            text += data[off:off + ln - len(text)]
+            addr, off = addr + bsize, 0
+        lines = text.decode().split("\n")
+        km, n = lines[0].split()
+        assert list(words) == orc.encode_kmer(orc.canonical(km)) and len(lines) == 1 + int(n)
+        want = {(o, len(j), ",".join(str(x) for x in cov), j) for o, _, j, cov in by_kmer[km]}
+        assert {tuple(l.split()) for l in lines[1:]} == {(o, str(n_), c_, j) for o, n_, c_, j in want}
+        seen.append(km)
+    assert p == len(raw) and seen == sorted(by_kmer)                    # TreeMap<CortexByteKmer, ...> order
+
+
 def case_link_formats(orc, lib, tmp):
     """the three header dialects (CortexLinksIterable.java:69-123) and record layouts (:172-226): header fields, record
     lookup in either orientation, junction records in the reference's HashSet order — product vs oracle, then a walk"""
@@ -852,20 +897,25 @@ def case_link_formats(orc, lib, tmp):
             # and the links drive a walk identically
             cs.olinks["s0"], cs.links["s0"] = ol, l
             compare_walks(cs, kmers[:25], trav=[0], links=["s0"], max_len=60)
-            if version == 4:
-                # the same file with an index next to it: CortexLinks picks the random-access back-end, whose records hash
-                # differently (quirk Q11) -> possibly another order of the junction records, same content
-                open(p + ".idx", "wb").write(b"LNKIDX")
-                oli, li = orc.Links(p), CortexLinks(p, cs.g)
-                expi = dict(oli.records())
-                for km, js in recs:
-                    found, got = li.get(km)
-                    assert found and [(x[0], x[3]) for x in got] == [(j[0] == "F", j[1]) for j in expi[km]]
+            # IndexLinks (IndexLinks.java:62-135) on this file: a BGZF copy + the big-endian LNKIDX index; CortexLinks then picks the
+            # random-access back-end (CortexLinksRandomAccess), whose records hash differently (quirk Q11) -> possibly another order of
+            # the junction records, same content.  The index is checked byte by byte against the reference's reader's view of it.
+            pb = str(tmp / ("v%d_%d.ctp.bgz" % (version, int(two))))
+            assert CortexLinks.index(p, pb, "src %d" % version, lib=lib) == len(recs)
+            _check_link_index(pb, k, recs, two, "src %d" % version, orc)
+            oli, li = orc.Links(pb), CortexLinks(pb, cs.g)
+            assert li.getSource() == "src %d" % version and l.getSource() == "unknown"
+            assert (li.numColors, li.kmerSize, li.numKmersInGraph, li.numKmersWithLinks, li.numLinks) == (2 if two else 1, k, 77, len(recs), sum(len(j) for _, j in recs))
+            assert li.getSampleNameForColor(0) == "s0"
+            expi = dict(oli.records())
+            for km, js in recs:
+                for q in (km, orc.revcomp(km)):
+                    found, got = li.get(q)
+                    assert found and [(x[0], x[3]) for x in got] == [(j[0] == "F", j[1]) for j in expi[km]], (version, km, got, expi[km])
                     assert sorted((x[0], x[3]) for x in got) == sorted((j[0] == "F", j[1]) for j in exp[km])
-                cs.olinks["s0"], cs.links["s0"] = oli, li
-                compare_walks(cs, kmers[:25], trav=[0], links=["s0"], max_len=60)
-                os.remove(p + ".idx")
-                li.close()
+            cs.olinks["s0"], cs.links["s0"] = oli, li
+            compare_walks(cs, kmers[:25], trav=[0], links=["s0"], max_len=60)
+            li.close()
             l.close()           # gives the graph's flag bit back: more than 6 link sets pass through this graph
 
 
