@@ -74,7 +74,7 @@ def test_full_size_walks(orc, workload):
     oe = orc.Engine(og, [0], links=[ol], stopper="ContigStopper")
     t0, checked = time.time(), 0
     for i in sample:
-        if time.time() - t0 > 60:
+        if time.time() - t0 > (60 if checked >= 20 else 400):      # (a time budget, but never fewer than 20 walks)
             break
         exp, nv = oe.walk(seeds[i].tobytes().decode())
         assert raw[offs[i]:offs[i + 1]].decode() == exp and wl[i] == nv
@@ -146,7 +146,7 @@ def test_full_size_lookups_and_walks_c2(orc, workload_c2):
     og = orc.Graph(workload_c2 + ".ctx", use_cache=True, tuned=False)
     t0, checked = time.time(), 0
     for i in rng.choice(n, 4000, replace=False):
-        if time.time() - t0 > 40:
+        if time.time() - t0 > (40 if checked >= 500 else 400):
             break
         exp, ecov, eed = og.find(q[i].tobytes().decode())
         assert exp == int(idx[i]), (q[i].tobytes(), exp, int(idx[i]))
@@ -170,7 +170,7 @@ def test_full_size_lookups_and_walks_c2(orc, workload_c2):
     oe = orc.Engine(ogt, [0], stopper="ContigStopper")
     t0, checked = time.time(), 0
     for i in rng.choice(len(seeds), 600, replace=False):
-        if time.time() - t0 > 40:
+        if time.time() - t0 > (40 if checked >= 20 else 400):      # (a time budget, but never fewer than 20 walks)
             break
         exp, nv = oe.walk(seeds[i].tobytes().decode())
         assert raw[offs[i]:offs[i + 1]].decode() == exp and wl[i] == nv
@@ -241,7 +241,7 @@ def test_full_size_dfs_c4(orc, workload):
     oe = orc.Engine(og, [0], links=[ol], stopper="DestinationStopper", direction=orc.FORWARD)
     t0, checked = time.time(), 0
     for i in sample:
-        if time.time() - t0 > 60:
+        if time.time() - t0 > (60 if checked >= 20 else 400):
             break
         r = oe.dfs(seeds[i].tobytes().decode(), [sink[i].tobytes().decode()])
         gi = b1.graph(int(i))
