@@ -26,16 +26,19 @@
 #include <unordered_set>
 
 #include "lscoop.h"
+#include "runstep.h"
 #include "stoppers.h"
 #include "shard.h"
 #include "strand.h"
 
 namespace ldbg {
 
+// log entries that are not vertices carry bit 63 (strand.h: path descriptors); the markers of this log are kind LDBG_PD_MARK
 #define DFS_MARK (1ull << 63)
-#define DFS_OPEN (DFS_MARK | 1ull)
-#define DFS_CLOSE (DFS_MARK | 2ull)
-#define DFS_KMER (DFS_MARK | 3ull)   // the W entries that follow are the packed k-mer of the vertex before (it has no record)
+#define DFS_OPEN (DFS_MARK | ((uint64_t)LDBG_PD_MARK << 60) | 1ull)
+#define DFS_CLOSE (DFS_MARK | ((uint64_t)LDBG_PD_MARK << 60) | 2ull)
+#define DFS_KMER (DFS_MARK | ((uint64_t)LDBG_PD_MARK << 60) | 3ull)   // the 2 W entries that follow are the packed k-mer of the vertex before (it has no record), 32 bits each
+#define DFS_HALF(x) (DFS_MARK | ((uint64_t)LDBG_PD_HALF << 60) | (uint64_t)(uint32_t)(x))
 
 enum : uint8_t { PH_ITER = 0, PH_CHILD = 1, PH_UNDO = 2 };
 
@@ -45,7 +48,8 @@ struct DfsFrame {
     StopState ss;
     uint8_t child[4];                     // child bases in the reference's iteration order
     uint8_t nchild, next, any, adj;
-    uint32_t pad;
+    uint32_t cut;                         // run-index position of the branch's first vertex (LDBG_RUN_NONE: it has none)
+    uint32_t kids_start, pad;             // log position where the children's logs begin
 };
 static_assert(sizeof(DfsFrame) % 8 == 0, "frame layout");
 
@@ -69,6 +73,7 @@ struct DfsLane {
     int64_t sink_lo, sink_hi;
     uint32_t depth, size, nlin, log_start;
     uint32_t undo_pos, undo_left;
+    uint32_t cut;                  // run-index position of this branch's first vertex: it is a piece of its own (runstep.h)
     uint8_t phase;
     bool result, last_prev;
 };
@@ -176,8 +181,62 @@ LDBG_DEV bool log_vertex(const DfsArgs& a, DfsLane<W>& L, const Node& v, const K
     if (!path_append(a.w, st.s, st.pw, pack_vertex(v))) return false;
     if (v.idx < 0) {
         if (!path_append(a.w, st.s, st.pw, DFS_KMER)) return false;
-        for (int i = 0; i < W; i++) if (!path_append(a.w, st.s, st.pw, kmer_word<W>(nk, i))) return false;
+        for (int i = 0; i < W; i++) {
+            const uint64_t w = kmer_word<W>(nk, i);
+            if (!path_append(a.w, st.s, st.pw, DFS_HALF(w)) || !path_append(a.w, st.s, st.pw, DFS_HALF(w >> 32))) return false;
+        }
     }
+    return true;
+}
+
+// ---- the size of a branch's graph once children have been merged into it (Graphs.addGraph :454).  dfs() hands every child
+// currentGraphSize + g.vertexSet().size() (:445), and g has grown by the graphs of the children that returned one before: by the
+// vertices they hold that g did not — siblings do not see each other's `visited`, so two of them can come back with the same
+// vertices.  Only DestinationStopper looks at the graph size (its junction limit), so the count is taken for that rule alone, when a
+// junction that already has a successful child opens another: the DISTINCT vertices among the log entries of the children so far, in
+// a scratch hash set placed behind the log (rare, and as long as the logs it reads).
+LDBG_DEV void path_write(const WalkArgs& a, int64_t s, uint32_t pos, uint64_t v) {
+    a.pool[(uint64_t)a.block_table[s * a.max_blocks + pos / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK + (pos & (LDBG_PATH_BLOCK - 1))] = v;
+}
+template <int W>
+LDBG_DEV bool merged_vertices(const DfsArgs& a, DfsLane<W>& L, uint32_t start, uint32_t& count) {
+    StrandState& st = L.st;
+    const uint32_t end = st.pw.n;
+    uint32_t cap = 64;
+    while (cap < 2u * (end - start)) cap <<= 1;
+    for (uint32_t i = 0; i < cap; i++) if (!path_append(a.w, st.s, st.pw, 0ull)) { st.status = append_failure(a, st); return false; }
+    count = 0;
+    const uint64_t len_mask = 0x7FFFull;
+    for (uint32_t pos = start; pos < end; pos++) {
+        const uint64_t en = path_read(a.w, st.s, pos);
+        uint64_t key;
+        uint32_t len = 1;
+        if (en & DFS_MARK) {
+            if (en == DFS_KMER) { st.status = ST_MERGE_UNSUPPORTED; return false; }
+            if (LDBG_PD_KIND(en) != LDBG_PD_RUN) continue;                     // OPEN, CLOSE, PAD
+            const uint64_t payload = path_read(a.w, st.s, pos + 1);
+            pos++;
+            len = (uint32_t)(en & 0xFFFFFu);
+            // interiors always start at q_2: (first position, copyIndex, direction bits) names the stretch, the longest crossing counts
+            key = DFS_MARK | ((uint64_t)(uint32_t)payload << 15) | (((en >> 20) & 0x7FFFull) << 46) | (((en >> 36) & 3ull) << 61);
+        } else {
+            if (path_idx(en) < 0) { st.status = ST_MERGE_UNSUPPORTED; return false; }
+            key = en;
+        }
+        uint32_t h = (uint32_t)(sig_mix(key) >> 20) & (cap - 1u);
+        while (true) {
+            const uint64_t cur = path_read(a.w, st.s, end + h);
+            if (cur == 0ull) { path_write(a.w, st.s, end + h, (en & DFS_MARK) ? (key | (uint64_t)len) : key); count += len; break; }
+            if (!(en & DFS_MARK)) { if (cur == key) break; }
+            else if ((cur & ~len_mask) == key) {
+                const uint32_t had = (uint32_t)(cur & len_mask);
+                if (len > had) { path_write(a.w, st.s, end + h, key | (uint64_t)len); count += len - had; }
+                break;
+            }
+            h = (h + 1u) & (cap - 1u);
+        }
+    }
+    path_truncate(a.w, st.s, st.pw, end);
     return true;
 }
 
@@ -195,6 +254,7 @@ LDBG_DEV void open_branch(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, con
     st.gV = 0;
     st.cv = av;
     L.nullk = avk;
+    L.cut = av.idx >= 0 && ui_valid(av.ui) ? ui_pos(av.ui) : LDBG_RUN_NONE;     // (Node.ui is 0 where the engine has no run index)
     if (!path_append(a.w, st.s, st.pw, DFS_OPEN) || !log_vertex<W>(a, L, av, avk)) { st.status = append_failure(a, st); return; }
     st.quirk |= av.flip && !av.fj;
     if (e.cursor_on) {                                   // seek(cv.getKmerAsString()) :363-365
@@ -226,6 +286,193 @@ LDBG_DEV bool end_branch(const DfsArgs& a, DfsLane<W>& L, bool success) {
     return false;
 }
 
+// ---- run steps (runstep.h) in a search.  A branch walks through an unbranched stretch exactly as a contig walk does; what differs
+// is that the stopping rule is asked at every vertex, that a branch can end inside a stretch with the search going on elsewhere,
+// and that what a branch added to `visited` is taken out again when it returns.
+//  * every branch's first vertex is a piece of its own (a cut, like the seed of a walk): the branch opens with seek() and a general
+//    step there, and its parents' first vertices stay cut for as long as their `visited` entries are in the table;
+//  * for the rules below, "how many iterations until the rule fires" has a closed form over a stretch (the adjacent-vertex count
+//    is 1 throughout): thresholds on the branch and graph sizes, and the position of a sink in the stretch;
+//  * a branch that ends inside a stretch marks the interior as visited like one that crossed it: the marks are undone at once
+//    (PH_UNDO sees the RUN descriptor) or the strand ends.
+// Rules that look at every vertex (ROI lookups, degrees) run without the index.
+LDBG_HOSTDEV bool dfs_rule_has_closed_form(int stopper) {
+    return stopper == LDBG_STOP_CONTIG || stopper == LDBG_STOP_CYCLE_COLLAPSING_CONTIG || stopper == LDBG_STOP_DESTINATION || stopper == LDBG_STOP_EXPLORATION ||
+           stopper == LDBG_STOP_GAP_CLOSING || stopper == LDBG_STOP_BUBBLE_CLOSING || stopper == LDBG_STOP_VISUALIZATION;
+}
+template <int W>
+LDBG_DEV Piece dfs_piece(const DfsArgs& a, const DfsLane<W>& L, int64_t slot, const Node& v) {
+    const uint32_t pos = ui_pos(v.ui);
+    uint32_t S = pos - ui_dstart(v.ui), E = pos + ui_dend(v.ui);
+    piece_cut(S, E, pos, L.cut);
+    if (E - S + 1u >= LDBG_RUN_MIN)                     // (cuts only shorten a piece)
+        for (uint32_t d = 0; d < L.depth; d++) piece_cut(S, E, pos, LDBG_GLOBAL(const uint32_t, &a.frames[(size_t)slot * a.max_depth + d].cut)[0]);
+    return piece_make(v.ui, v.flip != 0, L.st.fwd, S, E);
+}
+template <int W>
+LDBG_DEV bool dfs_mode_a(const DfsArgs& a, const DfsLane<W>& L, int64_t slot) {
+    const StrandState& st = L.st;
+    if (!lean_cursor_ok(a.w.e, st) || !ui_valid(st.cv.ui) || !ui_valid(st.cu.nxt.ui)) return false;
+    const Piece pc = dfs_piece<W>(a, L, slot, st.cv);
+    if (pc.q != 0u || pc.n < LDBG_RUN_MIN) return false;
+    const Piece pt = dfs_piece<W>(a, L, slot, st.cu.nxt);
+    return pt.S == pc.S && pt.E == pc.E && pt.plus == pc.plus && pt.q == 1u;
+}
+template <int W>
+LDBG_DEV bool dfs_mode_b(const DfsArgs& a, const DfsLane<W>& L, int64_t slot) {
+    const EngineView& e = a.w.e;
+    const StrandState& st = L.st;
+    const Node& cv = st.cv;
+    if (st.status != ST_OK || (e.cursor_on && st.cu.has) || !(e.g.k & 1)) return false;
+    if (cv.idx < 0 || cv.npe || cv.flip != cv.fj || !ui_valid(cv.ui)) return false;
+    const int acopy = cv.copy < 0 ? -cv.copy : cv.copy;
+    if (!(acopy >= vt_count_e(cv.vent) && acopy + 1 <= 32767)) return false;
+    const Piece pc = dfs_piece<W>(a, L, slot, cv);
+    return pc.q == 1u && pc.n >= LDBG_RUN_MIN;
+}
+// Iterations i = 1 .. steps of the loop at :373-481, iteration i standing on q_{q0+i-1} with one adjacent vertex.  keep = the
+// iterations that pass before the rule ends the branch (== steps: it does not, in this stretch); succ: how it ends.
+template <int W>
+LDBG_DEV void dfs_rule_run(const DfsArgs& a, DfsLane<W>& L, const Piece& pc, uint32_t q0, uint32_t steps, uint32_t& keep, bool& succ) {
+    const EngineView& e = a.w.e;
+    StrandState& st = L.st;
+    keep = 0; succ = false;
+    {   // the first iteration as the k-mer-by-k-mer code would take it (these rules keep no state)
+        TravState ts{(int)(L.size + st.gV), (int)L.depth, (int)st.gV, 1, false, st.gV > (uint32_t)e.max_len};
+        StopEval<W> ev(e, a.env, L.sink_lo, L.sink_hi, st.cv, L.nullk);
+        StopState ss = L.ss;
+        if (ev.has_succeeded(ss, ts) || ev.has_failed(ss, ts) || ev.status != ST_OK) return;
+    }
+    // from the second iteration on the branch size is base + i - 1 (connectVertex counts the first pair as two, :494-516)
+    const int64_t base = st.gV == 0 ? 1 : (int64_t)st.gV;
+    int64_t fire = (int64_t)steps + 1;                  // first iteration at which the rule ends the branch
+    bool fire_succ = false;
+    auto threshold = [&](int64_t limit, bool is_succ) {  // the rule fires once the branch size exceeds `limit`
+        const int64_t i = limit - base + 2 < 2 ? 2 : limit - base + 2;
+        if (i < fire) { fire = i; fire_succ = is_succ; }
+    };
+    switch (e.stopper) {
+        case LDBG_STOP_CONTIG: case LDBG_STOP_EXPLORATION: threshold(e.max_len, true); break;
+        case LDBG_STOP_VISUALIZATION: threshold(500, true); break;
+        case LDBG_STOP_BUBBLE_CLOSING: threshold(10000, false); break;
+        case LDBG_STOP_DESTINATION: {
+            threshold(e.max_len, false);
+            // junction depth > 1 + ceil(5 exp(-size / 10^4)) (stoppers.h: destination_junction_limit): the first graph size at which it holds
+            const int d = (int)L.depth;
+            const int64_t s_star = d >= 6 ? 2232 : (d == 5 ? 5109 : (d == 4 ? 9163 : (d == 3 ? 16095 : (d == 2 ? 7451333 : -1))));
+            if (s_star >= 0) threshold(s_star - 1 - (int64_t)L.size, false);     // size + branch size >= s_star
+            for (int64_t t = L.sink_lo; t < L.sink_hi; t++) {                   // a sink in the stretch: the rule succeeds standing on it
+                const uint64_t key = a.env.sink_keys[t];
+                if (key == 0) continue;
+                const uint64_t ui = LDBG_GLOBAL(const uint64_t, e.runs.uinfo)[(key >> 1) - 1];
+                if (!ui_valid(ui)) continue;
+                const uint32_t pos = ui_pos(ui);
+                if (pos < pc.S || pos > pc.E || (((key & 1ull) != 0ull) == ui_orient(ui)) != pc.plus) continue;
+                const int64_t i = (int64_t)(pc.asc ? pos - pc.S : pc.E - pos) - (int64_t)q0 + 1;
+                if (i >= 2 && i <= fire) { fire = i; fire_succ = true; }        // (<=: has_succeeded is asked first)
+            }
+            break;
+        }
+        default: break;                                  // CycleCollapsingContig, GapClosing: nothing changes along a stretch
+    }
+    keep = fire > (int64_t)steps ? steps : (uint32_t)(fire - 1);
+    succ = fire_succ;
+}
+LDBG_DEV bool dfs_run_emit(const WalkArgs& a, StrandState& st, uint32_t len, uint32_t acopy, const Piece& pc) {
+    if (len == 0u) return true;
+    const uint32_t first = pc.asc ? pc.S + 2u : pc.E - 2u;        // interior vertices q_2 ..; the piece's start rides along for PH_UNDO
+    return path_append_pair(a, st.s, st.pw, pd_run_head(len, acopy, pc.asc, !pc.plus), (uint64_t)first | ((uint64_t)pc.S << 32));
+}
+// 0: not taken (the iteration is left to dfs_step); 1: taken; 2: taken and the strand has ended
+template <int W>
+LDBG_DEV int dfs_run_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t slot, bool mode_a) {
+    const EngineView& e = a.w.e;
+    StrandState& st = L.st;
+    const bool fwd = st.fwd;
+    Node& cv = st.cv;
+    const Piece pc = dfs_piece<W>(a, L, slot, cv);
+    const uint32_t n = pc.n, nB = n - 4u;
+    const bool inv = !pc.plus;
+    const uint32_t steps = mode_a ? n - 2u : n - 3u;
+    uint32_t keep; bool succ;
+    dfs_rule_run<W>(a, L, pc, mode_a ? 0u : 1u, steps, keep, succ);
+    if (keep == 0u) return 0;
+    const bool full = keep >= steps;
+    const uint32_t k = full ? steps : keep;
+    Node y, z;
+    run_vertex(e, st.vt, pc.asc ? pc.E - 1u : pc.S + 1u, inv, fwd, y);
+    run_vertex(e, st.vt, pc.asc ? pc.E : pc.S, inv, fwd, z);
+    uint64_t eB = 0;
+    const uint64_t kB = piece_key(pc);
+    const uint32_t hB = vt_hash(kB) & st.vt.mask;
+    const uint32_t slotB = vt_probe_from(st.vt, kB, hB, vt_peek(st.vt, hB), &eB);
+    const int cntB = vt_count_e(eB), cntY = vt_count_e(y.vent);
+    const uint32_t base = st.gV == 0u ? 1u : st.gV;
+    const int acv = cv.copy < 0 ? -cv.copy : cv.copy;
+    if (mode_a) {
+        // iterations i = 1 .. n-2: cursor onto t = q_i with q_{i+1} looked up, av = q_i, visited.add(q_{i-1}), the rule on q_{i-1}
+        Node& t = st.cu.nxt;
+        const uint32_t ep = st.cu.epoch;
+        const int cntT = vt_count_e(t.vent);
+        const bool seenB = vt_seen_e(eB, ep), seenY = vt_seen_e(y.vent, ep), seenZ = vt_seen_e(z.vent, ep);
+        bool odd = false;
+        if (ls.n == 0u) odd = seenB || (seenY && k >= n - 3u);                 // the cursor would run out inside the piece
+        odd = odd || (k >= 2u && cntT + 1 > 32767) || (k >= 3u && cntB + 1 > 32767);
+        if (odd) { st.status = ST_RETRY_PLAIN; return 2; }
+#ifdef LDBG_HOSTSIM
+        ls_debug().runs_a++; ls_debug().run_vertices += k;
+#endif
+        if (ls_num_new(ls) > 0) ls_increment_ages(ls);                         // :274-276, first step; nothing is new afterwards
+        st.iters += k;
+        Node tv = t;
+        tv.copy = fwd ? cntT : -cntT;
+        bool ok = path_append(a.w, st.s, st.pw, pack_vertex(tv));
+        ok = ok && dfs_run_emit(a.w, st, k - 1u < nB ? k - 1u : nB, (uint32_t)cntB, pc);
+        if (full) { y.copy = fwd ? cntY : -cntY; ok = ok && path_append(a.w, st.s, st.pw, pack_vertex(y)); }
+        if (!ok) { st.status = append_failure(a, st); return 2; }
+        st.gV = base + k;
+        L.nlin += k;
+        L.last_prev = false;
+        node_store(st.vt, cv, vt_with_count(cv.vent, acv + 1));
+        node_store(st.vt, t, vt_with_count(t.vent, cntT + 1));
+        if (!full) {
+            // iteration k + 1 ends the branch standing on q_k: visited.add(q_0 .. q_k), nothing connected
+            st.iters += 1u;
+            if (k >= 2u) LDBG_GLOBAL(uint64_t, st.vt.tab)[slotB] = vt_with_count(eB, cntB + 1);
+            return end_branch<W>(a, L, succ) ? 2 : 1;
+        }
+        // visited.add(q_0 .. q_{n-3}); seen.add(q_2 .. q_{n-1})
+        uint64_t nb = vt_with_count(eB, cntB + 1);
+        if (!seenB) nb = vt_with_seen(nb, ep);
+        LDBG_GLOBAL(uint64_t, st.vt.tab)[slotB] = nb;
+        if (!seenY) node_store(st.vt, y, vt_with_seen(y.vent, ep));
+        if (!seenZ) node_store(st.vt, z, vt_with_seen(z.vent, ep));
+        st.cu.has = !seenZ || ls.n > 0u;                                      // :262
+        if (st.cu.has) st.cu.nxt = z;
+        cv = y;
+        st.cu.cur = cv;
+        return 1;
+    }
+    // without the cursor: iterations j = 1 .. n-3 on cv = q_j whose only neighbour q_{j+1} has not been visited.  A visited interior or
+    // far fringe under an unvisited q_1 takes a branch that started inside the stretch — those are cut out — so it is not expected
+    if (cntB > 0 || cntY > 0) { st.status = ST_RETRY_PLAIN; return 2; }
+#ifdef LDBG_HOSTSIM
+    ls_debug().runs_b++; ls_debug().run_vertices += k;
+#endif
+    st.iters += k + (full ? 0u : 1u);
+    bool ok = dfs_run_emit(a.w, st, k < nB ? k : nB, 0u, pc);
+    if (full) { y.copy = 0; ok = ok && path_append(a.w, st.s, st.pw, pack_vertex(y)); }
+    if (!ok) { st.status = append_failure(a, st); return 2; }
+    st.gV = base + k;
+    L.nlin += k;
+    L.last_prev = false;
+    node_store(st.vt, cv, vt_with_count(cv.vent, acv + 1));
+    LDBG_GLOBAL(uint64_t, st.vt.tab)[slotB] = vt_with_count(eB, 1);
+    if (!full) return end_branch<W>(a, L, succ) ? 2 : 1;                      // iteration k + 1 ends the branch on q_{k+1}
+    cv = y;
+    return 1;
+}
+
 // one micro-step; returns true when the strand has ended
 template <int W>
 LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t slot, const StepPre& pre, bool lean) {
@@ -239,7 +486,21 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
     if (L.phase == PH_UNDO) {
         if (L.undo_left > 0) {
             const uint64_t en = path_read(a.w, st.s, L.undo_pos);
-            if (en == DFS_KMER) { L.undo_pos += 1 + W; return false; }
+            if (en == DFS_KMER) { L.undo_pos += 1 + 2 * W; return false; }
+            if (en & DFS_MARK) {
+                if (LDBG_PD_KIND(en) == LDBG_PD_RUN) {       // a stretch crossed in one step (dfs_run_step): its interior is one table entry
+                    const uint64_t payload = path_read(a.w, st.s, L.undo_pos + 1);
+                    const uint32_t len = (uint32_t)(en & 0xFFFFFu);
+                    const uint64_t key = (1ull << 33) | ((payload >> 32) << 1) | (((en >> 37) & 1ull) ? 0ull : 1ull);   // runstep.h: piece_key
+                    uint64_t ev = 0;
+                    const uint32_t h0 = vt_hash(key) & st.vt.mask;
+                    const uint32_t h = vt_probe_from(st.vt, key, h0, vt_peek(st.vt, h0), &ev);
+                    LDBG_GLOBAL(uint64_t, st.vt.tab)[h] = vt_with_count(ev, vt_count_e(ev) - 1);
+                    L.undo_left -= len < L.undo_left ? len : L.undo_left;
+                    L.undo_pos += 2;
+                } else L.undo_pos++;                          // (a PAD before a pair that would have straddled two blocks)
+                return false;
+            }
             L.undo_pos++;
             L.undo_left--;
             const int64_t idx = path_idx(en);
@@ -256,7 +517,7 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
         DfsFrame& F = a.frames[(size_t)slot * a.max_depth + L.depth];
         if (L.result) F.any = 1;
         st.cv = F.cv; st.gV = F.gV;
-        L.nlin = F.nlin; L.log_start = F.log_start; L.size = F.size; L.ss = F.ss;
+        L.nlin = F.nlin; L.log_start = F.log_start; L.size = F.size; L.ss = F.ss; L.cut = F.cut;
         L.last_prev = false;
         L.phase = PH_CHILD;
         return false;
@@ -273,7 +534,12 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
 #pragma unroll
             for (int i = 0; i < W; i++) avk.w[i] = 0;
             if (av.idx < 0) avk = child_kmer<W>(e, F.cv, fwd, b);
-            const uint32_t size = F.size + F.gV;
+            uint32_t size = F.size + F.gV;
+            if (F.any && e.stopper == LDBG_STOP_DESTINATION) {      // g has grown by the graphs of the children before this one (merged_vertices)
+                uint32_t merged = 0;
+                if (!merged_vertices<W>(a, L, F.kids_start, merged)) return true;
+                size = F.size + (F.gV ? F.gV : 1u) + merged;
+            }
             L.depth++;
             open_branch<W>(a, L, ls, av, avk, size);
             if (st.cv.npe && st.status == ST_OK) st.status = ST_NULLPTR;
@@ -358,8 +624,8 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
         }
         // a junction (or a dead end the rule wants to look beyond): children in the reference's order :441-468
         DfsFrame& F = a.frames[(size_t)slot * a.max_depth + L.depth];
-        F.cv = cv; F.log_start = L.log_start; F.size = L.size; F.gV = st.gV; F.nlin = L.nlin; F.ss = L.ss;
-        F.next = 0; F.any = 0; F.adj = (uint8_t)adj;
+        F.cv = cv; F.log_start = L.log_start; F.size = L.size; F.gV = st.gV; F.nlin = L.nlin; F.ss = L.ss; F.cut = L.cut;
+        F.next = 0; F.any = 0; F.adj = (uint8_t)adj; F.kids_start = st.pw.n;
         F.nchild = adj > 0 ? (uint8_t)order_children<W>(a, st.vt, cv, fwd, avs_mask, F.child) : 0;
         L.phase = PH_CHILD;
         return false;
@@ -424,6 +690,7 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
     // over an image (image.h): a search that needs a row that has not been sent yet suspends for the rest of this launch; the one a
     // lane was working on when the previous round ended is taken up again
     bool suspended = false, begun = true;
+    const bool runs_on = a.w.e.runs.uinfo != nullptr;
     DfsSave<W>* save = (DfsSave<W>*)a.lane_save;
     if constexpr (IMG) {
         const DfsSave<W>& sv = save[slot];
@@ -494,12 +761,25 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
         }
         const bool running = active && begun && !suspended;
         wave_grow_tables(a.w, L.st, running);
-        const bool lean = running && L.phase == PH_ITER && lean_cursor_ok(a.w.e, L.st);
-        const bool cur_mode = running && !lean && L.st.status == ST_OK && L.phase == PH_ITER && a.w.e.cursor_on && L.st.cu.has;
+        // a whole unbranched stretch in one step (dfs_run_step)
+        bool stepped = false;
+        if (!IMG && runs_on && running && L.phase == PH_ITER && L.st.status == ST_OK && L.st.iters <= a.iter_limit &&
+            (L.st.vt.used + 8) * 4 <= (L.st.vt.mask + 1) * 3) {
+            const bool ma = dfs_mode_a<W>(a, L, slot);
+            const bool mb = !ma && dfs_mode_b<W>(a, L, slot);
+            if (ma || mb) {
+                const int r = dfs_run_step<W>(a, L, ls, slot, ma);
+                stepped = r != 0;
+                if (r == 2) { strand_finish(a.w, L.st); active = false; }
+            }
+        }
+        const bool stepping = running && !stepped;
+        const bool lean = stepping && L.phase == PH_ITER && lean_cursor_ok(a.w.e, L.st);
+        const bool cur_mode = stepping && !lean && L.st.status == ST_OK && L.phase == PH_ITER && a.w.e.cursor_on && L.st.cu.has;
         StepPre pre;
         pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0; pre.has_child = false;
-        if (wave_ballot(running && !lean) != 0ull) coop_step_prepare<W>(a.w.e, L.st, ls, lw, cur_mode, pre);
-        if (running && dfs_step<W>(a, L, ls, slot, pre, lean)) { strand_finish(a.w, L.st); active = false; }
+        if (wave_ballot(stepping && !lean) != 0ull) coop_step_prepare<W>(a.w.e, L.st, ls, lw, cur_mode, pre);
+        if (stepping && dfs_step<W>(a, L, ls, slot, pre, lean)) { strand_finish(a.w, L.st); active = false; }
     }
     if constexpr (IMG) {
         DfsSave<W>& sv = save[slot];
@@ -672,15 +952,17 @@ struct LogParser {
         else {
             if (pos >= n || log[pos] != DFS_KMER) throw StatusError(LDBG_ERR_HIP, "dfs log: a vertex without a record lacks its k-mer");
             pos++;
-            std::string s((const char*)(log + pos), (size_t)W * 8);
+            std::vector<uint64_t> kw((size_t)W);
+            for (int i = 0; i < W; i++) kw[(size_t)i] = (log[pos + 2 * i] & 0xFFFFFFFFull) | ((log[pos + 2 * i + 1] & 0xFFFFFFFFull) << 32);
+            std::string s((const char*)kw.data(), (size_t)W * 8);
             auto it = null_ids.find(s);
             uint32_t id;
             if (it == null_ids.end()) {
                 id = (uint32_t)null_kmers.size();
-                null_kmers.emplace_back(log + pos, log + pos + W);
+                null_kmers.push_back(kw);
                 null_ids.emplace(s, id);
             } else id = it->second;
-            pos += W;
+            pos += 2 * W;
             v.id = DFS_MARK | id;
         }
         return v;
@@ -912,6 +1194,11 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     a.w.ls = (LsElem*)d_ls_; a.w.ecap = ecap_;
     a.w.strand_c = nullptr; a.w.retry = nullptr; a.w.snap = nullptr;
     a.w.unfinished = d_ctr + 4;
+    // unbranched stretches in one step (dfs_run_step), for the rules that allow it and over a resident table
+    if (!sharded && dfs_rule_has_closed_form(view.stopper)) {
+        ensure_run_index();
+        if (runs_) a.w.e.runs = runs_->view;
+    }
     if (sharded) {
         if (rois) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs over a sharded table: stopping rules that consult a ROI graph are not routed yet");
         a.w.img_on = 1;
@@ -961,8 +1248,26 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             }
         }
     };
-    if (!sharded) launch(s);
-    else {
+    if (!sharded) {
+        launch(s);
+        if (a.w.e.runs.uinfo) {
+            // a search the run steps handed back (ST_RETRY_PLAIN: cases they leave to the k-mer-by-k-mer code) sends the chunk round again without the index
+            std::vector<uint32_t> st0((size_t)ns);
+            rt::d2h(st0.data(), d_status, (size_t)ns * 4, s);
+            unsigned long long c0[4] = {0, 0, 0, 0};
+            rt::d2h(c0, d_ctr, 32, s);
+            rt::stream_sync(s);
+            bool again = false;
+            for (int64_t i = 0; i < ns; i++) again |= st0[(size_t)i] == ST_RETRY_PLAIN;
+            if (again) {
+                vpool_dirty_ = c0[2];
+                zero_dirty_tables(s);
+                rt::dmemset(d_ctr, 0, 64, s);
+                a.w.e.runs = RunIndexView{nullptr, nullptr, nullptr};
+                launch(s);
+            }
+        }
+    } else {
         // bulk-synchronous rounds (image.h): every search runs until it needs a row that is not in the image; the caller's callback
         // carries the requests to their owners and the rows back, and says when no rank has a search left
         rt::stream_sync(s);
@@ -988,6 +1293,14 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     profile_add("dfs", rt::Event::elapsed_ms(e0, e1));
 
     if (getenv("LDBG_DEBUG_STATUS")) { fprintf(stderr, "[ldbg] dfs statuses:"); for (int64_t i = 0; i < ns && i < 64; i++) fprintf(stderr, " %u/%u/%u", status[i], strand_n[i], iters[i]); fprintf(stderr, " ctr %llu %llu %llu\n", ctr[0], ctr[1], ctr[2]); }
+    if (getenv("LDBG_DFS_HIST")) {      // diagnostics: how the loop iterations are spread over the searches (the longest one bounds the launch)
+        std::vector<uint32_t> it(iters);
+        std::sort(it.begin(), it.end());
+        unsigned long long tot = 0;
+        for (uint32_t v : it) tot += v;
+        fprintf(stderr, "[ldbg] dfs iterations: total %llu  median %u  p90 %u  p99 %u  p99.9 %u  max %u  (kernel %.1f ms)\n", tot, it[(size_t)ns / 2], it[(size_t)(ns * 0.9)],
+                it[(size_t)(ns * 0.99)], it[(size_t)(ns * 0.999)], it[(size_t)ns - 1], rt::Event::elapsed_ms(e0, e1));
+    }
     for (int64_t i = 0; i < ns; i++) if (status[i] == ST_POOL_FULL) return false;
     // errors the reference raises as exceptions abort the call (first seed in input order)
     for (int64_t i = 0; i < ns; i++) {
@@ -1000,6 +1313,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             case ST_LOG_FULL: throw StatusError(LDBG_ERR_CAPACITY, "LOG_FULL");
             case ST_TABLE_FULL: throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs outgrew the per-seed visited table or its step limit (a rule that never stops on a cycle spins in the reference too)" + where);
             case ST_COPY_OVERFLOW: throw StatusError(LDBG_ERR_UNSUPPORTED, "a vertex was visited more than 32767 times in one branch chain" + where);
+            case ST_MERGE_UNSUPPORTED: throw StatusError(LDBG_ERR_UNSUPPORTED, "DestinationStopper: a junction with several successful children whose graphs hold vertices without records is not supported" + where);
             default: break;
         }
     }
@@ -1009,9 +1323,16 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_phase = now();
 
-    // dense logs -> host
+    // dense logs -> host: the stored logs with their RUN descriptors expanded (walk.cpp: k_expand_paths)
+    std::vector<uint32_t> dense_n((size_t)ns);
+    {
+        uint32_t* d_len = (uint32_t*)tmp.get((size_t)ns * 4);
+        launch_path_lengths(d_strand_n, ns, max_blocks, d_len);
+        rt::d2h(dense_n.data(), d_len, (size_t)ns * 4, s);
+        rt::stream_sync(s);
+    }
     std::vector<int64_t> strand_off((size_t)ns + 1, 0);
-    for (int64_t i = 0; i < ns; i++) strand_off[i + 1] = strand_off[i] + strand_n[i];
+    for (int64_t i = 0; i < ns; i++) strand_off[i + 1] = strand_off[i] + dense_n[i];
     const int64_t total = strand_off[ns];
     // page-locked and kept from batch to batch: a pageable vector cost 40 ms to zero and downloaded at 5 GB/s
     if (h_log_cap_ < (size_t)std::max<int64_t>(1, total)) {
@@ -1025,7 +1346,8 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         int64_t* d_off = (int64_t*)tmp.get((size_t)(ns + 1) * 8);
         uint64_t* d_dense = (uint64_t*)tmp.get((size_t)total * 8);
         rt::h2d(d_off, strand_off.data(), (size_t)(ns + 1) * 8, s);
-        launch_compact_paths(d_off, ns, d_dense, max_blocks);
+        unsigned* d_ovf = (unsigned*)tmp.get(4);
+        launch_expand_paths(d_strand_n, d_off, ns, d_dense, max_blocks, a.w.e.runs, d_ovf);
         rt::d2h(log, d_dense, (size_t)total * 8, s);
         rt::stream_sync(s);
     }
@@ -1052,7 +1374,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
                     if (status[sidx] != ST_OK) continue;       // ST_BRANCH_NULL: that direction returned null
                     have[d] = true;
                     if (strand_n[sidx] == 0) continue;
-                    LogParser lp{log + strand_off[sidx], (int64_t)strand_n[sidx], 0, W, color, d == 1, r.null_kmers, null_ids};
+                    LogParser lp{log + strand_off[sidx], (int64_t)dense_n[sidx], 0, W, color, d == 1, r.null_kmers, null_ids};
                     VKey v0;
                     lp.parse_branch(dir_g[d], v0, seed_at[d]);
                 }

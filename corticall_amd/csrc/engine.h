@@ -42,8 +42,9 @@ enum : uint32_t {
     ST_DEPTH_OVERFLOW = 7, // dfs recursion deeper than the frame stack -> host retries with a deeper one
     ST_TABLE_FULL = 8,     // a strand's visited table reached its maximum size
     ST_LOG_FULL = 9,       // a strand's dfs log outgrew its block table -> host retries with a longer one
-    ST_RETRY_PLAIN = 10    // walk kernel: the strand met a case the run steps (runstep.h) leave to the k-mer-by-k-mer code -> the host
+    ST_RETRY_PLAIN = 10,   // the strand met a case the run steps (runstep.h) leave to the k-mer-by-k-mer code -> the host
                            // walks it again without the run index
+    ST_MERGE_UNSUPPORTED = 11   // dfs.cpp: merged_vertices met a vertex without a record
 };
 
 // ---- path entry: one vertex of a branch, 8 bytes

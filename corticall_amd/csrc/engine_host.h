@@ -122,6 +122,11 @@ private:
     bool dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
                    int64_t first, int64_t n, DfsBatch& out, const ShardedRun* sharded);
     void launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks);
+    // stored paths with descriptors (strand.h): entries they expand to per strand, and the expansion (walk.cpp: k_expand_paths)
+    void launch_path_lengths(const uint32_t* d_strand_c, int64_t n_strands, int max_blocks, uint32_t* d_len);
+    void launch_expand_paths(const uint32_t* d_strand_c, const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks, const RunIndexView& runs,
+                             unsigned* d_overflow);
+    void ensure_run_index();           // the run index of this engine's colour masks (runs.h), built on first use
     void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks, uint64_t table_floor = 0);   // table_floor: entries the table pool holds at least
     uint64_t table_floor_ = 0;
     uint64_t* h_log_ = nullptr; size_t h_log_cap_ = 0;   // page-locked landing buffer of the dfs logs (dfs.cpp)

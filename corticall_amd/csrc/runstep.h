@@ -28,20 +28,29 @@ struct Piece {
     uint32_t q, n;      // travel index of the vertex, vertices in the piece
     bool plus, asc;     // the vertex is the chain-orientation member of its record; travel goes towards larger positions
 };
-LDBG_DEV Piece piece_of(uint64_t ui, bool flip, bool fwd, uint32_t seed_pos) {
+// a cut: the vertex at position `cut` is a piece of its own (a walk's seed, the first vertex of a dfs branch)
+LDBG_DEV void piece_cut(uint32_t& S, uint32_t& E, uint32_t pos, uint32_t cut) {
+    if (cut >= S && cut <= E) {                         // (LDBG_RUN_NONE lies in no piece)
+        if (pos < cut) E = cut - 1u;
+        else if (pos > cut) S = cut + 1u;
+        else S = E = pos;
+    }
+}
+LDBG_DEV Piece piece_make(uint64_t ui, bool flip, bool fwd, uint32_t S, uint32_t E) {
     Piece p;
     const uint32_t pos = ui_pos(ui);
-    p.S = pos - ui_dstart(ui); p.E = pos + ui_dend(ui);
-    if (seed_pos >= p.S && seed_pos <= p.E) {           // (seed_pos = LDBG_RUN_NONE lies in no piece)
-        if (pos < seed_pos) p.E = seed_pos - 1u;
-        else if (pos > seed_pos) p.S = seed_pos + 1u;
-        else p.S = p.E = pos;
-    }
+    p.S = S; p.E = E;
     p.plus = flip == ui_orient(ui);
     p.asc = p.plus == fwd;
     p.q = p.asc ? pos - p.S : p.E - pos;
     p.n = p.E - p.S + 1u;
     return p;
+}
+LDBG_DEV Piece piece_of(uint64_t ui, bool flip, bool fwd, uint32_t seed_pos) {
+    const uint32_t pos = ui_pos(ui);
+    uint32_t S = pos - ui_dstart(ui), E = pos + ui_dend(ui);
+    piece_cut(S, E, pos, seed_pos);
+    return piece_make(ui, flip, fwd, S, E);
 }
 // key of a piece's interior in the visited table: bit 33 is never set in a vertex key (engine.h: vt_key)
 LDBG_DEV uint64_t piece_key(const Piece& p) { return (1ull << 33) | ((uint64_t)p.S << 1) | (p.plus ? 1ull : 0ull); }

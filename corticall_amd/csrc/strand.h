@@ -76,6 +76,8 @@ struct WalkArgs {
 #define LDBG_PD_KIND(e) ((unsigned)((e) >> 60) & 7u)
 #define LDBG_PD_RUN 0u
 #define LDBG_PD_REPEAT 1u
+#define LDBG_PD_MARK 2u          // dfs logs (dfs.cpp): OPEN / CLOSE / KMER markers, kept as they are by the expansion
+#define LDBG_PD_HALF 3u          // dfs logs: 32 bits of the k-mer of a vertex without a record (bits 0..31), kept as they are
 #define LDBG_PD_PAD 7u
 LDBG_HOSTDEV uint64_t pd_run_head(uint32_t len, uint32_t acopy, bool asc, bool inv) {
     return LDBG_PD_TAG | ((uint64_t)LDBG_PD_RUN << 60) | (uint64_t)(len & 0xFFFFFu) | ((uint64_t)(acopy & 0xFFFFu) << 20) | ((uint64_t)(asc ? 1 : 0) << 36) | ((uint64_t)(inv ? 1 : 0) << 37);
@@ -84,11 +86,13 @@ LDBG_HOSTDEV uint64_t pd_repeat_head(uint32_t count) { return LDBG_PD_TAG | ((ui
 LDBG_HOSTDEV uint64_t pd_pad() { return LDBG_PD_TAG | ((uint64_t)LDBG_PD_PAD << 60); }
 // vertices an entry stands for, given the entry before it (0 if there is none)
 LDBG_HOSTDEV uint32_t pd_expanded(uint64_t prev, uint64_t e) {
-    if ((prev & LDBG_PD_TAG) && LDBG_PD_KIND(prev) != LDBG_PD_PAD) return 0u;        // e is a payload word
+    if ((prev & LDBG_PD_TAG) && LDBG_PD_KIND(prev) <= LDBG_PD_REPEAT) return 0u;     // e is a payload word
     if (!(e & LDBG_PD_TAG)) return 1u;
     const unsigned kd = LDBG_PD_KIND(e);
-    return kd == LDBG_PD_RUN ? (uint32_t)(e & 0xFFFFFu) : (kd == LDBG_PD_REPEAT ? (uint32_t)e : 0u);
+    return kd == LDBG_PD_RUN ? (uint32_t)(e & 0xFFFFFu) : (kd == LDBG_PD_REPEAT ? (uint32_t)e : ((kd == LDBG_PD_MARK || kd == LDBG_PD_HALF) ? 1u : 0u));
 }
+// is e (not a payload word) the head of a RUN or REPEAT descriptor?
+LDBG_HOSTDEV bool pd_is_head(uint64_t e) { return (e & LDBG_PD_TAG) && LDBG_PD_KIND(e) <= LDBG_PD_REPEAT; }
 
 LDBG_DEV uint64_t pack_vertex(const Node& v) { return path_pack(v.idx, v.flip != 0, v.base, v.copy, v.flip && !v.fj); }
 

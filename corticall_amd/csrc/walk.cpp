@@ -378,7 +378,7 @@ LDBG_KERNEL void k_expand_paths(ExpandArgs a) {
             const uint32_t cnt = j < nc ? pd_expanded(prev, e) : 0u;
             const uint32_t incl = wave_incl_scan_u32(cnt);
             const uint32_t at = base_v + incl - cnt;
-            const bool head = cnt > 0u && (e & LDBG_PD_TAG) != 0ull;
+            const bool head = cnt > 0u && pd_is_head(e);
             if (cnt == 1u && !head) out[at] = e;
             unsigned long long hb = wave_ballot(head);
             while (hb) {
@@ -524,7 +524,7 @@ LDBG_KERNEL void k_contigs_rle(ContigRleArgs a) {
                 const uint32_t cnt = j < nc ? pd_expanded(prev, e) : 0u;
                 const uint32_t incl = wave_incl_scan_u32(cnt);
                 const uint32_t at = base_v + incl - cnt;
-                const bool head = cnt > 0u && (e & LDBG_PD_TAG) != 0ull;
+                const bool head = cnt > 0u && pd_is_head(e);
                 if (cnt == 1u && !head && at >= 1u) o[place(at)] = "ACGT"[path_base(e)];
                 unsigned long long hb = wave_ballot(head);
                 while (hb) {
@@ -751,6 +751,15 @@ void Engine::walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, u
     if (total > capacity) throw StatusError(LDBG_ERR_CAPACITY, "hit buffer too small: need " + std::to_string(total));
 }
 
+void Engine::ensure_run_index() {
+    if (runs_ || getenv("LDBG_NO_RUNS") || !(view.g.k & 1) || graph->is_image) return;
+    runs_.reset(new RunIndex(view, graph->device, graph->stream));
+    profile_add("run_index", runs_->build_ms);
+    if (getenv("LDBG_HOST_TIMES"))
+        fprintf(stderr, "[ldbg] run index: %lld chains hold %lld of %lld records, built in %.1f ms\n", (long long)runs_->n_chains,
+                (long long)runs_->n_in_chains, (long long)view.g.N, runs_->build_ms);
+}
+
 // the dense 8-byte vertex entries of a chunk's walks, expanded from the stored paths the first time they are needed
 void Engine::ensure_dense(WalkChunk& c) {
     if (!c.dense_pending) return;
@@ -774,6 +783,39 @@ void Engine::ensure_dense(WalkChunk& c) {
 }
 // before the path pool is used for something else: the vertex entries of the walks still held
 void Engine::materialize_pending() { for (auto& c : chunks) ensure_dense(c); }
+
+// vertices (and, in a dfs log, markers) the stored entries of every strand stand for
+LDBG_KERNEL void k_path_lengths(const uint64_t* pool, const uint32_t* block_table, int max_blocks, const uint32_t* strand_c, int64_t n_strands, uint32_t* len) {
+    const int64_t wave = global_tid() / wave_size(), nwaves = (global_nthreads() + wave_size() - 1) / wave_size();
+    const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
+    for (int64_t s = wave; s < n_strands; s += nwaves) {
+        const uint32_t nc = strand_c[s];
+        uint32_t total = 0;
+        for (uint32_t j0 = 0; j0 < nc; j0 += WS) {
+            const uint32_t j = j0 + lane;
+            uint32_t cnt = 0;
+            if (j < nc) {
+                const uint64_t* blk = pool + (uint64_t)block_table[s * max_blocks + j / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK;
+                const uint32_t o = j & (LDBG_PATH_BLOCK - 1);
+                cnt = pd_expanded(o ? blk[o - 1] : 0ull, blk[o]);
+            }
+            total += wave_bcast_u32(wave_incl_scan_u32(cnt), (int)WS - 1);
+        }
+        if (lane == 0) len[s] = total;
+    }
+}
+void Engine::launch_path_lengths(const uint32_t* d_strand_c, int64_t n_strands, int max_blocks, uint32_t* d_len) {
+    LDBG_LAUNCH(k_path_lengths, grid_for(n_strands * 64, 64, 256 * 64), 64, graph->stream, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
+                d_strand_c, n_strands, d_len);
+}
+void Engine::launch_expand_paths(const uint32_t* d_strand_c, const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks, const RunIndexView& runs,
+                                 unsigned* d_overflow) {
+    ExpandArgs xa;
+    xa.pool = (const uint64_t*)d_pool_; xa.block_table = (const uint32_t*)d_block_table_; xa.max_blocks = max_blocks;
+    xa.strand_c = d_strand_c; xa.strand_off = d_strand_off; xa.n_strands = n_strands;
+    xa.runs = runs; xa.dense = d_dense; xa.overflow = d_overflow;
+    LDBG_LAUNCH(k_expand_paths, grid_for(n_strands * 64, 64, 256 * 64), 64, graph->stream, xa);
+}
 
 void Engine::launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks) {
     LDBG_LAUNCH(k_compact_paths, grid_for(n_strands * 64, 256, 4096), 256, graph->stream, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
@@ -1010,13 +1052,7 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
 
     laps.lap("small allocations");
     a.e = view;
-    if (!img && !runs_ && !getenv("LDBG_NO_RUNS") && (view.g.k & 1)) {       // the run index of this engine's colour masks (runs.h), built on first use
-        runs_.reset(new RunIndex(view, graph->device, s));
-        profile_add("run_index", runs_->build_ms);
-        if (getenv("LDBG_HOST_TIMES"))
-            fprintf(stderr, "[ldbg] run index: %lld chains hold %lld of %lld records, built in %.1f ms\n", (long long)runs_->n_chains,
-                    (long long)runs_->n_in_chains, (long long)view.g.N, runs_->build_ms);
-    }
+    if (!img) ensure_run_index();
     if (runs_ && !img) a.e.runs = runs_->view;
     a.retry = nullptr;
     a.img_on = img ? 1 : 0;

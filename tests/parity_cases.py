@@ -681,6 +681,61 @@ def case_dfs_rules(orc, lib, tmp, k, seed, with_links):
         g.close()
 
 
+def case_dfs_run_steps(orc, lib, tmp, seed):
+    """searches through long unbranched stretches (csrc/dfs.cpp: dfs_run_step): sinks in the middle of a stretch, on its fringes and
+    nowhere; maxLength, the rules' size limits (VisualizationStopper 500, DestinationStopper's junction limit at graph sizes 2231 /
+    5108) and failing branches ending inside a stretch with the search going on in a sibling; stretches entered again by a child
+    branch after the parent went through them (tandem arrays with links); both directions; with and without the cursor."""
+    rng = random.Random(7000 + seed)
+    k = rng.choice([9, 11, 15, 21])
+    parts = []
+    for _ in range(4):
+        parts.append(rand_seq(rng, rng.randint(300, 1500)))
+        unit = rand_seq(rng, rng.randint(k + 3, 3 * k + 20))
+        parts.append(unit * rng.randint(2, 5))
+        parts.append(rand_seq(rng, rng.randint(100, 900)))
+        inv = rand_seq(rng, rng.randint(k + 5, 3 * k))
+        parts.append(inv + rand_seq(rng, rng.randint(5, 40)) + orc.revcomp(inv))
+    rep = rand_seq(rng, rng.randint(2 * k, 4 * k))
+    g1 = "".join(parts) + rep + rand_seq(rng, 250) + rep + rand_seq(rng, 400)
+    g2 = mutate(rng, g1, snv=0.004, indel=0.0)
+    rl = rng.choice([4 * k, 8 * k])
+    reads = {"a": [g1[i:i + rl] for i in range(0, max(1, len(g1) - rl + 1), max(1, k // 2))] + [g1[-rl:]]}
+    cs = Case(orc, tmp, lib, [("a", [g1]), ("b", [g2])], k, link_samples=["a"], reads=reads, name="drs%d" % seed)
+    pos = {}
+    for i in range(len(g1) - k + 1):
+        pos.setdefault(g1[i:i + k], i)
+    starts = rng.sample(range(len(g1) - k), 50)
+    seeds, sinks = [], []
+    for i in starts:
+        s = g1[i:i + k]
+        d = rng.choice([rng.randint(1, 12), rng.randint(20, 400), rng.randint(400, 3000)])
+        j = min(len(g1) - k, i + d)
+        sk = [g1[j:j + k]]
+        r = rng.random()
+        if r < 0.2:
+            sk = [rand_seq(rng, k)]                          # unreachable: the search fails at its limits
+        elif r < 0.4:
+            sk.append(g1[max(0, i - d):max(0, i - d) + k])   # one ahead, one behind
+        if rng.random() < 0.3:
+            s, sk = orc.revcomp(s), [orc.revcomp(x) for x in sk]
+        seeds.append(s)
+        sinks.append(sk)
+    compare_dfs(cs, seeds[:4], sinks=sinks[:4], trav=[0], stopper="DestinationStopper", links=["a"], max_len=30000)
+    for ml in (5000, 1200):
+        compare_dfs(cs, seeds, sinks=sinks, trav=[0], stopper="DestinationStopper", links=["a"], max_len=ml)
+    compare_dfs(cs, seeds, sinks=sinks, trav=[0], stopper="DestinationStopper", links=["a"], max_len=4000, direction=FORWARD)
+    compare_dfs(cs, seeds, sinks=sinks, trav=[0], stopper="DestinationStopper", max_len=6000)
+    compare_dfs(cs, seeds[:30], sinks=sinks[:30], trav=[0, 1], stopper="DestinationStopper", max_len=3000, direction=FORWARD)
+    compare_dfs(cs, seeds[:30], sinks=sinks[:30], trav=[0, 1], stopper="DestinationStopper", links=["a"], max_len=3000)
+    for stopper in ("ContigStopper", "ExplorationStopper", "VisualizationStopper", "BubbleClosingStopper", "GapClosingStopper"):
+        compare_dfs(cs, seeds[:25], sinks=sinks[:25], trav=[0, 1], stopper=stopper, max_len=rng.choice([700, 2500]))
+    for stopper in ("GapClosingStopper", "BubbleClosingStopper"):
+        compare_dfs(cs, seeds[:25], sinks=sinks[:25], trav=[0], stopper=stopper, max_len=20000)
+    for stopper in ("ContigStopper", "ExplorationStopper", "VisualizationStopper"):
+        compare_dfs(cs, seeds[:25], sinks=sinks[:25], trav=[0], stopper=stopper, links=["a"], max_len=rng.choice([333, 2500, 20000]))
+
+
 def case_dfs_dense(orc, lib, tmp, seed):
     """tiny k: junctions everywhere, deep recursion, many failing branches (visited-set undo, log truncation)"""
     rng = random.Random(1000 + seed)

@@ -51,6 +51,10 @@ def test_dense_cycles(orc, lib, tmp_path, seed): pc.case_dense_cycles(orc, lib, 
 def test_run_steps(orc, lib, tmp_path, seed): pc.case_run_steps(orc, lib, tmp_path, seed)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_dfs_run_steps(orc, lib, tmp_path, seed): pc.case_dfs_run_steps(orc, lib, tmp_path, seed)
+
+
 def test_long_walks(orc, lib, tmp_path): pc.case_long_walks(orc, lib, tmp_path)
 
 
