@@ -1365,6 +1365,54 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             std::vector<uint64_t>& keys = thread_keys[(size_t)t];
             for (int64_t i = lo; i < hi; i++) {
                 DfsGraphHost& r = out.results[(size_t)(first + i)];
+                // the common result: every direction that ran is ONE branch of vertices with records (no junction taken, nothing to merge) —
+                // the graph is the two paths joined at the seed (:75-99), written straight from the logs
+                {
+                    bool flat = true, any_dir = false;
+                    for (int d = 0; d < 2 && flat; d++) {
+                        const int64_t sidx = 2 * i + d;
+                        if (status[sidx] != ST_OK) continue;
+                        any_dir = true;
+                        const uint64_t* lg = log + strand_off[sidx];
+                        const int64_t ln = (int64_t)dense_n[sidx];
+                        if (ln == 0) continue;
+                        flat = ln >= 3 && lg[0] == DFS_OPEN && lg[ln - 1] == DFS_CLOSE;
+                        for (int64_t j = 1; flat && j < ln - 1; j++) flat = !(lg[j] & DFS_MARK) && path_idx(lg[j]) >= 0;
+                    }
+                    const bool null_r0 = !run_r || status[2 * i] != ST_OK, null_f0 = !run_f || status[2 * i + 1] != ST_OK;
+                    if (flat && any_dir && !(op_and ? (null_r0 || null_f0) : (null_r0 && null_f0))) {
+                        r.is_null = false;
+                        int64_t nv = 0;
+                        for (int d = 0; d < 2; d++) if (status[2 * i + d] == ST_OK && dense_n[2 * i + d] > 3) nv += (int64_t)dense_n[2 * i + d] - 2;
+                        r.verts.reserve((size_t)nv);
+                        r.edges.reserve((size_t)nv);
+                        int seed_m = -1;
+                        for (int d = 0; d < 2; d++) {
+                            const int64_t sidx = 2 * i + d;
+                            if (status[sidx] != ST_OK || dense_n[sidx] <= 3) continue;     // (a branch that decided at its first vertex returns an empty graph)
+                            const uint64_t* lg = log + strand_off[sidx] + 1;
+                            const int64_t cnt = (int64_t)dense_n[sidx] - 2;
+                            int prev = -1;
+                            for (int64_t j = 0; j < cnt; j++) {
+                                int at;
+                                if (j == 0 && seed_m >= 0) at = seed_m;
+                                else {
+                                    const uint64_t en = lg[j];
+                                    DfsVertex o;
+                                    o.rec = path_idx(en); o.flip = path_flip(en) ? 1 : 0; o.copy = path_copy(en); o.index = j == 0 ? 0 : (d == 0 ? -1 : 1);
+                                    o.slot = (int64_t)keys.size();
+                                    keys.push_back(((uint64_t)(o.rec + 1) << 1) | (uint64_t)o.flip);
+                                    at = (int)r.verts.size();
+                                    r.verts.push_back(o);
+                                    if (j == 0) seed_m = at;
+                                }
+                                if (j > 0) { if (d == 1) r.edges.push_back({prev, at, color}); else r.edges.push_back({at, prev, color}); }
+                                prev = at;
+                            }
+                        }
+                        continue;
+                    }
+                }
                 std::unordered_map<std::string, uint32_t> null_ids;
                 HGraph dir_g[2];
                 bool have[2] = {false, false};
@@ -1421,28 +1469,10 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         for (auto& er : thread_err) if (!er.empty()) throw StatusError(LDBG_ERR_HIP, er);
     }
     if (want_times) { fprintf(stderr, "[ldbg] dfs host: graph assembly %.1f ms on %d threads\n", ms_since(t_phase), n_threads); t_phase = now(); }
-    // slots were numbered per thread (and per chunk): make them global.  The k-mers and coverages of the vertices are
+    // slots were numbered per thread: a result keeps the offset of its thread's keys among the keys of the batch (its vertices are
+    // renumbered only where the secondary colours below need one contiguous list).  The k-mers and coverages of the vertices are
     // gathered when a result is first read (DfsBatch::materialize): the graphs themselves — record numbers, orientations,
     // copy indices, edges — are complete here.
-    {
-        std::vector<int64_t> base((size_t)n_threads + 1, (int64_t)out.gather_keys.size());
-        for (int t = 0; t < n_threads; t++) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)thread_keys[(size_t)t].size();
-        out.gather_keys.reserve((size_t)base[(size_t)n_threads]);
-        for (int t = 0; t < n_threads; t++) out.gather_keys.insert(out.gather_keys.end(), thread_keys[(size_t)t].begin(), thread_keys[(size_t)t].end());
-        const int64_t per = (n + n_threads - 1) / n_threads;
-        auto shift = [&](int t) {
-            const int64_t off = base[(size_t)t];
-            if (off == 0) return;
-            for (int64_t i = std::min<int64_t>(n, t * per); i < std::min<int64_t>(n, (t + 1) * per); i++)
-                for (auto& o : out.results[(size_t)(first + i)].verts) if (o.rec >= 0) o.slot += off;
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < n_threads; t++) pool.emplace_back(shift, t);
-        shift(0);
-        for (auto& th : pool) th.join();
-    }
-    // ---- TraversalEngine.addSecondaryColors (:108-145): for every secondary colour that is not a traversal colour, the edges
-    // of that colour at every vertex of the combined graph, to neighbours looked up with findRecord (here: the neighbour index)
     std::vector<int> sec_cols;
     for (int c = 0; c < graph->hdr.C; c++) {
         bool sec = false, trav = false;
@@ -1450,9 +1480,31 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         for (int j = 0; j < cfg.n_traversal; j++) trav |= cfg.traversal_colors[j] == c;
         if (sec && !trav) sec_cols.push_back(c);
     }
+    const int64_t base0 = out.n_gather;                  // keys of the chunks before this one
+    std::vector<uint64_t> chunk_keys;                   // (secondary colours only) this chunk's keys in one list
+    {
+        const int64_t per = (n + n_threads - 1) / n_threads;
+        std::vector<int64_t> tbase((size_t)n_threads + 1, 0);
+        for (int t = 0; t < n_threads; t++) tbase[(size_t)t + 1] = tbase[(size_t)t] + (int64_t)thread_keys[(size_t)t].size();
+        if (sec_cols.empty()) {
+            for (int t = 0; t < n_threads; t++) {
+                for (int64_t i = std::min<int64_t>(n, t * per); i < std::min<int64_t>(n, (t + 1) * per); i++) out.results[(size_t)(first + i)].slot_base = base0 + tbase[(size_t)t];
+                out.key_segments.push_back(std::move(thread_keys[(size_t)t]));
+            }
+            out.n_gather += tbase[(size_t)n_threads];
+        } else {
+            chunk_keys.reserve((size_t)tbase[(size_t)n_threads]);
+            for (int t = 0; t < n_threads; t++) {
+                chunk_keys.insert(chunk_keys.end(), thread_keys[(size_t)t].begin(), thread_keys[(size_t)t].end());
+                for (int64_t i = std::min<int64_t>(n, t * per); i < std::min<int64_t>(n, (t + 1) * per); i++)
+                    for (auto& o : out.results[(size_t)(first + i)].verts) if (o.rec >= 0) o.slot += base0 + tbase[(size_t)t];
+            }
+        }
+    }
+    // ---- TraversalEngine.addSecondaryColors (:108-145): for every secondary colour that is not a traversal colour, the edges
+    // of that colour at every vertex of the combined graph, to neighbours looked up with findRecord (here: the neighbour index)
     if (!sec_cols.empty()) {
-        const int64_t base0 = (int64_t)out.gather_keys.size() - [&] { int64_t t = 0; for (auto& v : thread_keys) t += (int64_t)v.size(); return t; }();
-        const int64_t ngk = (int64_t)out.gather_keys.size() - base0;        // this chunk's keys
+        const int64_t ngk = (int64_t)chunk_keys.size();                      // this chunk's keys
         std::vector<uint8_t> redges((size_t)std::max<int64_t>(1, ngk) * C), rflags((size_t)std::max<int64_t>(1, ngk));
         std::vector<uint32_t> rnbr((size_t)std::max<int64_t>(1, ngk) * 8);
         if (ngk > 0) {
@@ -1460,7 +1512,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             uint8_t* d_e = (uint8_t*)tmp.get((size_t)ngk * C);
             uint8_t* d_f = (uint8_t*)tmp.get((size_t)ngk);
             uint32_t* d_n = (uint32_t*)tmp.get((size_t)ngk * 32);
-            rt::h2d(d_keys, out.gather_keys.data() + base0, (size_t)ngk * 8, s);
+            rt::h2d(d_keys, chunk_keys.data(), (size_t)ngk * 8, s);
             LDBG_LAUNCH(k_gather_rows, grid_of(ngk, 256, 4096), 256, s, graph->view, (const uint64_t*)d_keys, ngk, d_e, d_f, d_n);
             rt::d2h(redges.data(), d_e, (size_t)ngk * C, s);
             rt::d2h(rflags.data(), d_f, (size_t)ngk, s);
@@ -1530,7 +1582,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
                     map[j] = M.add_vertex(g2.verts[j]);
                     if (M.verts.size() > before) {
                         int64_t sl = g2_slot[j];
-                        if (sl < 0) { sl = (int64_t)out.gather_keys.size() + (int64_t)extra_keys.size(); extra_keys.push_back(g2.verts[j].id); }
+                        if (sl < 0) { sl = base0 + ngk + (int64_t)extra_keys.size(); extra_keys.push_back(g2.verts[j].id); }
                         slot_of.push_back(sl);
                     }
                 }
@@ -1544,9 +1596,11 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             }
             r.edges = std::move(M.edges);
         }
-        out.gather_keys.insert(out.gather_keys.end(), extra_keys.begin(), extra_keys.end());
+        chunk_keys.insert(chunk_keys.end(), extra_keys.begin(), extra_keys.end());
+        out.n_gather += (int64_t)chunk_keys.size();
+        out.key_segments.push_back(std::move(chunk_keys));
     }
-    if (want_times) fprintf(stderr, "[ldbg] dfs host: slot renumbering %.1f ms\n", ms_since(t_phase));
+    if (want_times) fprintf(stderr, "[ldbg] dfs host: key lists + secondary colours %.1f ms\n", ms_since(t_phase));
     return true;
 }
 
@@ -1556,14 +1610,15 @@ void DfsBatch::materialize() {
     materialized = true;
     rt::set_device(graph->device);
     rt::stream_t s = graph->stream;
-    const int64_t ng = (int64_t)gather_keys.size();
+    const int64_t ng = n_gather;
     std::vector<uint64_t> gw((size_t)std::max<int64_t>(1, ng) * W);
     std::vector<uint32_t> gc((size_t)std::max<int64_t>(1, ng) * C);
     if (ng > 0) {
         uint64_t* d_keys = (uint64_t*)rt::dmalloc((size_t)ng * 8);
         uint64_t* d_w = (uint64_t*)rt::dmalloc((size_t)ng * W * 8);
         uint32_t* d_c = (uint32_t*)rt::dmalloc((size_t)ng * C * 4);
-        rt::h2d(d_keys, gather_keys.data(), (size_t)ng * 8, s);
+        int64_t at = 0;
+        for (auto& seg : key_segments) { if (!seg.empty()) rt::h2d(d_keys + at, seg.data(), seg.size() * 8, s); at += (int64_t)seg.size(); }
         const int g = grid_of(ng, 256, 4096);
         switch (W) {
             case 1: LDBG_LAUNCH(k_gather_vertices<1>, g, 256, s, graph->view, (const uint64_t*)d_keys, ng, d_w, d_c); break;
@@ -1576,7 +1631,7 @@ void DfsBatch::materialize() {
         rt::stream_sync(s);
         rt::dfree(d_keys); rt::dfree(d_w); rt::dfree(d_c);
     }
-    std::vector<uint64_t>().swap(gather_keys);
+    std::vector<std::vector<uint64_t>>().swap(key_segments);
     const int64_t n = (int64_t)results.size();
     const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)16, n / 64 + 1}));
     auto fill = [&](int64_t lo, int64_t hi) {
@@ -1587,8 +1642,8 @@ void DfsBatch::materialize() {
             for (size_t v = 0; v < r.verts.size(); v++) {
                 const DfsVertex& o = r.verts[v];
                 if (o.rec >= 0) {
-                    for (int w = 0; w < W; w++) r.words[v * W + w] = gw[(size_t)o.slot * W + w];
-                    for (int c = 0; c < C; c++) r.cov[v * C + c] = gc[(size_t)o.slot * C + c];
+                    for (int w = 0; w < W; w++) r.words[v * W + w] = gw[(size_t)(o.slot + r.slot_base) * W + w];
+                    for (int c = 0; c < C; c++) r.cov[v * C + c] = gc[(size_t)(o.slot + r.slot_base) * C + c];
                 } else {
                     const auto& nk = r.null_kmers[(size_t)(-o.slot - 1)];
                     for (int w = 0; w < W; w++) r.words[v * W + w] = nk[w];

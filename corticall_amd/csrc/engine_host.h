@@ -35,6 +35,7 @@ struct DfsVertex { int64_t rec; int64_t slot; int32_t copy, index; uint8_t flip;
 struct DfsEdge { int src, dst, color; };
 struct DfsGraphHost {
     bool is_null = true;                   // dfs() returned null
+    int64_t slot_base = 0;                 // added to the slots of the vertices with records (their place among DfsBatch::key_segments)
     std::vector<DfsVertex> verts;          // insertion order
     std::vector<DfsEdge> edges;            // insertion order
     std::vector<uint64_t> words;           // [verts][W]
@@ -47,7 +48,8 @@ struct DfsBatch {
     std::vector<DfsGraphHost> results;
     // the k-mer words and coverages of the vertices are gathered from the device on first use (the graph must still be open)
     const Graph* graph = nullptr;
-    std::vector<uint64_t> gather_keys;
+    std::vector<std::vector<uint64_t>> key_segments;   // keys ((record + 1) << 1 | flip) of the vertices to gather, in segments laid end to end
+    int64_t n_gather = 0;
     bool materialized = false;
     void materialize();
     std::string walk_contig(int64_t i, const char* seed, int color);
