@@ -10,4 +10,4 @@ from .graph import CortexGraph, CortexRecord  # noqa: F401
 from .traversal import (AND, BOTH, FORWARD, OR, REVERSE, STOPPING_RULES, CortexLinks, CortexVertex,  # noqa: F401
                         TraversalEngine, TraversalEngineFactory, TraversalUtils, profile_get, profile_reset)
 from .traversal import *  # noqa: F401,F403  (stopping-rule names: ContigStopper, DestinationStopper, ...)
-from .partition import Join, Partition, Sort  # noqa: F401,E402
+from .partition import FindTips, Join, Partition, Sort  # noqa: F401,E402

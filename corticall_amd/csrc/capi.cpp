@@ -12,6 +12,7 @@ using namespace ldbg;
 
 namespace ldbg {
 int64_t sort_ctx_file(const std::string& in_path, const std::string& out_path, int device);
+int64_t subset_ctx_file(const std::string& in_path, const int64_t* indices, int64_t n, const std::string& out_path);
 int64_t join_ctx_files(const std::vector<std::string>& paths, const std::string& out_path, int device);
 void profile_reset_all();
 bool profile_get(const char* family, double* ms, int64_t* n);
@@ -74,6 +75,10 @@ ldbg_status ldbg_kmer_decode(const uint64_t* words, int k, char* ascii_out) {
 
 ldbg_status ldbg_sort_ctx(const char* in_path, const char* out_path, int device, int64_t* num_records) {
     return guard([&] { const int64_t n = sort_ctx_file(in_path, out_path, device); if (num_records) *num_records = n; });
+}
+
+ldbg_status ldbg_ctx_write_records(const char* in_path, const int64_t* indices, int64_t n, const char* out_path) {
+    return guard([&] { subset_ctx_file(in_path, indices, n, out_path); });
 }
 
 ldbg_status ldbg_join_ctx(const char* const* in_paths, int n_paths, const char* out_path, int device, int64_t* num_records) {

@@ -170,6 +170,30 @@ int64_t sort_ctx_file(const std::string& in_path, const std::string& out_path, i
     return n;
 }
 
+// CortexGraphWriter over a selection of a graph's records (what FindTips.java:112-131 and the other filters write): the header
+// re-serialised from its parsed values, then the chosen records in the order given
+int64_t subset_ctx_file(const std::string& in_path, const int64_t* indices, int64_t n, const std::string& out_path) {
+    MappedCtx in(in_path);
+    const CtxHeader& h = in.h;
+    const size_t rec = (size_t)h.record_size;
+    for (int64_t i = 0; i < n; i++)
+        if (indices[i] < 0 || indices[i] >= h.num_records) throw StatusError(LDBG_ERR_ARG, "record " + std::to_string(indices[i]) + " is not in '" + in_path + "'");
+    FILE* f = fopen(out_path.c_str(), "wb");
+    if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "cannot write '" + out_path + "'");
+    bool ok = true;
+    write_all(f, serialize_ctx_header(h), ok);
+    std::vector<uint8_t> buf;
+    buf.reserve((size_t)(1 << 16) * rec);
+    for (int64_t i = 0; i < n && ok; i++) {
+        const uint8_t* r = in.record(indices[i]);
+        buf.insert(buf.end(), r, r + rec);
+        if (buf.size() >= (size_t)(1 << 16) * rec || i + 1 == n) { write_all(f, buf, ok); buf.clear(); }
+    }
+    ok = fclose(f) == 0 && ok;
+    if (!ok) throw StatusError(LDBG_ERR_CORTEXJDK, "error while writing '" + out_path + "'");
+    return n;
+}
+
 // Join (J/commands/utils/Join.java:16-60 over CortexCollection, J/utils/io/graph/cortex/CortexCollection.java:34-58, 218-293):
 // the union of the k-mers of several sorted graphs, each graph's colours side by side (a k-mer missing from a graph has
 // coverage 0 and no edges there).  The reference merges the files' iterators head by head; here the keys of all files are

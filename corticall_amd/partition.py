@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native
-from .traversal import BOTH, OR, ContigStopper, TraversalEngineFactory
+from .traversal import AND, BOTH, OR, ContigStopper, TraversalEngineFactory
 
 _COMP = bytes.maketrans(b"ACGT", b"TGCA")
 
@@ -104,6 +104,120 @@ class Partition:
             out.append(part)
         e.close()
         return "\n".join(out) + ("\n" if out else "")
+
+
+def java_bytes_hash(kmers):
+    """java.util.Arrays.hashCode(byte[]) of every row of an ASCII u8[n, k] array (what CanonicalKmer.hashCode returns,
+    J/utils/kmer/CanonicalKmer.java:72-74), as u32"""
+    a = np.ascontiguousarray(kmers, dtype=np.uint8)
+    h = np.ones(a.shape[0], dtype=np.uint32)
+    for i in range(a.shape[1]):
+        h = h * np.uint32(31) + a[:, i].astype(np.uint32)
+    return h
+
+
+def java_hashmap_order(hashes):
+    """iteration order of a java.util.HashMap filled by n successive put() calls of new keys with these hashCodes: by bucket of the
+    final table (16 doubling while n > 0.75 capacity; index = (h ^ h >>> 16) & (capacity - 1)), insertion order within a bucket
+    (resizes split a bucket without reordering it).  Bins of 8 and more keys are trees in Java 8; their iteration order is not
+    emulated."""
+    h = np.asarray(hashes, dtype=np.uint32)
+    cap = 16
+    while len(h) > (cap * 3) // 4:
+        cap *= 2
+    bucket = (h ^ (h >> np.uint32(16))) & np.uint32(cap - 1)
+    return np.argsort(bucket, kind="stable")
+
+
+class FindTips:
+    """FindTips — chains of novel k-mers anchored at one end only (J/commands/prefilter/FindTips.java:30-137): every ROI k-mer that
+    no earlier walk has covered is walked (child colour, BOTH, AND, ContigStopper, links if given); the walk is a tip when one of its
+    ends is a novel k-mer without neighbours beyond it; the ROI records on tip walks are written as a graph.
+
+    As in Partition the walks do not depend on the bookkeeping, so all ROI k-mers are walked in one device batch and the loop over
+    `used.keySet()` — a HashMap, so in Java hash order — is replayed on the host."""
+
+    def __init__(self, graph, rois, parents, links=()):
+        self.GRAPH, self.ROI, self.PARENTS, self.LINKS = graph, rois, list(parents), list(links)
+        self.numTipChains = 0
+        self.tips = []                 # ROI record numbers of the tip k-mers, ascending
+
+    def execute(self, out=None):
+        g, roi = self.GRAPH, self.ROI
+        k = g.getKmerSize()
+        child = g.getColorForSampleName(roi.getSampleName(0))
+        parents = g.getColorsForSampleNames(self.PARENTS)
+        n = roi.getNumRecords()
+        self.numTipChains, self.tips = 0, []
+        if n > 0:
+            f = (TraversalEngineFactory(lib=g._lib).traversalDirection(BOTH).combinationOperator(AND).traversalColors(child)
+                 .joiningColors(*parents).stoppingRule(ContigStopper).rois(roi).graph(g))
+            if self.LINKS:
+                f.links(*self.LINKS)
+            e = f.make()
+            words, _, _ = roi.records(0, n)
+            seeds = unpack_kmers(words, k)                                  # rr.getCanonicalKmer(): records hold canonical k-mers
+            arena, offs, wl = e.walk_batch_arrays(seeds)
+            hit_off = np.zeros(n + 1, dtype=np.int64)
+            has_null = np.zeros(n, dtype=np.uint8)
+            hits = np.zeros(1, dtype=np.uint32)
+            st = e._d.ldbg_engine_walk_roi_hits(e._h, hit_off.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p), C.c_int64(0),
+                                                has_null.ctypes.data_as(C.c_void_p))
+            if st not in (0, 7):
+                e._lib.check(st)
+            hits = np.zeros(max(1, int(hit_off[n])), dtype=np.uint32)
+            e._lib.check(e._d.ldbg_engine_walk_roi_hits(e._h, hit_off.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p),
+                                                        C.c_int64(len(hits)), has_null.ctypes.data_as(C.c_void_p)))
+            # the two ends of every walk: is the end a novel k-mer, and does the graph go on beyond it (:80-86)
+            walked = np.nonzero(wl > 0)[0]
+            ends = np.empty((2 * len(walked), k), dtype=np.uint8)
+            for j, i in enumerate(walked):
+                c = arena[offs[i]:offs[i + 1]]
+                ends[2 * j], ends[2 * j + 1] = c[:k], c[len(c) - k:]
+            tip_of = np.zeros(n, dtype=bool)
+            if len(walked):
+                comp = np.zeros(256, dtype=np.uint8)
+                for a, b in zip(b"ACGT", b"TGCA"):
+                    comp[a] = b
+                rc = comp[ends[:, ::-1]]
+                lower = rc.view("S%d" % k).ravel() < ends.view("S%d" % k).ravel()
+                canon = np.where(lower[:, None], rc, ends)
+                # CanonicalKmer.isFlipped(): by hash inequality (Q6), which is what getPrev/NextVertices orient the record by
+                flipped = java_bytes_hash(canon) != java_bytes_hash(ends)
+                if n > 2:
+                    ridx, _, _ = roi.find_batch(np.ascontiguousarray(canon), with_payload=False)
+                    novel = ridx >= 0
+                else:       # (used.containsKey is a HashMap lookup; findRecord never finds anything in a graph of <= 2 records, Q1)
+                    keys = {seeds[j].tobytes() for j in range(n)}
+                    novel = np.array([canon[j].tobytes() in keys for j in range(len(canon))], dtype=bool)
+                gidx, _, gedges = g.find_batch(np.ascontiguousarray(ends))
+                novel = novel & (gidx >= 0)                                  # CortexVertex.getCanonicalKmer() is null without a record (:45)
+                eb = gedges[:, child].astype(np.uint32)
+                pop4 = np.array([bin(x).count("1") for x in range(16)], dtype=np.uint8)
+                n_in, n_out = pop4[eb >> 4], pop4[eb & 15]
+                n_prev = np.where(flipped, n_out, n_in)
+                n_next = np.where(flipped, n_in, n_out)
+                n_prev[gidx < 0] = 0                                         # no record: no neighbours (no recruitment colours here)
+                n_next[gidx < 0] = 0
+                left = novel[0::2] & (n_prev[0::2] == 0)
+                right = novel[1::2] & (n_next[1::2] == 0)
+                tip_of[walked] = left | right
+            used = np.zeros(n, dtype=bool)
+            is_tip = np.zeros(n, dtype=bool)
+            for i in java_hashmap_order(java_bytes_hash(seeds)):            # for (CanonicalKmer rr : used.keySet()) :62
+                if used[i] or wl[i] == 0:
+                    continue
+                mine = hits[hit_off[i]:hit_off[i + 1]]
+                used[mine] = True
+                if tip_of[i]:
+                    self.numTipChains += 1
+                    is_tip[mine] = True
+            self.tips = [int(x) for x in np.nonzero(is_tip)[0]]
+            e.close()
+        if out is not None:
+            idx = np.asarray(self.tips, dtype=np.int64)
+            g._lib.check(g._d.ldbg_ctx_write_records(roi.getFile().encode(), idx.ctypes.data_as(C.c_void_p), C.c_int64(len(idx)), str(out).encode()))
+        return self.numTipChains, len(self.tips)
 
 
 class Sort:

@@ -63,6 +63,10 @@ ldbg_status ldbg_sort_ctx(const char* in_path, const char* out_path, int device,
 /* Join (J/commands/utils/Join.java:16-60; CortexCollection.java:34-58, 218-293): the union of the k-mers of several sorted
  * graphs with every graph's colours side by side, written as one graph.  num_records = k-mers written. */
 ldbg_status ldbg_join_ctx(const char* const* in_paths, int n_paths, const char* out_path, int device, int64_t* num_records);
+/* CortexGraphWriter over a selection of records (J/utils/io/graph/cortex/CortexGraphWriter.java:40-135, as the filters use it:
+ * setHeader(in.getHeader()), addRecord for the chosen records in the order given, close — FindTips.java:112-131).  A file
+ * operation on the host. */
+ldbg_status ldbg_ctx_write_records(const char* in_path, const int64_t* indices, int64_t n, const char* out_path);
 
 /* ------------------------------------------------------------------ graph: G1-G3
  * new CortexGraph(path)              J/utils/io/graph/cortex/CortexGraph.java:40-48, 66-168

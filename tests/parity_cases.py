@@ -781,6 +781,114 @@ def case_big_link_stores(orc, lib, tmp):
         compare_dfs(cs, seeds[:10], trav=[0], stopper="ExplorationStopper", links=["a"], max_len=200)
 
 
+# ------------------------------------------------------------------ FindTips (the other seed loop around the walks)
+class JavaHashMap:
+    """java.util.HashMap as far as iteration order goes: an array of buckets (chains in insertion order), index (h ^ h >>> 16) & (n - 1),
+    doubled when the size passes 0.75 n — every chain split in two without reordering (HashMap.resize)"""
+
+    def __init__(self):
+        self.table, self.size, self.vals = [[] for _ in range(16)], 0, {}
+
+    @staticmethod
+    def _spread(h):
+        return (h ^ (h >> 16)) & 0xFFFFFFFF
+
+    def put(self, key, h, val):
+        if key not in self.vals:
+            self.table[self._spread(h) & (len(self.table) - 1)].append((key, h))
+            self.size += 1
+            if self.size > len(self.table) * 3 // 4:
+                new = [[] for _ in range(2 * len(self.table))]
+                for chain in self.table:
+                    for kh in chain:
+                        new[self._spread(kh[1]) & (len(new) - 1)].append(kh)
+                self.table = new
+        self.vals[key] = val
+
+    def keys(self):
+        return [kh[0] for chain in self.table for kh in chain]
+
+
+def findtips_reference(orc, og, oroi, olinks, parents, k):
+    """J/commands/prefilter/FindTips.java:30-137 restated over the oracle engine, one seed at a time -> (numTipChains, tip k-mers)"""
+    child = og.color_for_sample_name(oroi.sample_name(0))
+    pcols = [og.color_for_sample_name(p) for p in parents]
+    oe = orc.Engine(og, [child], links=olinks, rois=oroi, joining_colors=pcols, op_and=True, stopper="ContigStopper")
+    used = JavaHashMap()
+    for i in range(oroi.N):
+        ck = oroi.record_string(i).split()[0]
+        used.put(ck, (orc.jhash_bytes(ck)) & 0xFFFFFFFF, False)
+
+    def degree(sk, prev):
+        idx = og.find(sk)[0]
+        if idx < 0:
+            return 0
+        edges = og.record_string(idx).split()[1 + og.C + child]
+        ins, outs = sum(1 for c in edges[:4] if c != "."), sum(1 for c in edges[4:] if c != ".")
+        return (outs if prev else ins) if orc.is_flipped(sk) else (ins if prev else outs)
+
+    tips, chains = set(), 0
+    for rr in used.keys():
+        if used.vals[rr]:
+            continue
+        contig, nv = oe.walk(rr)
+        if nv == 0:
+            continue
+        w = [contig[j:j + k] for j in range(len(contig) - k + 1)]
+        canon = [orc.canonical(sk) if og.find(sk)[0] >= 0 else None for sk in w]
+        left = canon[0] in used.vals and degree(w[0], True) == 0
+        right = canon[-1] in used.vals and degree(w[-1], False) == 0
+        if left or right:
+            chains += 1
+        for c in canon:
+            if c in used.vals:
+                used.vals[c] = True
+                if left or right:
+                    tips.add(c)
+    return chains, tips
+
+
+def case_findtips(orc, lib, tmp, k, seed, with_links):
+    from corticall_amd.partition import FindTips
+    rng = random.Random(9100 + seed * 17 + k)
+    base = genome_with_repeats(rng, 1800, n_rep=4, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+    kid = list(base)
+    for _ in range(8):                                   # de novo mutations: chains of child-only k-mers anchored at both ends
+        p = rng.randrange(2 * k, len(kid) - 2 * k)
+        kid[p] = rng.choice([b for b in "ACGT" if b != kid[p]])
+    kid = "".join(kid)
+    # tips: child-only sequence hanging off the genome (an error at the end of a read), in both orientations, and a free-standing one
+    extra = [kid[p:p + k + 5] + rand_seq(rng, rng.randint(2, k)) for p in rng.sample(range(100, len(kid) - 200), 4)]
+    extra += [orc.revcomp(rand_seq(rng, rng.randint(2, k)) + kid[p:p + k + 5]) for p in rng.sample(range(100, len(kid) - 200), 3)]
+    extra.append(rand_seq(rng, 2 * k + 7))
+    dad = mutate(rng, base, snv=0.01, indel=0.002)
+    reads = {"kid": [kid[i:i + 4 * k] for i in range(0, len(kid) - 4 * k, k)] + [kid[-4 * k:]] + extra} if with_links else None
+    cs = Case(orc, tmp, lib, [("kid", [kid] + extra), ("mom", [base]), ("dad", [dad])], k, link_samples=(["kid"] if with_links else []), reads=reads,
+              name="tips%d_%d_%d" % (k, seed, int(with_links)))
+    parents = set()
+    for h in (base, dad):
+        parents |= {orc.canonical(h[i:i + k]) for i in range(len(h) - k + 1)}
+    novel = [h[i:i + k] for h in [kid] + extra for i in range(len(h) - k + 1) if orc.canonical(h[i:i + k]) not in parents]
+    assert len(novel) > 8
+    roi_path = str(tmp / "roi.ctx")
+    orc.build_graph(roi_path, [("kid", novel)], k)
+    oroi, roi = orc.Graph(roi_path, tuned=True), CortexGraph(roi_path, lib=lib)
+    exp_chains, exp_tips = findtips_reference(orc, cs.og, oroi, [cs.olinks["kid"]] if with_links else [], ["mom", "dad"], k)
+    ft = FindTips(cs.g, roi, ["mom", "dad"], [cs.links["kid"]] if with_links else [])
+    out_path = str(tmp / "tips.ctx")
+    got_chains, got_n = ft.execute(out_path)
+    got_tips = {roi.getRecord(i).getKmerAsString() for i in ft.tips}
+    assert (got_chains, got_tips) == (exp_chains, exp_tips), (got_chains, exp_chains, sorted(got_tips ^ exp_tips))
+    assert exp_chains >= 3 and 0 < len(exp_tips) < oroi.N
+    # the graph written: the ROI header, the tip records in ROI order
+    tg = CortexGraph(out_path, lib=lib)
+    assert tg.getNumRecords() == got_n and tg.getKmerSize() == k and tg.getNumColors() == roi.getNumColors() and tg.getSampleName(0) == roi.getSampleName(0)
+    for j, i in enumerate(ft.tips):
+        a, b = tg.getRecord(j), roi.getRecord(i)
+        assert a.getKmerAsString() == b.getKmerAsString() and list(a.getCoverages()) == list(b.getCoverages()) and list(a.getEdges()) == list(b.getEdges())
+    tg.close(); roi.close(); oroi.close()
+
+
 # ------------------------------------------------------------------ Partition (the seed loop around the walks)
 def partition_reference(orc, og, oroi, olinks, k):
     """J/commands/discover/call/Partition.java:57-219 restated over the oracle engine, one seed at a time"""

@@ -82,6 +82,10 @@ def test_ref_dfs_with_sinks(orc, lib, tmp_path): pc.test_ref_dfs_with_sinks(orc,
 def test_partition(orc, lib, tmp_path, k, seed, links): pc.case_partition(orc, lib, tmp_path, k, seed, links)
 
 
+@pytest.mark.parametrize("k,seed,links", [(21, 1, False), (31, 2, True)])
+def test_findtips(orc, lib, tmp_path, k, seed, links): pc.case_findtips(orc, lib, tmp_path, k, seed, links)
+
+
 def test_batch_splitting_on_a_small_device(orc, lib, tmp_path, monkeypatch):
     """3 MB of "device memory": the path / table pools run dry, the host splits the batch and re-runs — results stay exact"""
     monkeypatch.setenv("LDBG_HOSTSIM_MEM_MB", "3")
