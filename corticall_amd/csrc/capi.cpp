@@ -14,6 +14,7 @@ namespace ldbg {
 int64_t sort_ctx_file(const std::string& in_path, const std::string& out_path, int device);
 int64_t subset_ctx_file(const std::string& in_path, const int64_t* indices, int64_t n, const std::string& out_path);
 int64_t join_ctx_files(const std::vector<std::string>& paths, const std::string& out_path, int device);
+std::vector<uint8_t> join_ctx_image(const std::vector<std::string>& paths, int device, bool find_view);
 void profile_reset_all();
 bool profile_get(const char* family, double* ms, int64_t* n);
 }  // namespace ldbg
@@ -96,6 +97,15 @@ ldbg_status ldbg_graph_open(const char* path, int device, ldbg_graph** out) {
 }
 ldbg_status ldbg_graph_open_memory(const void* image, int64_t nbytes, int device, ldbg_graph** out) {
     return guard([&] { *out = nullptr; *out = new ldbg_graph("<memory>", image, nbytes, device); });
+}
+ldbg_status ldbg_graph_open_collection(const char* const* paths, int n_paths, int find_view, int device, ldbg_graph** out) {
+    return guard([&] {
+        *out = nullptr;
+        std::vector<std::string> ps;
+        for (int i = 0; i < n_paths; i++) ps.push_back(paths[i]);
+        const std::vector<uint8_t> img = join_ctx_image(ps, device, find_view != 0);
+        *out = new ldbg_graph("<collection>", img.data(), (int64_t)img.size(), device);
+    });
 }
 ldbg_status ldbg_graph_close(ldbg_graph* g) { return guard([&] { delete g; }); }
 ldbg_status ldbg_graph_info(const ldbg_graph* g, int* k, int* W, int* C, int64_t* N, int* version) {

@@ -198,7 +198,9 @@ int64_t subset_ctx_file(const std::string& in_path, const int64_t* indices, int6
 // the union of the k-mers of several sorted graphs, each graph's colours side by side (a k-mer missing from a graph has
 // coverage 0 and no edges there).  The reference merges the files' iterators head by head; here the keys of all files are
 // concatenated and go through the same stable device sort (ties stay in file order), then equal neighbours are folded.
-int64_t join_ctx_files(const std::vector<std::string>& paths, const std::string& out_path, int device) {
+// emit(bytes, n): the joined graph, header first.  find_view: the graphs as CortexCollection.findRecord sees them (:160-188) — one
+// findRecord per member graph, which never finds anything in a graph of two records or fewer, so such a member's records stay out
+static int64_t join_ctx(const std::vector<std::string>& paths, int device, bool find_view, const std::function<void(const uint8_t*, size_t)>& emit) {
     if (rt::device_count() <= device) throw StatusError(LDBG_ERR_HIP, "no HIP device " + std::to_string(device) + " available (libldbg has no CPU fallback)");
     if (paths.empty()) throw StatusError(LDBG_ERR_ARG, "Join: no graphs");
     std::vector<std::unique_ptr<MappedCtx>> in;
@@ -215,23 +217,22 @@ int64_t join_ctx_files(const std::vector<std::string>& paths, const std::string&
         first_col.push_back(out_h.C);
         out_h.C += h.C;
         out_h.colors.insert(out_h.colors.end(), h.colors.begin(), h.colors.end());
-        first_rec.push_back(first_rec.back() + h.num_records);
+        first_rec.push_back(first_rec.back() + ((find_view && h.num_records <= 2) ? 0 : h.num_records));
     }
     const int64_t n = first_rec.back();
     const int W = out_h.W, C = out_h.C;
     auto locate = [&](int64_t i, size_t* g) { size_t x = 0; while (i >= first_rec[x + 1]) x++; *g = x; return i - first_rec[x]; };
-    const std::vector<uint32_t> perm = radix_sort_permutation(n, W, 2 * out_h.k - 64 * (W - 1), device, [&](int w, uint64_t* col) {
+    std::vector<uint32_t> perm;
+    if (n > 0) perm = radix_sort_permutation(n, W, 2 * out_h.k - 64 * (W - 1), device, [&](int w, uint64_t* col) {
         for (size_t g = 0; g < in.size(); g++)
-            for (int64_t i = 0; i < in[g]->h.num_records; i++) memcpy(&col[first_rec[g] + i], in[g]->record(i) + (size_t)w * 8, 8);
+            for (int64_t i = 0; i < first_rec[g + 1] - first_rec[g]; i++) memcpy(&col[first_rec[g] + i], in[g]->record(i) + (size_t)w * 8, 8);
     });
-    FILE* f = fopen(out_path.c_str(), "wb");
-    if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "cannot write '" + out_path + "'");
-    bool ok = true;
-    write_all(f, serialize_ctx_header(out_h), ok);
+    const std::vector<uint8_t> hb = serialize_ctx_header(out_h);
+    emit(hb.data(), hb.size());
     const size_t rec = (size_t)(8 * W + 5 * C);
     std::vector<uint8_t> buf, cur(rec);
     int64_t n_out = 0;
-    for (int64_t i = 0; i < n && ok;) {
+    for (int64_t i = 0; i < n;) {
         size_t g;
         int64_t li = locate((int64_t)perm[(size_t)i], &g);
         const uint8_t* key = in[g]->record(li);
@@ -250,12 +251,32 @@ int64_t join_ctx_files(const std::vector<std::string>& paths, const std::string&
         buf.insert(buf.end(), cur.begin(), cur.end());
         n_out++;
         i = j;
-        if (buf.size() >= ((size_t)1 << 16) * rec) { write_all(f, buf, ok); buf.clear(); }
+        if (buf.size() >= ((size_t)1 << 16) * rec) { emit(buf.data(), buf.size()); buf.clear(); }
     }
-    write_all(f, buf, ok);
-    ok = fclose(f) == 0 && ok;
+    if (!buf.empty()) emit(buf.data(), buf.size());
+    return n_out;
+}
+
+int64_t join_ctx_files(const std::vector<std::string>& paths, const std::string& out_path, int device) {
+    FILE* f = nullptr;
+    bool ok = true;
+    int64_t n_out = 0;
+    try {
+        n_out = join_ctx(paths, device, false, [&](const uint8_t* b, size_t nb) {
+            if (!f) { f = fopen(out_path.c_str(), "wb"); if (!f) throw StatusError(LDBG_ERR_CORTEXJDK, "cannot write '" + out_path + "'"); }
+            ok = ok && fwrite(b, 1, nb, f) == nb;
+        });
+    } catch (...) { if (f) fclose(f); throw; }
+    ok = f && fclose(f) == 0 && ok;
     if (!ok) throw StatusError(LDBG_ERR_CORTEXJDK, "error while writing '" + out_path + "'");
     return n_out;
+}
+
+// the joined graph as a file image in memory: what a CortexCollection over the graphs presents (ldbg_graph_open_collection)
+std::vector<uint8_t> join_ctx_image(const std::vector<std::string>& paths, int device, bool find_view) {
+    std::vector<uint8_t> img;
+    join_ctx(paths, device, find_view, [&](const uint8_t* b, size_t nb) { img.insert(img.end(), b, b + nb); });
+    return img;
 }
 
 }  // namespace ldbg

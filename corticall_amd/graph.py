@@ -237,3 +237,104 @@ class CortexGraph:
             self.close()
         except Exception:
             pass
+
+
+class CortexCollection(CortexGraph):
+    """J/utils/io/graph/cortex/CortexCollection.java — several sorted graphs of one k-mer size presented as ONE graph with every
+    member's colours side by side (:34-58).  The merge is done once, on the device (ldbg_graph_open_collection: the radix sort of
+    Join without the file), so findRecord (:160-188), the iterator (:218-293) and traversal engines over the collection run on a
+    resident table like any CortexGraph.
+
+    Quirks kept: getNumRecords() is 0 (:95-98); getFile / position / getRecord are unsupported (:190-193, 205-213, 300-303);
+    getColorForSampleName is -1 unless exactly one colour carries the name (:111-116); findRecord asks every member graph, and a
+    member of two records or fewer never answers while the iterator still yields its records."""
+
+    def __init__(self, *graphs, device=0, lib=None):
+        if len(graphs) == 1 and isinstance(graphs[0], (list, tuple)):
+            graphs = tuple(graphs[0])
+        self._members = [g for g in graphs if isinstance(g, CortexGraph)]
+        paths = [g.getFile() if isinstance(g, CortexGraph) else str(g) for g in graphs]
+        self._lib = lib or (self._members[0]._lib if self._members else _native.default_lib())
+        self._d = self._lib.dll
+        self.path = "<collection>"
+        self._paths = paths
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        self._lib.check(self._d.ldbg_graph_open_collection(arr, len(paths), 1, int(device), C.byref(h)))
+        self._h = h
+        k, W, Cc, N, v = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        self._lib.check(self._d.ldbg_graph_info(h, C.byref(k), C.byref(W), C.byref(Cc), C.byref(N), C.byref(v)))
+        self._k, self._W, self._C, self._N, self._version = k.value, W.value, Cc.value, N.value, 6
+        self._pos = 0
+        # the iterator's view differs from findRecord's only when a member has two records or fewer
+        self._member_info = []
+        first = 0
+        for p in paths:
+            hd = _ctx_header_of(p)
+            self._member_info.append((p, first, hd["C"], hd["N"]))
+            first += hd["C"]
+        self._iter_view = None
+        if any(n <= 2 for _, _, _, n in self._member_info):
+            hi = C.c_void_p()
+            self._lib.check(self._d.ldbg_graph_open_collection(arr, len(paths), 0, int(device), C.byref(hi)))
+            self._iter_view = CortexGraph._from_handle(hi, self._lib, "<collection iterator>")
+            self._iter_view._borrowed = False
+
+    def getFile(self):
+        raise NotImplementedError("UnsupportedOperationException")
+
+    def getNumRecords(self):
+        return 0
+
+    def getGraph(self, color):
+        for i, (p, first, nc, _) in enumerate(self._member_info):
+            if first <= color < first + nc:
+                for g in self._members:
+                    if g.getFile() == p:
+                        return g
+                g = CortexGraph(p, lib=self._lib)
+                self._members.append(g)
+                return g
+        raise _native.CortexJDKException("Color doesn't exist in graph.")
+
+    def getColorsForSampleNames(self, names):
+        names = set(names or [])
+        return [c for c in range(self._C) if self.getSampleName(c) in names]
+
+    def getColorForSampleName(self, name):
+        cols = self.getColorsForSampleNames([name])
+        return cols[0] if len(cols) == 1 else -1
+
+    def position(self, i=None):
+        raise NotImplementedError("UnsupportedOperationException")
+
+    def getRecord(self, i):
+        raise NotImplementedError("UnsupportedOperationException")
+
+    def __iter__(self):
+        view = self._iter_view or self
+        n, chunk = view._N, 1 << 16
+        for first in range(0, n, chunk):
+            m = min(chunk, n - first)
+            w, c, e = CortexGraph.records(view, first, m)
+            for j in range(m):
+                yield CortexRecord(w[j], c[j], e[j], self._k, first + j)
+
+    def close(self):
+        if self._iter_view is not None:
+            self._iter_view.close()
+            self._iter_view = None
+        for g in self._members:
+            g.close()
+        CortexGraph.close(self)
+
+
+def _ctx_header_of(path):
+    """k, W, C and the record count of a .ctx file, from its header"""
+    import os
+    from .distributed import ctx_header
+    with open(path, "rb") as f:
+        raw = f.read(1 << 22)
+    h = ctx_header(raw)
+    h["N"] = (os.path.getsize(path) - h["data_offset"]) // (8 * h["W"] + 5 * h["C"])
+    return h

@@ -75,6 +75,12 @@ ldbg_status ldbg_ctx_write_records(const char* in_path, const int64_t* indices, 
 ldbg_status ldbg_graph_open(const char* path, int device, ldbg_graph** out);
 /* same, from an in-memory image of a .ctx file (header + records) */
 ldbg_status ldbg_graph_open_memory(const void* image, int64_t nbytes, int device, ldbg_graph** out);
+/* new CortexCollection(graphs...)   J/utils/io/graph/cortex/CortexCollection.java:34-58: several sorted graphs of one k-mer size as ONE
+ * graph, every member's colours side by side, merged on the device without writing a file.  find_view = 0: the records its
+ * iterator yields (:218-293, the union of the members' k-mers); find_view = 1: the graph its findRecord answers from (:160-188, one
+ * findRecord per member — a member of two records or fewer never finds anything).  Engines are created on the find
+ * view; the two differ only when such a member is present. */
+ldbg_status ldbg_graph_open_collection(const char* const* paths, int n_paths, int find_view, int device, ldbg_graph** out);
 ldbg_status ldbg_graph_close(ldbg_graph* g);                                     /* DeBruijnGraph.close() */
 /* getKmerSize/getKmerBits/getNumColors/getNumRecords/getVersion   CortexGraph.java:325-335 */
 ldbg_status ldbg_graph_info(const ldbg_graph* g, int* k, int* W, int* C, int64_t* N, int* version);

@@ -1186,6 +1186,90 @@ def case_sort_rewrites_header(orc, lib, tmp):
     g.close()
 
 
+def case_collection(orc, lib, tmp):
+    """CortexCollection.java:34-58, 160-188, 218-293: several graphs as one — the iterator's records (head-by-head merge), findRecord
+    (one lookup per member, Q1 for a member of two records), the colour bookkeeping, and a traversal engine over the collection
+    against the oracle over the joined file"""
+    from corticall_amd import CortexCollection
+    from corticall_amd.distributed import ctx_header
+    from corticall_amd.partition import Join
+    rng = random.Random(77)
+    k = 21
+    base = rand_seq(rng, 1500)
+    specs = [[("kid", [mutate(rng, base, snv=0.01)])], [("mom", [base[:900]]), ("dad", [mutate(rng, base[300:], snv=0.02)])], [("kid", [base[100:100 + k + 1]])]]
+    paths, parsed = [], []
+    for gi, haps in enumerate(specs):
+        p = str(tmp / ("c%d.ctx" % gi))
+        orc.build_graph(p, haps, k)
+        raw = np.fromfile(p, dtype=np.uint8)
+        h = ctx_header(raw)
+        parsed.append((h, raw[h["data_offset"]:].reshape(-1, 8 * h["W"] + 5 * h["C"])))
+        paths.append(p)
+    assert len(parsed[2][1]) == 2                      # the member findRecord never answers from (Q1)
+    W, Ctot = parsed[0][0]["W"], sum(h["C"] for h, _ in parsed)
+
+    def merged(members):
+        out, off = {}, 0
+        for mi, (h, recs) in enumerate(parsed):
+            if mi in members:
+                for r in recs:
+                    cov, edges = out.setdefault(r[:8 * W].tobytes(), ([0] * Ctot, [0] * Ctot))
+                    for c in range(h["C"]):
+                        cov[off + c] = int.from_bytes(r[8 * W + 4 * c:8 * W + 4 * c + 4].tobytes(), "little")
+                        edges[off + c] = int(r[8 * W + 4 * h["C"] + c])
+            off += h["C"]
+        return out
+
+    def key_str(key):
+        return orc.decode_kmer([int.from_bytes(key[8 * w:8 * w + 8], "little") for w in range(W)], k)
+
+    it_view, find_view = merged({0, 1, 2}), merged({0, 1})
+    members = [CortexGraph(p, lib=lib) for p in paths]
+    col = CortexCollection(*members)
+    assert col.getNumColors() == Ctot == 4 and col.getKmerSize() == k and col.getNumRecords() == 0 and col.getVersion() == 6
+    assert [col.getSampleName(c) for c in range(4)] == ["kid", "mom", "dad", "kid"]
+    assert col.getColorForSampleName("mom") == 1 and col.getColorForSampleName("kid") == -1 and col.getColorForSampleName("nobody") == -1
+    assert col.getColorsForSampleNames(["kid", "dad"]) == [0, 2, 3]
+    assert col.getGraph(2) is members[1] and col.hasColor(3) and not col.hasColor(4)
+    for bad in (lambda: col.getFile(), lambda: col.position(), lambda: col.getRecord(0)):
+        with pytest.raises(NotImplementedError):
+            bad()
+    rows = [(r.getKmerAsString(), [int(x) & 0xFFFFFFFF for x in r.getCoverages()], [int(x) for x in r.getEdges()]) for r in col]
+    exp_rows = sorted((key_str(key), cov, edges) for key, (cov, edges) in it_view.items())
+    assert rows == exp_rows and len(rows) > 1000
+    tiny_only = [key_str(key) for key in it_view if key not in find_view]
+    for ks, cov, edges in exp_rows[::7] + [r for r in exp_rows if r[0] in tiny_only]:
+        for q in (ks, orc.revcomp(ks)):
+            r = col.findRecord(q)
+            if ks in tiny_only:
+                assert r is None
+            else:
+                assert r is not None and r.getKmerAsString() == ks
+    by_str = {key_str(key): v for key, v in find_view.items()}
+    idx, cov, edges = col.find_batch([r[0] for r in exp_rows])
+    for j, (ks, _, _) in enumerate(exp_rows):
+        if ks in by_str:
+            assert idx[j] >= 0 and [int(x) & 0xFFFFFFFF for x in cov[j]] == by_str[ks][0] and [int(x) for x in edges[j]] == by_str[ks][1]
+        else:
+            assert idx[j] < 0
+    assert col.findRecord(rand_seq(rng, k)) is None
+    # a traversal engine over the collection = the oracle over the file Join writes of the same graphs (no tiny member here)
+    joined = str(tmp / "joined.ctx")
+    Join(paths[:2], joined, lib=lib).execute()
+    og = orc.Graph(joined, tuned=True)
+    col2 = CortexCollection(paths[0], paths[1], lib=lib)
+    seeds = [r[0] for r in exp_rows[::40]]
+    for trav, stopper in (([0], "ContigStopper"), ([1, 2], "ContigStopper")):
+        oe = orc.Engine(og, trav, stopper=stopper)
+        e = TraversalEngineFactory(lib=lib).traversalColors(*trav).graph(col2).stoppingRule(stopper).make()
+        got, _ = e.walk_batch(seeds)
+        for s_, c in zip(seeds, got):
+            assert c == oe.walk(s_)[0]
+        assert max(len(c) for c in got) > 3 * k
+        e.close()
+    col2.close(); col.close(); og.close()
+
+
 def case_join(orc, lib, tmp):
     """Join.java:16-60 over CortexCollection (:34-58 colours side by side, :218-293 head-by-head merge of the sorted files):
     the union of the k-mers, zero coverage / no edges where a file lacks the k-mer — byte for byte"""

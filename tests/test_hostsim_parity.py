@@ -61,6 +61,9 @@ def test_sort_rewrites_header(orc, lib, tmp_path): pc.case_sort_rewrites_header(
 def test_join(orc, lib, tmp_path): pc.case_join(orc, lib, tmp_path)
 
 
+def test_collection(orc, lib, tmp_path): pc.case_collection(orc, lib, tmp_path)
+
+
 def test_big_link_stores(orc, lib, tmp_path): pc.case_big_link_stores(orc, lib, tmp_path)
 
 
