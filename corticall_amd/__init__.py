@@ -11,3 +11,4 @@ from .traversal import (AND, BOTH, FORWARD, OR, REVERSE, STOPPING_RULES, CortexL
                         TraversalEngine, TraversalEngineFactory, TraversalUtils, profile_get, profile_reset)
 from .traversal import *  # noqa: F401,F403  (stopping-rule names: ContigStopper, DestinationStopper, ...)
 from .partition import FindTips, Join, Partition, Sort  # noqa: F401,E402
+from . import traversal_utils  # noqa: F401,E402

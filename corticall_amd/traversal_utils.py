@@ -1,0 +1,304 @@
+"""The graph utilities around the dfs path (J/utils/traversal/TraversalUtils.java): toGraph (:330-352), fillGaps (:235-315),
+toWalk (:387-488), toContig (:367-381), over the part of JGraphT's DirectedWeightedPseudograph they rely on.
+
+The searches themselves — one DestinationStopper dfs per gap source — run on the device in ONE batch per colour and direction
+(TraversalEngine.dfs_batch); what is replayed on the host is the container bookkeeping: vertex and edge sets in insertion order,
+edges refused when an equal CortexEdge is present (CortexEdge.java:42-57: same two vertices in either direction, same colour,
+same weight), Graphs.addGraph, and the order in which a java.util.HashSet<String> hands out the gap sources."""
+import numpy as np
+
+from .partition import java_hashmap_order
+from .traversal import FORWARD, OR, REVERSE, CortexVertex, DestinationStopper, TraversalEngineFactory
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _revcomp(s):
+    return s.encode().translate(_COMP)[::-1].decode()
+
+
+class CortexEdge:
+    """J/utils/traversal/CortexEdge.java: identity = ({source, target} as a set, colour, weight)"""
+
+    def __init__(self, s, t, color, weight=1.0):
+        self.vertices, self.color, self.weight = frozenset((s, t)), color, weight
+
+    def getColor(self): return self.color
+    def getWeight(self): return self.weight
+    def __eq__(self, o): return isinstance(o, CortexEdge) and (self.color, self.weight, self.vertices) == (o.color, o.weight, o.vertices)
+    def __hash__(self): return hash((self.vertices, self.color, self.weight))
+
+
+class Pseudograph:
+    """org.jgrapht.graph.DirectedWeightedPseudograph<CortexVertex, CortexEdge> (1.0.1) as the reference uses it: LinkedHashSet-like
+    vertex and edge sets, per-vertex incoming / outgoing edge lists in insertion order, addEdge refusing an edge that equals one
+    already present (AbstractBaseGraph.addEdge(V, V, E): containsEdge(e))."""
+
+    def __init__(self):
+        self._v = {}            # vertex -> ([outgoing edges], [incoming edges])
+        self._e = {}            # edge -> (source, target)
+
+    def vertexSet(self): return list(self._v)
+    def edgeSet(self): return list(self._e)
+    def containsVertex(self, v): return v in self._v
+    def getEdgeSource(self, e): return self._e[e][0]
+    def getEdgeTarget(self, e): return self._e[e][1]
+    def outgoingEdgesOf(self, v): return list(self._v[v][0])
+    def incomingEdgesOf(self, v): return list(self._v[v][1])
+
+    def addVertex(self, v):
+        if v in self._v:
+            return False
+        self._v[v] = ([], [])
+        return True
+
+    def addEdge(self, s, t, e):
+        if e in self._e:
+            return False
+        if s not in self._v or t not in self._v:
+            raise ValueError("no such vertex in graph")
+        self._e[e] = (s, t)
+        self._v[s][0].append(e)
+        self._v[t][1].append(e)
+        return True
+
+    def addGraph(self, src, rename=None):
+        """Graphs.addGraph(this, src): all vertices, then all edges (each with its end points).  rename: vertex of src -> the vertex of this
+        graph that stands for it (fillGaps with relabel=True)"""
+        rn = (lambda v: rename.get(v, v)) if rename else (lambda v: v)
+        for v in src.vertexSet():
+            self.addVertex(rn(v))
+        for e in src.edgeSet():
+            s, t = rn(src.getEdgeSource(e)), rn(src.getEdgeTarget(e))
+            self.addVertex(s)
+            self.addVertex(t)
+            self.addEdge(s, t, e if not rename else CortexEdge(s, t, e.getColor(), e.getWeight()))
+
+    @staticmethod
+    def fromDfsGraph(dg):
+        """the graph a device dfs returned (traversal.DfsGraph), with its vertices and edges in their insertion order"""
+        g = Pseudograph()
+        vs = dg.vertexSet()
+        for v in vs:
+            g.addVertex(v)
+        for s, t, c in dg.edge_tuples():
+            g.addEdge(vs[s], vs[t], CortexEdge(vs[s], vs[t], c, 1.0))
+        return g
+
+
+def java_string_hash(s):
+    h = 0
+    for ch in s.encode():
+        h = (31 * h + ch) & 0xFFFFFFFF
+    return h
+
+
+def java_string_set_order(strings):
+    """iteration order of a HashSet<String> the strings were added to in this order (duplicates ignored)"""
+    uniq = list(dict.fromkeys(strings))
+    if not uniq:
+        return []
+    order = java_hashmap_order(np.array([java_string_hash(s) for s in uniq], dtype=np.uint32))
+    return [uniq[i] for i in order]
+
+
+def _java_small_sort(items, cmp):
+    """java.util.TimSort on fewer than 32 elements (countRunAndMakeAscending + binarySort): toWalk's comparators never return 0
+    (:424-428, 466-470), so the outcome depends on the algorithm"""
+    v = list(items)
+    n = len(v)
+    if n < 2:
+        return v
+    assert n < 32
+    hi = 1
+    if cmp(v[1], v[0]) < 0:
+        hi = 2
+        while hi < n and cmp(v[hi], v[hi - 1]) < 0:
+            hi += 1
+        v[:hi] = v[:hi][::-1]
+    else:
+        hi = 2
+        while hi < n and cmp(v[hi], v[hi - 1]) >= 0:
+            hi += 1
+    for start in range(hi, n):
+        pivot = v[start]
+        lo, r = 0, start
+        while lo < r:
+            mid = (lo + r) >> 1
+            if cmp(pivot, v[mid]) < 0:
+                r = mid
+            else:
+                lo = mid + 1
+        v[lo + 1:start + 1] = v[lo:start]
+        v[lo] = pivot
+    return v
+
+
+def toGraph(walk, colors):
+    """:330-352 — a walk as a graph: consecutive vertices joined in every colour both of them have coverage in"""
+    g = Pseudograph()
+    pv = walk[0]
+    g.addVertex(pv)
+    for nv in walk[1:]:
+        g.addVertex(nv)
+        for c in colors:
+            if pv.getCortexRecord().getCoverage(c) > 0 and nv.getCortexRecord().getCoverage(c) > 0:
+                g.addEdge(pv, nv, CortexEdge(pv, nv, c, 1.0))
+        pv = nv
+    return g
+
+
+def _next_kmers(v, c):
+    """getAllNextKmers(record, flipped).get(c) as strings (:536-560), flipped by comparison with the canonical k-mer as fillGaps does"""
+    cr, sk = v.getCortexRecord(), v.getKmerAsString()
+    if cr is None:
+        return None
+    flipped = sk != cr.getKmerAsString()
+    bases = cr.getOutEdgesAsStrings(c) if not flipped else cr.getInEdgesAsStrings(c, True)
+    return {sk[1:] + b for b in bases}
+
+
+def _prev_kmers(v, c):
+    cr, sk = v.getCortexRecord(), v.getKmerAsString()
+    if cr is None:
+        return None
+    flipped = sk != cr.getKmerAsString()
+    bases = cr.getInEdgesAsStrings(c) if not flipped else cr.getOutEdgesAsStrings(c, True)
+    return {b + sk[:-1] for b in bases}
+
+
+def _dfs_collection(engine, sources, sinks):
+    """TraversalEngine.dfs(Collection<String> sources, Collection<String> sinks) :41-58: one dfs per source, in the collection's
+    order, the graphs merged with Graphs.addGraph — all searches in one device batch"""
+    if not sources:
+        return None
+    batch = engine.dfs_batch(sources, [list(sinks)] * len(sources))
+    out = None
+    for dg in batch:
+        if dg is None:
+            continue
+        g = Pseudograph.fromDfsGraph(dg)
+        if out is None:
+            out = g
+        else:
+            out.addGraph(g)
+    return out
+
+
+def fillGaps(g, graph, links, colors, relabel=False):
+    """:235-315 — per colour: edges the colour has between joined vertices; vertices with an edge in the colour that leaves the
+    graph are sources (outgoing) / sinks (incoming); DestinationStopper searches of at most 1000 vertices from every source towards
+    the sinks (forward; if that returns nothing, backwards from the sinks) are merged in.
+
+    relabel=False is the literal reading: Graphs.addGraph joins vertices that are equal, and CortexVertex.equals includes `index` —
+    the source a search starts from comes back with index 0 while the same k-mer in g (a walk: index -1 / +1 either side of its seed)
+    does not, so the filled stretch hangs on g at its far end only.  The reference's own test of this function
+    (TraversalUtilsTest.java:19-97) expects it joined at both ends; relabel=True gives that: a vertex of a search result
+    that differs from a vertex already in the graph by `index` alone is taken to be that vertex."""
+    filled = Pseudograph()
+    filled.addGraph(g)
+    colors = list(colors)
+    for e in g.edgeSet():
+        v0, v1 = g.getEdgeSource(e), g.getEdgeTarget(e)
+        for c in colors:
+            nks = _next_kmers(v0, c)
+            if nks is None:
+                raise _npe("fillGaps: a vertex without a record")
+            if v1.getKmerAsString() in nks:
+                filled.addEdge(v0, v1, CortexEdge(v0, v1, c, 1.0))
+    for c in colors:
+        sources, sinks = [], []
+        for v in filled.vertexSet():
+            vs = {filled.getEdgeTarget(e).getKmerAsString() for e in filled.outgoingEdgesOf(v) if e.getColor() == c}
+            nk = _next_kmers(v, c)
+            if nk is None:
+                raise _npe("fillGaps: a vertex without a record")
+            if nk - vs:
+                sources.append(v.getKmerAsString())
+            vp = {filled.getEdgeSource(e).getKmerAsString() for e in filled.incomingEdgesOf(v) if e.getColor() == c}
+            if _prev_kmers(v, c) - vp:
+                sinks.append(v.getKmerAsString())
+        sources, sinks = java_string_set_order(sources), java_string_set_order(sinks)
+
+        def engine(direction):
+            f = (TraversalEngineFactory(lib=graph._lib).traversalColors(c).traversalDirection(direction).combinationOperator(OR)
+                 .stoppingRule(DestinationStopper).maxBranchLength(1000).graph(graph))
+            if links:
+                f.links(*links)
+            return f.make()
+
+        ef = engine(FORWARD)
+        fill = _dfs_collection(ef, sources, sinks)
+        ef.close()
+        if fill is None:
+            er = engine(REVERSE)
+            fill = _dfs_collection(er, sinks, sources)
+            er.close()
+        if fill is not None:
+            rename = None
+            if relabel:
+                have = {}
+                for v in filled.vertexSet():
+                    have.setdefault((v.getKmerAsString(), v.getCortexRecord(), v.getCopyIndex()), v)
+                rename = {v: have[(v.getKmerAsString(), v.getCortexRecord(), v.getCopyIndex())] for v in fill.vertexSet()
+                          if (v.getKmerAsString(), v.getCortexRecord(), v.getCopyIndex()) in have}
+            filled.addGraph(fill, rename)
+    return filled
+
+
+def _npe(msg):
+    from . import _native
+    return _native.JavaNullPointerException(msg)
+
+
+def toWalk(g, sk, color):
+    """:387-488 — the linear walk through g in one colour that passes the vertex with k-mer sk"""
+    w = []
+    if g is None:
+        return w
+    seed = None
+    for v in g.vertexSet():
+        cr = v.getCortexRecord()
+        if v.getKmerAsString() == sk and cr is not None and cr.getCoverage(color) > 0 and (seed is None or v.getCopyIndex() < seed.getCopyIndex()):
+            seed = v
+    if seed is None:
+        return w
+    w.append(seed)
+    for forward in (True, False):
+        seen, cv = set(), seed
+        while cv is not None and cv not in seen:
+            if forward:
+                nvs = [g.getEdgeTarget(e) for e in g.outgoingEdgesOf(cv) if e.getColor() == color]
+            else:
+                nvs = [g.getEdgeSource(e) for e in g.incomingEdgesOf(cv) if e.getColor() == color]
+            if cv in nvs:
+                nvs.remove(cv)                                       # List.remove(Object): the first occurrence
+            nv = None
+            if len(nvs) == 1:
+                nv = nvs[0]
+            elif len(nvs) > 1:
+                if any(x.getCortexRecord() is None for x in nvs):
+                    raise _npe("toWalk: a vertex without a record among the candidates")
+                if all(nvs[0].getCanonicalKmer() == x.getCanonicalKmer() for x in nvs[1:]):
+                    if forward:
+                        nvs = _java_small_sort(nvs, lambda a, b: -1 if a.getCopyIndex() < b.getCopyIndex() else 1)
+                    else:
+                        nvs = _java_small_sort(nvs, lambda a, b: -1 if a.getCopyIndex() > b.getCopyIndex() else 1)
+                    nv = nvs[0]
+            if nv is not None:
+                if forward:
+                    w.append(nv)
+                else:
+                    w.insert(0, nv)
+                seen.add(cv)
+            cv = nv
+    return w
+
+
+def toContig(walk):
+    """:367-381"""
+    s = ""
+    for v in walk:
+        sk = v.getKmerAsString()
+        s = sk if not s else s + sk[-1]
+    return s

@@ -757,6 +757,64 @@ def case_dfs_dense(orc, lib, tmp, seed):
     compare_dfs(cs, seeds, sinks=sinks, trav=[0, 1], stopper="ExplorationStopper", max_len=60)
 
 
+def test_ref_fill_gaps(orc, lib, tmp):                            # TraversalUtilsTest.java:19-97 (V13, both cases)
+    from corticall_amd import traversal_utils as tu
+    cases = [({"mom": ["TGGCTAGGTCATTATGATATTAAAATGCTAGCGC"], "kid": ["TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"]},
+              [("TGGCTAG", "kid", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"), ("TGGCTAG", "mom", "TGGCTAGGTCATTATGATATTAAAATGCTAGCGC")]),
+             ({"mom": ["TGGCTAGGTCATTATGATATTAAAATGCTAGCGC", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"], "kid": ["TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"]},
+              [("TGAGATT", "kid", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"), ("TGATATT", "mom", "TGGCTAGGTCATTATGATATTAAAATGCTAGCGC"),
+               ("TGAGATT", "mom", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC")])]
+    for ci, (haps, expected) in enumerate(cases):
+        # (a java.util.HashMap of the two sample names iterates "mom" before "kid": TempGraphAssembler gives mom colour 0)
+        cs = Case(orc, tmp, lib, [("mom", haps["mom"]), ("kid", haps["kid"])], 7, link_samples=["mom", "kid"], name="v13_%d" % ci)
+        colors = list(range(cs.g.getNumColors()))
+        kid = cs.g.getColorForSampleName("kid")
+        e = (TraversalEngineFactory(lib=lib).traversalColors(kid).traversalDirection(BOTH).combinationOperator(OR).stoppingRule("ContigStopper")
+             .graph(cs.g).links(cs.links["kid"]).make())
+        w = e.walk("TGAGATT")
+        assert tu.toContig(w) == haps["kid"][0]
+        gapped = tu.toGraph(w, colors)
+        # the five strings the reference's test asserts: reproduced when a search result is joined on (k-mer, record, copyIndex)
+        filled = tu.fillGaps(gapped, cs.g, [cs.links["mom"], cs.links["kid"]], colors, relabel=True)
+        for seed, sample, hap in expected:
+            assert tu.toContig(tu.toWalk(filled, seed, cs.g.getColorForSampleName(sample))) == hap, (ci, seed, sample)
+        assert filled.vertexSet()[:len(gapped.vertexSet())] == gapped.vertexSet()      # what was there stays there, in its place
+        # the literal reading (CortexVertex.equals includes `index`): the same searches, the filled stretch joined at its far end only
+        lit = tu.fillGaps(gapped, cs.g, [cs.links["mom"], cs.links["kid"]], colors)
+        assert {v.getKmerAsString() for v in lit.vertexSet()} == {v.getKmerAsString() for v in filled.vertexSet()}
+        assert len(lit.vertexSet()) > len(filled.vertexSet())                         # (at least) the search's own source vertex, index 0
+        if ci == 0:
+            mom_walk = tu.toContig(tu.toWalk(lit, "TGATATT", cs.g.getColorForSampleName("mom")))
+            assert mom_walk == haps["mom"][0][haps["mom"][0].index("ATTATGA"):]       # starts at the source, runs to the end of the haplotype
+        e.close()
+
+
+def case_fill_gaps_random(orc, lib, tmp, seed):
+    """fillGaps on a child walk over a three-colour graph: every parental allele next to a child-only stretch is recovered — after the
+    fill, a walk in a parent's colour from a shared k-mer spells that parent's haplotype across the gap"""
+    from corticall_amd import traversal_utils as tu
+    rng = random.Random(4400 + seed)
+    k = rng.choice([15, 17, 21])
+    mom = rand_seq(rng, 400)
+    kid = list(mom)
+    sites = sorted(rng.sample(range(3 * k, len(mom) - 3 * k, 4 * k), 3))
+    for p in sites:
+        kid[p] = rng.choice([b for b in "ACGT" if b != kid[p]])
+    kid = "".join(kid)
+    cs = Case(orc, tmp, lib, [("mom", [mom]), ("kid", [kid])], k, link_samples=["mom", "kid"], name="fg%d" % seed)
+    colors = [0, 1]
+    kc, mc = cs.g.getColorForSampleName("kid"), cs.g.getColorForSampleName("mom")
+    e = (TraversalEngineFactory(lib=lib).traversalColors(kc).traversalDirection(BOTH).combinationOperator(OR).stoppingRule("ContigStopper")
+         .graph(cs.g).links(cs.links["kid"]).make())
+    p0 = sites[1]
+    w = e.walk(kid[p0 - 2:p0 - 2 + k])
+    assert tu.toContig(w) == kid
+    filled = tu.fillGaps(tu.toGraph(w, colors), cs.g, [cs.links["mom"], cs.links["kid"]], colors, relabel=True)
+    assert tu.toContig(tu.toWalk(filled, kid[:k], kc)) == kid
+    assert tu.toContig(tu.toWalk(filled, mom[:k], mc)) == mom
+    e.close()
+
+
 def test_ref_dfs_with_sinks(orc, lib, tmp):                       # TraversalEngineTest.java:389-410
     hap = "GTGTGCTAGGTCTATAGTTATAGGCGCGTCTCCGCAAAAATCGT"
     cs = Case(orc, tmp, lib, [("test", [hap])], 5, link_samples=["test"], name="v12")

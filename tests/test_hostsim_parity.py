@@ -81,6 +81,13 @@ def test_dfs_dense(orc, lib, tmp_path, seed): pc.case_dfs_dense(orc, lib, tmp_pa
 def test_ref_dfs_with_sinks(orc, lib, tmp_path): pc.test_ref_dfs_with_sinks(orc, lib, tmp_path)
 
 
+def test_ref_fill_gaps(orc, lib, tmp_path): pc.test_ref_fill_gaps(orc, lib, tmp_path)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fill_gaps_random(orc, lib, tmp_path, seed): pc.case_fill_gaps_random(orc, lib, tmp_path, seed)
+
+
 @pytest.mark.parametrize("k,seed,links", [(21, 1, False), (31, 2, True), (47, 3, True)])
 def test_partition(orc, lib, tmp_path, k, seed, links): pc.case_partition(orc, lib, tmp_path, k, seed, links)
 
