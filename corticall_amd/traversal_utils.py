@@ -185,16 +185,17 @@ def _dfs_collection(engine, sources, sinks):
     return out
 
 
-def fillGaps(g, graph, links, colors, relabel=False):
+def fillGaps(g, graph, links, colors, relabel=True):
     """:235-315 — per colour: edges the colour has between joined vertices; vertices with an edge in the colour that leaves the
     graph are sources (outgoing) / sinks (incoming); DestinationStopper searches of at most 1000 vertices from every source towards
     the sinks (forward; if that returns nothing, backwards from the sinks) are merged in.
 
-    relabel=False is the literal reading: Graphs.addGraph joins vertices that are equal, and CortexVertex.equals includes `index` —
-    the source a search starts from comes back with index 0 while the same k-mer in g (a walk: index -1 / +1 either side of its seed)
-    does not, so the filled stretch hangs on g at its far end only.  The reference's own test of this function
-    (TraversalUtilsTest.java:19-97) expects it joined at both ends; relabel=True gives that: a vertex of a search result
-    that differs from a vertex already in the graph by `index` alone is taken to be that vertex."""
+    relabel=True (the default) is pinned by the reference's own test of this function (TraversalUtilsTest.java:19-97, SURVEY V13, five
+    strings): a vertex of a search result that differs from a vertex already in the graph by `index` alone is taken to be that vertex,
+    so a filled stretch is joined to g at both ends.  relabel=False is the literal reading of the sources: Graphs.addGraph joins
+    vertices that are equal, and CortexVertex.equals includes `index` — the source a search starts from comes back with index 0 while
+    the same k-mer in g (a walk: index -1 / +1 either side of its seed) does not, so the stretch hangs on g at its far end only and the
+    test's strings do not come out."""
     filled = Pseudograph()
     filled.addGraph(g)
     colors = list(colors)

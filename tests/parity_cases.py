@@ -775,12 +775,12 @@ def test_ref_fill_gaps(orc, lib, tmp):                            # TraversalUti
         assert tu.toContig(w) == haps["kid"][0]
         gapped = tu.toGraph(w, colors)
         # the five strings the reference's test asserts: reproduced when a search result is joined on (k-mer, record, copyIndex)
-        filled = tu.fillGaps(gapped, cs.g, [cs.links["mom"], cs.links["kid"]], colors, relabel=True)
+        filled = tu.fillGaps(gapped, cs.g, [cs.links["mom"], cs.links["kid"]], colors)
         for seed, sample, hap in expected:
             assert tu.toContig(tu.toWalk(filled, seed, cs.g.getColorForSampleName(sample))) == hap, (ci, seed, sample)
         assert filled.vertexSet()[:len(gapped.vertexSet())] == gapped.vertexSet()      # what was there stays there, in its place
         # the literal reading (CortexVertex.equals includes `index`): the same searches, the filled stretch joined at its far end only
-        lit = tu.fillGaps(gapped, cs.g, [cs.links["mom"], cs.links["kid"]], colors)
+        lit = tu.fillGaps(gapped, cs.g, [cs.links["mom"], cs.links["kid"]], colors, relabel=False)
         assert {v.getKmerAsString() for v in lit.vertexSet()} == {v.getKmerAsString() for v in filled.vertexSet()}
         assert len(lit.vertexSet()) > len(filled.vertexSet())                         # (at least) the search's own source vertex, index 0
         if ci == 0:
