@@ -45,6 +45,23 @@ public class GpuCortexGraph implements DeBruijnGraph {
         kmerSize = (int) i[0]; kmerBits = (int) i[1]; numColors = (int) i[2]; numRecords = i[3]; version = (int) i[4];
     }
 
+    /**
+     * Several graphs as one (CortexCollection.java:34-58): the members merged into one resident table, every member's colours side by
+     * side.  findView: the table CortexCollection.findRecord answers from (a member of two records or fewer never answers, :160-188);
+     * otherwise the records its iterator yields (:218-293).  getFile() is null for such a graph.
+     */
+    public static GpuCortexGraph collection(java.util.List<File> members, boolean findView, int device) {
+        String[] paths = new String[members.size()];
+        for (int i = 0; i < paths.length; i++) { paths[i] = members.get(i).getAbsolutePath(); }
+        return new GpuCortexGraph(openCollection(paths, findView, device));
+    }
+    private GpuCortexGraph(long h) {
+        file = null;
+        handle = h;
+        long[] i = info(handle);
+        kmerSize = (int) i[0]; kmerBits = (int) i[1]; numColors = (int) i[2]; numRecords = i[3]; version = (int) i[4];
+    }
+
     // ---- seeking / iterating (CortexGraph.java:183-258)
     @Override public long position() { return position; }
     @Override public void position(long i) {
@@ -163,6 +180,7 @@ public class GpuCortexGraph implements DeBruijnGraph {
     @Override public String toString() { return "GpuCortexGraph{" + file + ", k=" + kmerSize + ", colors=" + numColors + ", records=" + numRecords + "}"; }
 
     private static native long open(String path, int device);
+    private static native long openCollection(String[] paths, boolean findView, int device);
     private static native void close(long h);
     private static native long[] info(long h);
     private static native String sampleName(long h, int color);

@@ -18,9 +18,13 @@ public final class GpuCortexTools {
         return join(paths, out.getAbsolutePath(), 0);
     }
 
+    /** CortexGraphWriter over a selection: the header of `in` and its records `indices`, in that order (what FindTips writes) */
+    public static void writeRecords(File in, long[] indices, File out) { writeRecords(in.getAbsolutePath(), indices, out.getAbsolutePath()); }
+
     public static int devices() { return deviceCount(); }
 
     private static native long sort(String in, String out, int device);
     private static native long join(String[] ins, String out, int device);
+    private static native void writeRecords(String in, long[] indices, String out);
     private static native int deviceCount();
 }

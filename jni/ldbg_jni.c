@@ -41,6 +41,19 @@ jlong JNIFN(GpuCortexGraph, open)(JNIEnv* env, jclass c, jstring path, jint devi
     if (st != LDBG_OK) { rethrow(env, st); return 0; }
     return (jlong)(intptr_t)g;
 }
+/* new CortexCollection(graphs...): the members merged into one resident table; findView: the graph findRecord answers from */
+jlong JNIFN(GpuCortexGraph, openCollection)(JNIEnv* env, jclass c, jobjectArray ins, jboolean findView, jint device) {
+    jsize np = (*env)->GetArrayLength(env, ins);
+    const char** paths = (const char**)calloc((size_t)(np > 0 ? np : 1), sizeof(*paths));
+    jstring* held = (jstring*)calloc((size_t)(np > 0 ? np : 1), sizeof(*held));
+    for (jsize i = 0; i < np; i++) { held[i] = (jstring)(*env)->GetObjectArrayElement(env, ins, i); paths[i] = (*env)->GetStringUTFChars(env, held[i], NULL); }
+    ldbg_graph* g = NULL;
+    ldbg_status st = ldbg_graph_open_collection(paths, (int)np, findView ? 1 : 0, device, &g);
+    for (jsize i = 0; i < np; i++) (*env)->ReleaseStringUTFChars(env, held[i], paths[i]);
+    free(paths); free(held);
+    if (st != LDBG_OK) { rethrow(env, st); return 0; }
+    return (jlong)(intptr_t)g;
+}
 void JNIFN(GpuCortexGraph, close)(JNIEnv* env, jclass c, jlong h) { CHECK(ldbg_graph_close(G(h)), ); }
 /* getKmerSize / getKmerBits / getNumColors / getNumRecords / getVersion as a long[5] */
 jlongArray JNIFN(GpuCortexGraph, info)(JNIEnv* env, jclass c, jlong h) {
@@ -355,6 +368,18 @@ jlong JNIFN(GpuCortexTools, join)(JNIEnv* env, jclass c, jobjectArray ins, jstri
     free(paths); free(held);
     if (st != LDBG_OK) { rethrow(env, st); return -1; }
     return n;
+}
+/* CortexGraphWriter over a selection of records (FindTips.java:112-131 and the other filters) */
+void JNIFN(GpuCortexTools, writeRecords)(JNIEnv* env, jclass c, jstring in, jlongArray indices, jstring out) {
+    const char* a = (*env)->GetStringUTFChars(env, in, NULL);
+    const char* b = (*env)->GetStringUTFChars(env, out, NULL);
+    jsize n = (*env)->GetArrayLength(env, indices);
+    jlong* idx = (*env)->GetLongArrayElements(env, indices, NULL);
+    ldbg_status st = ldbg_ctx_write_records(a, (const int64_t*)idx, (int64_t)n, b);
+    (*env)->ReleaseLongArrayElements(env, indices, idx, JNI_ABORT);
+    (*env)->ReleaseStringUTFChars(env, in, a);
+    (*env)->ReleaseStringUTFChars(env, out, b);
+    if (st != LDBG_OK) { rethrow(env, st); }
 }
 jint JNIFN(GpuCortexTools, deviceCount)(JNIEnv* env, jclass c) {
     int n = 0;
