@@ -409,6 +409,17 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
     dt = time.time() - t0
     dfs_ms, launches = ca.profile_get("dfs")
     found = sum(1 for i in range(n) if b.graph(i) is not None)
+    # the same call followed by reading a graph WITH its k-mers: results of one branch per direction stay packed until then, and the
+    # k-mers and coverages of all vertices of the batch are gathered from the device on first use
+    sync()
+    t1 = time.time()
+    b2 = eng.dfs_batch_arrays(src, n, sink_buf, sink_off)
+    first_graph = next((b2.graph(i) for i in range(n) if b2.graph(i) is not None), None)
+    if first_graph is not None:
+        first_graph._fetch()
+    sync()
+    dt_fetched = time.time() - t1
+    del b2, first_graph
     tot_trav, tot_seeds, max_dt = traversed, n * args.steps, dt
     if dist is not None:
         t = torch.tensor([float(traversed), float(n * args.steps)], dtype=torch.float64, device="cuda")
@@ -430,8 +441,9 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {
                 "workload": "configs[3]: same %.1f Mb 3-colour k=%d LdBG with child links; dfs with DestinationStopper, FORWARD, from %d seeds per GPU "
-                            "to the child k-mer 200-2000 bp downstream on the seed's contig; timed: the C-ABI call (kernel, log download, "
-                            "graph assembly on the host)" % (args.genome_len / 1e6, k, n, ),
+                            "to the child k-mer 200-2000 bp downstream on the seed's contig; timed: the C-ABI call (kernel, log expansion and download, "
+                            "graph assembly on the host: results of one branch per direction are kept as packed vertex entries, the others "
+                            "as vertex and edge lists)" % (args.genome_len / 1e6, k, n, ),
                 "records": N, "seeds_per_gpu": n, "kmers_traversed_per_step": traversed // args.steps, "sinks_reached": found,
                 "multi_gpu": "replicated graph, seeds partitioned, no data-path collective" if world > 1 else "single GPU",
                 "load_seconds": round(t_load, 2),
@@ -439,6 +451,8 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
             "roofline": {"bound": "hbm", "kernel": "k_dfs<%d>" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_kmer": b_find + b_link,
                          "avg_launch_ms": avg_ms, "launches": launches},
+            "with_graphs_fetched": {"ms_per_step": dt_fetched * 1e3, "value": (traversed / args.steps) / dt_fetched,
+                                    "note": "one call + unpacking every graph of the batch + k-mers and coverages of all their vertices gathered from the device"},
         }
         if not args.no_cpu_baseline:
             from oracle import pyoracle as orc

@@ -449,8 +449,8 @@ ldbg_status ldbg_dfs_result_sizes(const ldbg_dfs_result* r, int64_t i, int* is_n
     return guard([&] {
         const DfsGraphHost& g = dfs_at(r, i);
         if (is_null) *is_null = g.is_null ? 1 : 0;
-        if (n_vertices) *n_vertices = (int64_t)g.verts.size();
-        if (n_edges) *n_edges = (int64_t)g.edges.size();
+        if (n_vertices) *n_vertices = g.n_vertices();
+        if (n_edges) *n_edges = g.n_edges();
     });
 }
 ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result* r, int64_t i, uint64_t* kmer_words, int64_t* rec, int32_t* copy_index, int32_t* index,
@@ -459,6 +459,7 @@ ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result* r, int64_t i, uint64_t* k
         dfs_at(r, i);
         if (kmer_words) r->b->materialize();
         const DfsGraphHost& g = dfs_at(r, i);
+        if (g.packed) { r->b->read_packed(i, rec, copy_index, index, edge_src, edge_dst, edge_color); return; }    // (no k-mers asked for: straight from the packed entries)
         if (kmer_words && !g.words.empty()) memcpy(kmer_words, g.words.data(), g.words.size() * 8);
         for (size_t v = 0; v < g.verts.size(); v++) {
             if (rec) rec[v] = g.verts[v].rec;

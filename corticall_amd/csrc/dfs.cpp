@@ -1360,9 +1360,20 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)16, n / 64 + 1}));
     std::vector<std::vector<uint64_t>> thread_keys((size_t)n_threads);
     std::vector<std::string> thread_err((size_t)n_threads);
+    const size_t seg0 = out.packed_store.size();
+    out.packed_store.resize(seg0 + (size_t)n_threads);
+    out.color = color;
+    bool pack_flat = true;                                 // (the secondary colours below work on vertex lists)
+    for (int c = 0; c < graph->hdr.C; c++) {
+        bool sec = false, trav = false;
+        for (int j = 0; j < cfg.n_secondary; j++) sec |= cfg.secondary_colors[j] == c;
+        for (int j = 0; j < cfg.n_traversal; j++) trav |= cfg.traversal_colors[j] == c;
+        if (sec && !trav) pack_flat = false;
+    }
     auto assemble_range = [&](int t, int64_t lo, int64_t hi) {
         try {
             std::vector<uint64_t>& keys = thread_keys[(size_t)t];
+            std::vector<uint64_t>& store = out.packed_store[(size_t)(seg0 + t)];
             for (int64_t i = lo; i < hi; i++) {
                 DfsGraphHost& r = out.results[(size_t)(first + i)];
                 // the common result: every direction that ran is ONE branch of vertices with records (no junction taken, nothing to merge) —
@@ -1380,35 +1391,17 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
                         for (int64_t j = 1; flat && j < ln - 1; j++) flat = !(lg[j] & DFS_MARK) && path_idx(lg[j]) >= 0;
                     }
                     const bool null_r0 = !run_r || status[2 * i] != ST_OK, null_f0 = !run_f || status[2 * i + 1] != ST_OK;
-                    if (flat && any_dir && !(op_and ? (null_r0 || null_f0) : (null_r0 && null_f0))) {
+                    if (flat && any_dir && pack_flat && !(op_and ? (null_r0 || null_f0) : (null_r0 && null_f0))) {
+                        // kept packed: the vertex entries of the two branches (a branch that decided at its first vertex returns an empty graph)
                         r.is_null = false;
-                        int64_t nv = 0;
-                        for (int d = 0; d < 2; d++) if (status[2 * i + d] == ST_OK && dense_n[2 * i + d] > 3) nv += (int64_t)dense_n[2 * i + d] - 2;
-                        r.verts.reserve((size_t)nv);
-                        r.edges.reserve((size_t)nv);
-                        int seed_m = -1;
+                        r.packed = true;
+                        r.p_seg = (uint32_t)(seg0 + t);
+                        r.p_off = store.size();
                         for (int d = 0; d < 2; d++) {
                             const int64_t sidx = 2 * i + d;
-                            if (status[sidx] != ST_OK || dense_n[sidx] <= 3) continue;     // (a branch that decided at its first vertex returns an empty graph)
-                            const uint64_t* lg = log + strand_off[sidx] + 1;
-                            const int64_t cnt = (int64_t)dense_n[sidx] - 2;
-                            int prev = -1;
-                            for (int64_t j = 0; j < cnt; j++) {
-                                int at;
-                                if (j == 0 && seed_m >= 0) at = seed_m;
-                                else {
-                                    const uint64_t en = lg[j];
-                                    DfsVertex o;
-                                    o.rec = path_idx(en); o.flip = path_flip(en) ? 1 : 0; o.copy = path_copy(en); o.index = j == 0 ? 0 : (d == 0 ? -1 : 1);
-                                    o.slot = (int64_t)keys.size();
-                                    keys.push_back(((uint64_t)(o.rec + 1) << 1) | (uint64_t)o.flip);
-                                    at = (int)r.verts.size();
-                                    r.verts.push_back(o);
-                                    if (j == 0) seed_m = at;
-                                }
-                                if (j > 0) { if (d == 1) r.edges.push_back({prev, at, color}); else r.edges.push_back({at, prev, color}); }
-                                prev = at;
-                            }
+                            const uint32_t cnt = (status[sidx] == ST_OK && dense_n[sidx] > 3) ? dense_n[sidx] - 2 : 0u;
+                            (d == 0 ? r.n_rev : r.n_fwd) = cnt;
+                            if (cnt) store.insert(store.end(), log + strand_off[sidx] + 1, log + strand_off[sidx] + 1 + cnt);
                         }
                         continue;
                     }
@@ -1605,11 +1598,86 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
 }
 
 // k-mers and coverages of every vertex of the batch, gathered from the probe rows in one launch
+void DfsBatch::read_packed(int64_t i, int64_t* rec, int32_t* copy_index, int32_t* index, int32_t* edge_src, int32_t* edge_dst, int32_t* edge_color) const {
+    const DfsGraphHost& r = results[(size_t)i];
+    const uint64_t* en = packed_store[r.p_seg].data() + r.p_off;
+    int64_t v = 0, x = 0;
+    int seed_m = -1;
+    for (int d = 0; d < 2; d++) {
+        const uint32_t cnt = d == 0 ? r.n_rev : r.n_fwd;
+        int prev = -1;
+        for (uint32_t j = 0; j < cnt; j++) {
+            int at;
+            if (j == 0 && seed_m >= 0) at = seed_m;
+            else {
+                const uint64_t e = en[j];
+                if (rec) rec[v] = path_idx(e);
+                if (copy_index) copy_index[v] = path_copy(e);
+                if (index) index[v] = j == 0 ? 0 : (d == 0 ? -1 : 1);
+                at = (int)v++;
+                if (j == 0) seed_m = at;
+            }
+            if (j > 0) {
+                if (edge_src) edge_src[x] = d == 1 ? prev : at;
+                if (edge_dst) edge_dst[x] = d == 1 ? at : prev;
+                if (edge_color) edge_color[x] = color;
+                x++;
+            }
+            prev = at;
+        }
+        en += cnt;
+    }
+}
+
 void DfsBatch::materialize() {
     if (materialized) return;
     materialized = true;
     rt::set_device(graph->device);
     rt::stream_t s = graph->stream;
+    {   // packed results -> vertex and edge lists, their keys joining the batch's lists (one more segment per thread)
+        const int64_t nres = (int64_t)results.size();
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)16, nres / 64 + 1}));
+        std::vector<std::vector<uint64_t>> tk((size_t)nt);
+        const int64_t per = (nres + nt - 1) / nt;
+        auto unpack = [&](int t) {
+            std::vector<uint64_t>& keys = tk[(size_t)t];
+            std::vector<int64_t> rec;
+            std::vector<int32_t> cp, ix, es, et, ec;
+            for (int64_t i = std::min<int64_t>(nres, t * per); i < std::min<int64_t>(nres, (t + 1) * per); i++) {
+                DfsGraphHost& r = results[(size_t)i];
+                if (!r.packed) continue;
+                const int64_t nv = r.n_vertices(), ne = r.n_edges();
+                rec.resize((size_t)nv); cp.resize((size_t)nv); ix.resize((size_t)nv); es.resize((size_t)ne); et.resize((size_t)ne); ec.resize((size_t)ne);
+                read_packed(i, rec.data(), cp.data(), ix.data(), es.data(), et.data(), ec.data());
+                const uint64_t* en = packed_store[r.p_seg].data() + r.p_off;
+                r.verts.resize((size_t)nv);
+                r.edges.resize((size_t)ne);
+                int64_t v = 0;
+                for (int d = 0; d < 2; d++) {
+                    const uint32_t cnt = d == 0 ? r.n_rev : r.n_fwd;
+                    for (uint32_t j = (d == 1 && r.n_rev) ? 1u : 0u; j < cnt; j++, v++) {
+                        DfsVertex& o = r.verts[(size_t)v];
+                        o.rec = rec[(size_t)v]; o.copy = cp[(size_t)v]; o.index = ix[(size_t)v]; o.flip = path_flip(en[j]) ? 1 : 0;
+                        o.slot = (int64_t)keys.size();
+                        keys.push_back(((uint64_t)(o.rec + 1) << 1) | (uint64_t)o.flip);
+                    }
+                    en += cnt;
+                }
+                for (int64_t x = 0; x < ne; x++) r.edges[(size_t)x] = {es[(size_t)x], et[(size_t)x], ec[(size_t)x]};
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(unpack, t);
+        unpack(0);
+        for (auto& th : pool) th.join();
+        for (int t = 0; t < nt; t++) {
+            for (int64_t i = std::min<int64_t>(nres, t * per); i < std::min<int64_t>(nres, (t + 1) * per); i++)
+                if (results[(size_t)i].packed) { results[(size_t)i].slot_base = n_gather; results[(size_t)i].packed = false; }
+            n_gather += (int64_t)tk[(size_t)t].size();
+            key_segments.push_back(std::move(tk[(size_t)t]));
+        }
+        std::vector<std::vector<uint64_t>>().swap(packed_store);
+    }
     const int64_t ng = n_gather;
     std::vector<uint64_t> gw((size_t)std::max<int64_t>(1, ng) * W);
     std::vector<uint32_t> gc((size_t)std::max<int64_t>(1, ng) * C);

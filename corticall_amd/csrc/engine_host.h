@@ -35,6 +35,14 @@ struct DfsVertex { int64_t rec; int64_t slot; int32_t copy, index; uint8_t flip;
 struct DfsEdge { int src, dst, color; };
 struct DfsGraphHost {
     bool is_null = true;                   // dfs() returned null
+    // a result whose directions are each one branch of vertices with records is kept PACKED until its vertex list is asked for with
+    // k-mers (DfsBatch::materialize): the log entries of the reverse branch (seed first), then those of the forward branch, in
+    // DfsBatch::packed_store[p_seg] from p_off on.  The graph is the two paths joined at the seed (TraversalEngine.java:75-99).
+    bool packed = false;
+    uint32_t n_rev = 0, n_fwd = 0, p_seg = 0;
+    uint64_t p_off = 0;
+    int64_t n_vertices() const { return packed ? (int64_t)n_rev + n_fwd - ((n_rev && n_fwd) ? 1 : 0) : (int64_t)verts.size(); }
+    int64_t n_edges() const { return packed ? (int64_t)(n_rev ? n_rev - 1 : 0) + (n_fwd ? n_fwd - 1 : 0) : (int64_t)edges.size(); }
     int64_t slot_base = 0;                 // added to the slots of the vertices with records (their place among DfsBatch::key_segments)
     std::vector<DfsVertex> verts;          // insertion order
     std::vector<DfsEdge> edges;            // insertion order
@@ -48,6 +56,10 @@ struct DfsBatch {
     std::vector<DfsGraphHost> results;
     // the k-mer words and coverages of the vertices are gathered from the device on first use (the graph must still be open)
     const Graph* graph = nullptr;
+    std::vector<std::vector<uint64_t>> packed_store;   // vertex entries (engine.h: path_pack) of the packed results
+    int color = 0;                                     // colour of the edges (the first traversal colour, TraversalEngine.java:502)
+    // vertices and edges of packed result i in the reference's insertion order, without unpacking it (outputs may be null)
+    void read_packed(int64_t i, int64_t* rec, int32_t* copy_index, int32_t* index, int32_t* edge_src, int32_t* edge_dst, int32_t* edge_color) const;
     std::vector<std::vector<uint64_t>> key_segments;   // keys ((record + 1) << 1 | flip) of the vertices to gather, in segments laid end to end
     int64_t n_gather = 0;
     bool materialized = false;

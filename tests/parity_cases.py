@@ -736,6 +736,49 @@ def case_dfs_run_steps(orc, lib, tmp, seed):
         compare_dfs(cs, seeds[:25], sinks=sinks[:25], trav=[0], stopper=stopper, links=["a"], max_len=rng.choice([333, 2500, 20000]))
 
 
+def case_dfs_packed_results(orc, lib, tmp):
+    """results that are one branch per direction stay packed until their k-mers are asked for: sizes and the vertex / edge lists read
+    from the packed form (ldbg_dfs_result_get without k-mer words) are those of the unpacked graphs"""
+    import ctypes as C
+    rng = random.Random(31)
+    g1 = rand_seq(rng, 900)
+    cs = Case(orc, tmp, lib, [("a", [g1])], 15, link_samples=["a"], name="packed")
+    seeds = [g1[i:i + 15] for i in (0, 100, 417, 885)] + [orc.revcomp(g1[300:315]), rand_seq(rng, 15)]
+    sinks = [[g1[i:i + 15]] for i in (60, 300, 500, 880)] + [[orc.revcomp(g1[250:265])], [g1[:15]]]
+    for direction in (BOTH, FORWARD):
+        e = (TraversalEngineFactory(lib=lib).traversalColors(0).traversalDirection(direction).combinationOperator(OR).stoppingRule("DestinationStopper")
+             .graph(cs.g).links(cs.links["a"]).make())
+        src = np.frombuffer("".join(seeds).encode(), dtype=np.uint8)
+        sink_buf = np.frombuffer("".join(x[0] for x in sinks).encode(), dtype=np.uint8)
+        off = np.arange(len(seeds) + 1, dtype=np.int64)
+        batch = e.dfs_batch_arrays(src, len(seeds), sink_buf, off)
+        raw = []
+        for i in range(len(seeds)):
+            isnull, nv, ne = C.c_int(), C.c_int64(), C.c_int64()
+            e._lib.check(e._d.ldbg_dfs_result_sizes(batch.h, C.c_int64(i), C.byref(isnull), C.byref(nv), C.byref(ne)))
+            if isnull.value:
+                raw.append(None)
+                continue
+            rec, cp, ix = np.zeros(max(1, nv.value), np.int64), np.zeros(max(1, nv.value), np.int32), np.zeros(max(1, nv.value), np.int32)
+            es, et, ec = (np.zeros(max(1, ne.value), np.int32) for _ in range(3))
+            P = lambda a: a.ctypes.data_as(C.c_void_p)
+            e._lib.check(e._d.ldbg_dfs_result_get(batch.h, C.c_int64(i), None, P(rec), P(cp), P(ix), P(es), P(et), P(ec)))
+            raw.append((nv.value, ne.value, list(rec[:nv.value]), list(cp[:nv.value]), list(ix[:nv.value]), list(zip(es[:ne.value], et[:ne.value], ec[:ne.value]))))
+        n_graphs = 0
+        for i in range(len(seeds)):
+            gi = batch.graph(i)
+            assert (gi is None) == (raw[i] is None)
+            if gi is None:
+                continue
+            vt, et_ = gi.vertex_tuples(), gi.edge_tuples()          # (asks for the k-mers: the batch is unpacked here)
+            assert raw[i][0] == len(vt) and raw[i][1] == len(et_)
+            assert raw[i][2] == [v[1] for v in vt] and raw[i][3] == [v[2] for v in vt] and raw[i][4] == [v[3] for v in vt]
+            assert [tuple(int(x) for x in t) for t in raw[i][5]] == et_
+            n_graphs += 1
+        assert n_graphs >= 4
+        e.close()
+
+
 def case_dfs_dense(orc, lib, tmp, seed):
     """tiny k: junctions everywhere, deep recursion, many failing branches (visited-set undo, log truncation)"""
     rng = random.Random(1000 + seed)
