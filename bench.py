@@ -393,7 +393,7 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
     sink_buf = np.ascontiguousarray(sink).reshape(-1)
     src = np.ascontiguousarray(seeds).reshape(-1)
     eng = (TraversalEngineFactory().traversalColors(g.getColorForSampleName("child")).traversalDirection(FORWARD)
-           .combinationOperator(OR).stoppingRule(DestinationStopper).maxBranchLength(args.max_len).graph(g).links(links).make())
+           .combinationOperator(OR).stoppingRule(args.stopper).maxBranchLength(args.max_len).graph(g).links(links).make())
     n = len(seeds)
     for _ in range(args.warmup):
         eng.dfs_batch_arrays(src, n, sink_buf, sink_off)
@@ -440,7 +440,7 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {
-                "workload": "configs[3]: same %.1f Mb 3-colour k=%d LdBG with child links; dfs with DestinationStopper, FORWARD, from %d seeds per GPU "
+                "workload": "configs[3]: same %.1f Mb 3-colour k=%d LdBG with child links; dfs with " + args.stopper + ", FORWARD, from %d seeds per GPU "
                             "to the child k-mer 200-2000 bp downstream on the seed's contig; timed: the C-ABI call (kernel, log expansion and download, "
                             "graph assembly on the host: results of one branch per direction are kept as packed vertex entries, the others "
                             "as vertex and edge lists)" % (args.genome_len / 1e6, k, n, ),
@@ -458,7 +458,7 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
             from oracle import pyoracle as orc
             og = orc.Graph(prefix + ".ctx", use_cache=True, tuned=False)
             ol = orc.Links(prefix + ".ctp.gz")
-            oe = orc.Engine(og, [0], links=[ol], stopper="DestinationStopper", max_length=args.max_len, direction=orc.FORWARD)
+            oe = orc.Engine(og, [0], links=[ol], stopper=args.stopper, max_length=args.max_len, direction=orc.FORWARD)
             t1 = time.time()
             i = mism = 0
             while i < n and time.time() - t1 < args.cpu_seconds:
@@ -498,6 +498,7 @@ def main():
     ap.add_argument("--check-every", type=int, default=16, help="--sharded: rounds between two looks at the 'anyone still walking' count")
     ap.add_argument("--workload", choices=["c3", "c4", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
+    ap.add_argument("--stopper", default="DestinationStopper", help="c4: the stopping rule of the searches (SURVEY 8d also names ExplorationStopper)")
     ap.add_argument("--use-seeds", type=int, default=0, help="experiment: walk only the first N seeds")
     ap.add_argument("--no-links", action="store_true", help="experiment: walk without the link annotations")
     ap.add_argument("--no-strict", action="store_true", help="experiment: CanonicalKmer.isFlipped by comparison (not Java-exact, Q6)")

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out_dir = os.path.join(ROOT, "profiles")
-WALK_KERNELS = ("k_walk", "k_expand_paths", "k_contigs", "k_zero16", "k_walk_lengths")
+WALK_KERNELS = ("k_walk", "k_expand_paths", "k_contigs", "k_zero16", "k_walk_lengths", "k_dfs", "k_path_lengths")
 
 
 def rows(pattern):
