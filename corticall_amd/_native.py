@@ -64,7 +64,7 @@ EXPORTS = [
     "ldbg_graph_sample_name", "ldbg_graph_color_info", "ldbg_graph_color_for_sample_name",
     "ldbg_graph_records", "ldbg_graph_records_dev", "ldbg_graph_find", "ldbg_graph_find_ascii", "ldbg_graph_find_dev", "ldbg_shard_owner_dev", "ldbg_shard_owner", "ldbg_shard_nbr_queries", "ldbg_shard_set_nbr",
     "ldbg_image_create", "ldbg_image_destroy", "ldbg_image_graph", "ldbg_image_row_bytes", "ldbg_image_clear", "ldbg_image_request", "ldbg_image_reset_requests", "ldbg_image_bucket",
-    "ldbg_image_serve", "ldbg_image_insert", "ldbg_image_lookup", "ldbg_image_counters",
+    "ldbg_image_serve", "ldbg_image_serve_chain", "ldbg_image_insert", "ldbg_image_lookup", "ldbg_image_counters",
     "ldbg_engine_sharded_walk_begin", "ldbg_engine_sharded_walk_round", "ldbg_engine_sharded_walk_finish", "ldbg_engine_sharded_dfs_batch",
     "ldbg_links_open", "ldbg_links_close", "ldbg_links_index", "ldbg_links_source", "ldbg_links_info", "ldbg_links_sample_name", "ldbg_links_get",
     "ldbg_engine_config_default", "ldbg_engine_create", "ldbg_engine_destroy",

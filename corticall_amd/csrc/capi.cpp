@@ -221,7 +221,10 @@ ldbg_status ldbg_image_row_bytes(const ldbg_image* im, int* bytes) { return guar
 ldbg_status ldbg_image_clear(ldbg_image* im) { return guard([&] { rt::set_device(im->img.graph().device); im->img.clear(); }); }
 static rt::stream_t image_stream(const ldbg_image* im, void* stream) { return stream ? (rt::stream_t)stream : im->img.graph().stream; }
 ldbg_status ldbg_image_serve(const ldbg_image* im, int my_rank, const uint64_t* d_keys, int64_t n, uint8_t* d_out, void* stream) {
-    return guard([&] { rt::set_device(im->img.graph().device); im->img.serve(my_rank, (const unsigned long long*)d_keys, n, d_out, image_stream(im, stream)); });
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.serve(my_rank, (const unsigned long long*)d_keys, n, 1, d_out, image_stream(im, stream)); });
+}
+ldbg_status ldbg_image_serve_chain(const ldbg_image* im, int my_rank, const uint64_t* d_keys, int64_t n, int depth, uint8_t* d_out, void* stream) {
+    return guard([&] { rt::set_device(im->img.graph().device); im->img.serve(my_rank, (const unsigned long long*)d_keys, n, depth, d_out, image_stream(im, stream)); });
 }
 ldbg_status ldbg_image_insert(ldbg_image* im, const ldbg_engine* e, const uint8_t* d_rows, int64_t n, void* stream) {
     return guard([&] { rt::set_device(im->img.graph().device); im->img.insert(e ? &e->e : nullptr, d_rows, n, image_stream(im, stream)); });

@@ -174,11 +174,33 @@ LDBG_KERNEL void k_find(GraphView g, const uint64_t* packed, const uint8_t* vmas
     }
 }
 
-// owner of a k-mer in a table hash-partitioned over `world` devices: a 64-bit mix of the CANONICAL k-mer's words.
+// owner of a k-mer in a table hash-partitioned over `world` devices: a 64-bit mix of the k-mer's MINIMIZER — the m-mer (in its own
+// canonical orientation, so that a k-mer and its reverse complement agree) with the smallest mixed value, m = shard_minimizer_len(k).
+// Consecutive k-mers of a walk share their minimizer more often than not (a run of about (k - m) / 2 of them), so most of a walk's
+// successors live on the owner of the row that was just asked for and can be sent along with it (image.cpp: k_serve_chain) — the
+// table is still spread by a hash, and the cross-shard lookups per traversed k-mer drop by that run length.
 // Queries that are not k-mers (Q4) go to shard 0, where they miss like everywhere else.
 LDBG_HOSTDEV uint64_t shard_mix64(uint64_t x) {
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
     return x;
+}
+LDBG_HOSTDEV int shard_minimizer_len(int k) { return k <= 8 ? k : (k + 2) / 3; }
+template <int W>
+LDBG_HOSTDEV uint64_t shard_minimizer_hash(const Kmer<W>& q, int k) {
+    const int m = shard_minimizer_len(k);
+    const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+    uint64_t fw = 0, rv = 0, best = ~0ull;
+    for (int j = 0; j < k; j++) {
+        const int bit = 2 * (k - 1 - j);                       // base j of the k-mer, first base most significant (kmer.h)
+        const uint64_t code = (kmer_word<W>(q, W - 1 - (bit >> 6)) >> (bit & 63)) & 3ull;
+        fw = ((fw << 2) | code) & mask;
+        rv = (rv >> 2) | ((3ull - code) << (2 * (m - 1)));
+        if (j >= m - 1) {
+            const uint64_t h = shard_mix64((fw < rv ? fw : rv) ^ 0x9E3779B97F4A7C15ull);
+            if (h < best) best = h;
+        }
+    }
+    return best;
 }
 template <int W>
 LDBG_KERNEL void k_owner(int k, const uint64_t* packed, int64_t n, int world, uint64_t* canon_out, int32_t* owner_out) {
@@ -192,10 +214,7 @@ LDBG_KERNEL void k_owner(int k, const uint64_t* packed, int64_t n, int world, ui
         if (valid) {
             bool f;
             q = kmer_canonical<W>(q, k, &f);
-            uint64_t h = 0x9E3779B97F4A7C15ull;
-#pragma unroll
-            for (int w = 0; w < W; w++) h = shard_mix64(h ^ kmer_word<W>(q, w));
-            owner = (int32_t)(h % (uint64_t)world);
+            owner = (int32_t)(shard_minimizer_hash<W>(q, k) % (uint64_t)world);
         }
         if (canon_out) for (int w = 0; w < W; w++) canon_out[i * W + w] = kmer_word<W>(q, w);
         owner_out[i] = owner;

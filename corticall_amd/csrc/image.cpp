@@ -17,21 +17,49 @@ int grid_of(int64_t n, int block = 256, int max_blocks = 4096) {
 }
 
 // ---- owner side: a "fat row" = own global id key | 8 global neighbour ids | the probe row
-LDBG_KERNEL void k_serve_fat(GraphView g, const uint64_t* nbrg, int my_rank, const unsigned long long* keys, int64_t n, int rowb, uint8_t* out) {
+LDBG_DEV void serve_row(const GraphView& g, const uint64_t* nbrg, int my_rank, int64_t r, uint64_t* o) {
     const int words = g.stride / 8;
-    for (int64_t t = global_tid(); t < n * (9 + words); t += global_nthreads()) {
-        const int64_t i = t / (9 + words);
-        const int w = (int)(t % (9 + words));
+    o[0] = gid_key(gid_make(my_rank, r, false));
+    for (int w = 0; w < 8; w++) o[1 + w] = nbrg[r * 8 + w];
+    const uint64_t* row = (const uint64_t*)graph_row(g, r);
+    for (int w = 0; w < words; w++) o[9 + w] = row[w];
+}
+// The row asked for and, in the `depth - 1` slots after it, rows the asker is likely to want next: from the record outwards in both
+// directions along edges (of any colour) for as long as the neighbour is unique and lives on this shard too — with ownership by
+// minimizer (graph.cpp) that is the usual case.  Where the way forks, the local neighbours of the fork are sent and that direction
+// ends.  What is sent beyond the first row is a prefetch: results never depend on it (an image row is the owner's row, whoever asked).
+LDBG_KERNEL void k_serve_chain(GraphView g, const uint64_t* nbrg, int my_rank, const unsigned long long* keys, int64_t n, int rowb, int depth, uint8_t* out) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        uint8_t* o = out + (size_t)i * (size_t)depth * (size_t)rowb;
+        for (int d = 0; d < depth; d++) ((uint64_t*)(o + (size_t)d * rowb))[0] = 0ull;        // key 0: nothing in this slot
         const uint64_t key = keys[i];
-        uint64_t* o = (uint64_t*)(out + (size_t)i * rowb);
-        const int64_t r = gid_lidx(key);
-        const bool mine = gid_owner(key) == my_rank && r >= 0 && r < g.N;
-        uint64_t v = 0;
-        if (w == 0) v = mine ? key : 0ull;                                // key 0: nothing served (a request that does not belong here)
-        else if (!mine) v = 0;
-        else if (w < 9) v = nbrg[r * 8 + (w - 1)];
-        else v = ((const uint64_t*)graph_row(g, r))[w - 9];
-        o[w] = v;
+        const int64_t r0 = gid_lidx(key);
+        if (!(gid_owner(key) == my_rank && r0 >= 0 && r0 < g.N)) continue;                    // (a request that does not belong here)
+        serve_row(g, nbrg, my_rank, r0, (uint64_t*)o);
+        int used = 1;
+        for (int dir = 0; dir < 2 && used < depth; dir++) {
+            const int budget = used + (depth - used) / (2 - dir);                              // half of what is left per direction
+            int64_t r = r0;
+            bool rc = dir == 1;                                                                // dir 1: backwards = forwards along the reverse complement
+            while (used < budget) {
+                const uint64_t* nb = nbrg + r * 8 + (rc ? 4 : 0);
+                int cnt = 0, last = -1;
+                for (int b = 0; b < 4; b++) if (nb[b] != 0ull) { cnt++; last = b; }
+                if (cnt == 0) break;
+                if (cnt > 1) {                                                                 // a fork: its local arms, then stop
+                    for (int b = 0; b < 4 && used < budget; b++)
+                        if (nb[b] != 0ull && gid_owner(nb[b]) == my_rank) { serve_row(g, nbrg, my_rank, gid_lidx(nb[b]), (uint64_t*)(o + (size_t)used * rowb)); used++; }
+                    break;
+                }
+                const uint64_t nx = nb[last];
+                if (gid_owner(nx) != my_rank) break;
+                r = gid_lidx(nx);
+                if (r == r0) break;                                                            // round a cycle
+                rc = rc != ((nx >> 63) != 0ull);
+                serve_row(g, nbrg, my_rank, r, (uint64_t*)(o + (size_t)used * rowb));
+                used++;
+            }
+        }
     }
 }
 
@@ -158,11 +186,11 @@ ImageView ShardImage::view(uint64_t* rec_of) const {
 }
 int ShardImage::row_bytes() const { return 72 + shard_.view.stride; }
 
-void ShardImage::serve(int my_rank, const unsigned long long* d_keys, int64_t n, uint8_t* d_out, rt::stream_t s) const {
+void ShardImage::serve(int my_rank, const unsigned long long* d_keys, int64_t n, int depth, uint8_t* d_out, rt::stream_t s) const {
     if (n <= 0) return;
     if (!shard_.d_nbrg) throw StatusError(LDBG_ERR_ARG, "image: the global neighbour index of this shard has not been built");
-    const int words = 9 + shard_.view.stride / 8;
-    LDBG_LAUNCH(k_serve_fat, grid_of(n * words), 256, s, shard_.view, (const uint64_t*)shard_.d_nbrg, my_rank, d_keys, n, row_bytes(), d_out);
+    if (depth < 1) throw StatusError(LDBG_ERR_ARG, "image: serve depth < 1");
+    LDBG_LAUNCH(k_serve_chain, grid_of(n, 64, 1 << 16), 64, s, shard_.view, (const uint64_t*)shard_.d_nbrg, my_rank, d_keys, n, row_bytes(), depth, d_out);
 }
 
 void ShardImage::insert(const Engine* e, const uint8_t* d_rows, int64_t n, rt::stream_t s) {

@@ -25,8 +25,9 @@ public:
     int64_t capacity() const { return cap_; }
     int row_bytes() const;                                     // bytes of one served row: global id key | 8 neighbour ids | probe row
     void clear();                                              // forget every row (a new batch starts from an empty image)
-    // owner side: rows for `n` requested global id keys -> d_out[n][row_bytes]
-    void serve(int my_rank, const unsigned long long* d_keys, int64_t n, uint8_t* d_out, rt::stream_t s) const;
+    // owner side: rows for `n` requested global id keys -> d_out[n][depth][row_bytes]: the row asked for, then up to depth - 1 rows around it
+    // that live on this shard too (key 0 = unused slot)
+    void serve(int my_rank, const unsigned long long* d_keys, int64_t n, int depth, uint8_t* d_out, rt::stream_t s) const;
     // requester side: rows that arrived (key 0 = none); e: the engine whose link table names the rows' link records (may be null)
     void insert(const Engine* e, const uint8_t* d_rows, int64_t n, rt::stream_t s);
     void lookup(const unsigned long long* d_keys, int64_t n, int32_t* d_slots, rt::stream_t s) const;

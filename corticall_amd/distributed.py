@@ -250,7 +250,7 @@ class ShardedTraversalEngine:
     links: CortexLinks objects opened on `sgraph.shard` (each rank opens the link file against its own shard)."""
 
     def __init__(self, sgraph, traversal_colors, links=(), recruitment_colors=(), joining_colors=(), direction=0, op=0, max_branch_length=75000,
-                 stopping_rule=None, image_rows=None, rows_per_owner=4096, check_every=8, keep_image=False):
+                 stopping_rule=None, image_rows=None, rows_per_owner=4096, check_every=8, keep_image=False, chain_depth=16):
         from .traversal import ContigStopper, TraversalEngineFactory
         self.g = sgraph
         if not sgraph.has_neighbour_index:
@@ -276,6 +276,7 @@ class ShardedTraversalEngine:
             f.links(*links)
         self.engine = f.make()
         self.rows_per_owner = int(rows_per_owner)
+        self.chain_depth = max(1, int(chain_depth))      # row slots per request: the row asked for + rows around it its owner holds too
         self.check_every = int(check_every)
         self.keep_image = keep_image
         self.kmers_traversed = 0
@@ -284,8 +285,8 @@ class ShardedTraversalEngine:
         w, cap_o = sgraph.world, self.rows_per_owner
         self._send = torch.zeros((w, cap_o), dtype=torch.int64, device=sgraph.device)
         self._recv = torch.zeros((w, cap_o), dtype=torch.int64, device=sgraph.device)
-        self._rows_out = torch.zeros((w, cap_o, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
-        self._rows_in = torch.zeros((w, cap_o, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
+        self._rows_out = torch.zeros((w, cap_o, self.chain_depth, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
+        self._rows_in = torch.zeros((w, cap_o, self.chain_depth, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
         self._stats = torch.zeros(2, dtype=torch.int64, device=sgraph.device)
         self._tstream = torch.cuda.Stream(device=sgraph.device) if sgraph.device.type == "cuda" else None
 
@@ -301,9 +302,9 @@ class ShardedTraversalEngine:
         n = g.world * self.rows_per_owner
         lib.check(d.ldbg_image_bucket(self._img, g.world, C.c_uint32(self.rows_per_owner), P(self._send), stream))
         dist.all_to_all_single(self._recv.view(-1), self._send.view(-1), group=g._group)
-        lib.check(d.ldbg_image_serve(self._img, g.rank, P(self._recv), C.c_int64(n), P(self._rows_out), stream))
+        lib.check(d.ldbg_image_serve_chain(self._img, g.rank, P(self._recv), C.c_int64(n), C.c_int(self.chain_depth), P(self._rows_out), stream))
         dist.all_to_all_single(self._rows_in.view(-1), self._rows_out.view(-1), group=g._group)
-        lib.check(d.ldbg_image_insert(self._img, self.engine._h, P(self._rows_in), C.c_int64(n), stream))
+        lib.check(d.ldbg_image_insert(self._img, self.engine._h, P(self._rows_in), C.c_int64(n * self.chain_depth), stream))
 
     def _all_done(self, local_count):
         t = local_count.clone().reshape(1)

@@ -162,6 +162,10 @@ ldbg_status ldbg_image_request(ldbg_image* im, const uint64_t* d_keys, int64_t n
 ldbg_status ldbg_image_reset_requests(ldbg_image* im, void* stream);
 ldbg_status ldbg_image_bucket(ldbg_image* im, int world, uint32_t cap_per_owner, uint64_t* d_send /* [world][cap_per_owner], 0 = unused */, void* stream);
 ldbg_status ldbg_image_serve(const ldbg_image* im, int my_rank, const uint64_t* d_keys, int64_t n, uint8_t* d_rows_out, void* stream);
+/* as ldbg_image_serve, `depth` row slots per request: the row asked for, then rows around it that this owner holds too (its unique
+ * neighbours outwards in both directions; ownership goes by minimizer, so these are mostly the rows the asker wants next).  A slot
+ * whose key is 0 is unused.  d_rows_out: [n][depth][row_bytes]; hand all n * depth slots to ldbg_image_insert. */
+ldbg_status ldbg_image_serve_chain(const ldbg_image* im, int my_rank, const uint64_t* d_keys, int64_t n, int depth, uint8_t* d_rows_out, void* stream);
 ldbg_status ldbg_image_insert(ldbg_image* im, const struct ldbg_engine* engine_or_null, const uint8_t* d_rows, int64_t n, void* stream);
 ldbg_status ldbg_image_lookup(const ldbg_image* im, const uint64_t* d_keys, int64_t n, int32_t* d_slots /* -1 = not in the image */, void* stream);
 ldbg_status ldbg_image_counters(const ldbg_image* im, int64_t* n_rows, int64_t* n_requests, int* overflow);   /* synchronises */
