@@ -17,25 +17,19 @@ int grid_of(int64_t n, int block = 256, int max_blocks = 4096) {
 }
 
 // ---- owner side: a "fat row" = own global id key | 8 global neighbour ids | the probe row
-LDBG_DEV void serve_row(const GraphView& g, const uint64_t* nbrg, int my_rank, int64_t r, uint64_t* o) {
-    const int words = g.stride / 8;
-    o[0] = gid_key(gid_make(my_rank, r, false));
-    for (int w = 0; w < 8; w++) o[1 + w] = nbrg[r * 8 + w];
-    const uint64_t* row = (const uint64_t*)graph_row(g, r);
-    for (int w = 0; w < words; w++) o[9 + w] = row[w];
-}
 // The row asked for and, in the `depth - 1` slots after it, rows the asker is likely to want next: from the record outwards in both
 // directions along edges (of any colour) for as long as the neighbour is unique and lives on this shard too — with ownership by
 // minimizer (graph.cpp) that is the usual case.  Where the way forks, the local neighbours of the fork are sent and that direction
 // ends.  What is sent beyond the first row is a prefetch: results never depend on it (an image row is the owner's row, whoever asked).
-LDBG_KERNEL void k_serve_chain(GraphView g, const uint64_t* nbrg, int my_rank, const unsigned long long* keys, int64_t n, int rowb, int depth, uint8_t* out) {
+// Two kernels: one thread per request picks the records (plan[n][depth], -1 = unused slot), then one thread per word copies the rows.
+LDBG_KERNEL void k_serve_plan(GraphView g, const uint64_t* nbrg, int my_rank, const unsigned long long* keys, int64_t n, int depth, int64_t* plan) {
     for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
-        uint8_t* o = out + (size_t)i * (size_t)depth * (size_t)rowb;
-        for (int d = 0; d < depth; d++) ((uint64_t*)(o + (size_t)d * rowb))[0] = 0ull;        // key 0: nothing in this slot
+        int64_t* pl = plan + i * depth;
+        for (int d = 0; d < depth; d++) pl[d] = -1;
         const uint64_t key = keys[i];
         const int64_t r0 = gid_lidx(key);
         if (!(gid_owner(key) == my_rank && r0 >= 0 && r0 < g.N)) continue;                    // (a request that does not belong here)
-        serve_row(g, nbrg, my_rank, r0, (uint64_t*)o);
+        pl[0] = r0;
         int used = 1;
         for (int dir = 0; dir < 2 && used < depth; dir++) {
             const int budget = used + (depth - used) / (2 - dir);                              // half of what is left per direction
@@ -48,7 +42,7 @@ LDBG_KERNEL void k_serve_chain(GraphView g, const uint64_t* nbrg, int my_rank, c
                 if (cnt == 0) break;
                 if (cnt > 1) {                                                                 // a fork: its local arms, then stop
                     for (int b = 0; b < 4 && used < budget; b++)
-                        if (nb[b] != 0ull && gid_owner(nb[b]) == my_rank) { serve_row(g, nbrg, my_rank, gid_lidx(nb[b]), (uint64_t*)(o + (size_t)used * rowb)); used++; }
+                        if (nb[b] != 0ull && gid_owner(nb[b]) == my_rank) pl[used++] = gid_lidx(nb[b]);
                     break;
                 }
                 const uint64_t nx = nb[last];
@@ -56,10 +50,25 @@ LDBG_KERNEL void k_serve_chain(GraphView g, const uint64_t* nbrg, int my_rank, c
                 r = gid_lidx(nx);
                 if (r == r0) break;                                                            // round a cycle
                 rc = rc != ((nx >> 63) != 0ull);
-                serve_row(g, nbrg, my_rank, r, (uint64_t*)(o + (size_t)used * rowb));
-                used++;
+                pl[used++] = r;
             }
         }
+    }
+}
+// a "fat row" = own global id key | 8 global neighbour ids | the probe row
+LDBG_KERNEL void k_serve_rows(GraphView g, const uint64_t* nbrg, int my_rank, const int64_t* plan, int64_t n_slots, int rowb, uint8_t* out) {
+    const int words = 9 + g.stride / 8;
+    for (int64_t t = global_tid(); t < n_slots * words; t += global_nthreads()) {
+        const int64_t i = t / words;
+        const int w = (int)(t % words);
+        const int64_t r = plan[i];
+        uint64_t v = 0;
+        if (r >= 0) {
+            if (w == 0) v = gid_key(gid_make(my_rank, r, false));
+            else if (w < 9) v = nbrg[r * 8 + (w - 1)];
+            else v = ((const uint64_t*)graph_row(g, r))[w - 9];
+        } else if (w != 0) continue;                                                           // (an unused slot: only its key, 0, is written)
+        ((uint64_t*)(out + (size_t)i * rowb))[w] = v;
     }
 }
 
@@ -165,7 +174,7 @@ ShardImage::ShardImage(const Graph& shard, int64_t cap, int64_t global_records) 
     d_bcount_ = rt::dmalloc(256 * 8);
     clear();
 }
-ShardImage::~ShardImage() { rt::dfree(d_nbrg_); rt::dfree(d_gkey_); rt::dfree(d_hkeys_); rt::dfree(d_hvals_); rt::dfree(d_ctr_); rt::dfree(d_req_); rt::dfree(d_bcount_); rt::dfree(d_rec_of_own_); }
+ShardImage::~ShardImage() { rt::dfree(d_nbrg_); rt::dfree(d_gkey_); rt::dfree(d_hkeys_); rt::dfree(d_hvals_); rt::dfree(d_ctr_); rt::dfree(d_req_); rt::dfree(d_bcount_); rt::dfree(d_rec_of_own_); rt::dfree(d_plan_); }
 
 void ShardImage::clear() {
     rt::stream_t s = graph_->stream;
@@ -190,7 +199,11 @@ void ShardImage::serve(int my_rank, const unsigned long long* d_keys, int64_t n,
     if (n <= 0) return;
     if (!shard_.d_nbrg) throw StatusError(LDBG_ERR_ARG, "image: the global neighbour index of this shard has not been built");
     if (depth < 1) throw StatusError(LDBG_ERR_ARG, "image: serve depth < 1");
-    LDBG_LAUNCH(k_serve_chain, grid_of(n, 64, 1 << 16), 64, s, shard_.view, (const uint64_t*)shard_.d_nbrg, my_rank, d_keys, n, row_bytes(), depth, d_out);
+    const size_t need = (size_t)n * (size_t)depth * 8;
+    if (need > plan_bytes_) { rt::dfree(d_plan_); d_plan_ = rt::dmalloc(need); plan_bytes_ = need; }
+    LDBG_LAUNCH(k_serve_plan, grid_of(n), 256, s, shard_.view, (const uint64_t*)shard_.d_nbrg, my_rank, d_keys, n, depth, (int64_t*)d_plan_);
+    const int words = 9 + shard_.view.stride / 8;
+    LDBG_LAUNCH(k_serve_rows, grid_of(n * depth * words), 256, s, shard_.view, (const uint64_t*)shard_.d_nbrg, my_rank, (const int64_t*)d_plan_, n * depth, row_bytes(), d_out);
 }
 
 void ShardImage::insert(const Engine* e, const uint8_t* d_rows, int64_t n, rt::stream_t s) {
