@@ -215,7 +215,7 @@ def bench_c3_sharded(args, ca, prefix, st, seeds, rank, local_rank, world, dist)
     t_load = time.time() - t0
     links = [] if args.no_links else [CortexLinks(prefix + ".ctp.gz", sg.shard)]
     eng = ShardedTraversalEngine(sg, [0], links=links, max_branch_length=args.max_len, rows_per_owner=args.rows_per_owner,
-                                 check_every=args.check_every)
+                                 check_every=args.check_every, chain_depth=args.chain_depth)
     mine = [s.tobytes().decode() for s in seeds[:args.sharded_seeds]]
 
     def sync():
@@ -254,7 +254,7 @@ def bench_c3_sharded(args, ca, prefix, st, seeds, rank, local_rank, world, dist)
                                    "owners on demand into a local image (empty at the start of every step), RCCL all-to-all per bulk-synchronous round"
                                    % (args.genome_len / 1e6, args.k, "" if args.no_links else " with child links (replicated on every rank)", world, len(mine), args.max_len),
                        "records": N, "records_per_rank": N // max(1, world), "rounds_per_step": rounds // max(1, args.steps), "ms_per_round": per_round_ms,
-                       "rows_per_owner_and_round": args.rows_per_owner, "image_rows_used": eng.image_rows_used,
+                       "rows_per_owner_and_round": args.rows_per_owner, "row_slots_per_request": args.chain_depth, "image_rows_used": eng.image_rows_used,
                        "kmers_traversed_per_step": traversed // max(1, args.steps), "multi_gpu": "hash-sharded table, rows exchanged, walks stay on the rank of their seed",
                        "load_seconds": round(t_load, 2), "shard_cut_seconds": round(t_shard, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_walk<%d> on the image, one launch per round" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -309,7 +309,7 @@ def bench_c4_sharded(args, ca, g, links, walk_eng, seeds, st, prefix, rank, loca
     t_load = time.time() - t0
     slinks = [CortexLinks(prefix + ".ctp.gz", sg.shard)]
     eng = ShardedTraversalEngine(sg, [0], links=slinks, direction=1, max_branch_length=args.max_len, stopping_rule=DestinationStopper,
-                                 rows_per_owner=args.rows_per_owner, check_every=args.check_every)
+                                 rows_per_owner=args.rows_per_owner, check_every=args.check_every, chain_depth=args.chain_depth)
     for _ in range(args.warmup):
         eng.dfs_batch(sources, sinks)
     sync()
@@ -496,6 +496,7 @@ def main():
     ap.add_argument("--sharded-seeds", type=int, default=8192, help="--sharded: seeds per GPU and step")
     ap.add_argument("--rows-per-owner", type=int, default=8192, help="--sharded: rows one rank may ask of one owner per round")
     ap.add_argument("--check-every", type=int, default=16, help="--sharded: rounds between two looks at the 'anyone still walking' count")
+    ap.add_argument("--chain-depth", type=int, default=16, help="--sharded: row slots per request (the row asked for + rows around it its owner holds too)")
     ap.add_argument("--workload", choices=["c3", "c4", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
     ap.add_argument("--stopper", default="DestinationStopper", help="c4: the stopping rule of the searches (SURVEY 8d also names ExplorationStopper)")

@@ -295,21 +295,39 @@ class ShardedTraversalEngine:
         stream has handle 0, which the C ABI reads as "the library's stream", and nothing would order the kernels with the collectives)"""
         return C.c_void_p(self._tstream.cuda_stream) if self._tstream is not None else None
 
-    def _exchange(self, stream):
-        """requests of this round -> rows in the image: bucket, all-to-all, serve, all-to-all, insert — all on one stream"""
+    def _exchange(self, stream, cap=None):
+        """requests of this round -> rows in the image: bucket, all-to-all, serve, all-to-all, insert — all on one stream.
+        cap: row requests per owner this round (every rank uses the same value; what does not fit is asked for again): the blocks that
+        travel have a fixed size, so a round costs what its capacity costs, whatever is in it"""
         g, d, lib, dist = self.g, self._d, self._lib, self.g._dist
         P = lambda t: C.c_void_p(t.data_ptr())
-        n = g.world * self.rows_per_owner
-        lib.check(d.ldbg_image_bucket(self._img, g.world, C.c_uint32(self.rows_per_owner), P(self._send), stream))
-        dist.all_to_all_single(self._recv.view(-1), self._send.view(-1), group=g._group)
-        lib.check(d.ldbg_image_serve_chain(self._img, g.rank, P(self._recv), C.c_int64(n), C.c_int(self.chain_depth), P(self._rows_out), stream))
-        dist.all_to_all_single(self._rows_in.view(-1), self._rows_out.view(-1), group=g._group)
-        lib.check(d.ldbg_image_insert(self._img, self.engine._h, P(self._rows_in), C.c_int64(n * self.chain_depth), stream))
+        cap = self.rows_per_owner if cap is None else int(cap)
+        n = g.world * cap
+        send, recv = self._send.view(-1)[:n], self._recv.view(-1)[:n]
+        rb = self.chain_depth * self.row_bytes
+        rows_out, rows_in = self._rows_out.view(-1)[:n * rb], self._rows_in.view(-1)[:n * rb]
+        lib.check(d.ldbg_image_bucket(self._img, g.world, C.c_uint32(cap), P(send), stream))
+        dist.all_to_all_single(recv, send, group=g._group)
+        lib.check(d.ldbg_image_serve_chain(self._img, g.rank, P(recv), C.c_int64(n), C.c_int(self.chain_depth), P(rows_out), stream))
+        dist.all_to_all_single(rows_in, rows_out, group=g._group)
+        lib.check(d.ldbg_image_insert(self._img, self.engine._h, P(rows_in), C.c_int64(n * self.chain_depth), stream))
 
     def _all_done(self, local_count):
         t = local_count.clone().reshape(1)
         self.g._dist.all_reduce(t, group=self.g._group)
         return int(t.item()) == 0
+
+    def _round_state(self):
+        """(no rank has a strand left, row requests per owner to provide for in the coming rounds) from the counters of the round that has
+        just run: one small all-reduce (MAX) of (strands in progress, requests filed)"""
+        t = self._stats.clone()
+        self.g._dist.all_reduce(t, op=self.g._dist.ReduceOp.MAX, group=self.g._group)
+        left, nreq = int(t[0].item()), int(t[1].item())
+        want = max(64, -(-3 * nreq // max(1, self.g.world)))       # three times an even spread of the busiest rank's requests
+        cap = 64
+        while cap < want:
+            cap *= 2
+        return left == 0, min(self.rows_per_owner, cap)
 
     def walk_batch(self, seeds):
         """contigs of this rank's seeds (list of str); collective: every rank calls it (possibly with no seeds)"""
@@ -377,13 +395,14 @@ class ShardedTraversalEngine:
         slots = self._resolve(ascii_, stream)
         seed_buf = np.ascontiguousarray(ascii_).reshape(-1)
         lib.check(d.ldbg_engine_sharded_walk_begin(self.engine._h, self._img, seed_buf.ctypes.data_as(C.c_char_p), C.c_int64(n), P(slots), stream))
-        rounds, gap = 0, 1
+        rounds, gap, cap = 0, 1, self.rows_per_owner
         while True:
             for _ in range(gap):
                 lib.check(d.ldbg_engine_sharded_walk_round(self.engine._h, P(self._stats)))
-                self._exchange(stream)
+                self._exchange(stream, cap)
                 rounds += 1
-            if self._all_done(self._stats[0]):
+            done, cap = self._round_state()
+            if done:
                 break
             gap = min(self.check_every, gap * 2)
         self.rounds = rounds
@@ -443,18 +462,19 @@ class ShardedTraversalEngine:
                 lib.check(d.ldbg_image_clear(self._img))
             seed_slots = self._resolve(src_ascii, stream)
             sink_slots = self._resolve(sink_ascii, stream)
-            state = {"rounds": 0, "gap": 1, "since": 0, "error": None}
+            state = {"rounds": 0, "gap": 1, "since": 0, "error": None, "cap": self.rows_per_owner}
 
             def round_done(_user):
                 try:
-                    self._exchange(stream)
+                    self._exchange(stream, state["cap"])
                     state["rounds"] += 1
                     state["since"] += 1
                     if state["since"] < state["gap"]:
                         return 0
                     state["since"] = 0
                     state["gap"] = min(self.check_every, state["gap"] * 2)
-                    return 1 if self._all_done(self._stats[0]) else 0
+                    done, state["cap"] = self._round_state()
+                    return 1 if done else 0
                 except BaseException as ex:        # never let an exception cross the C boundary
                     state["error"] = ex
                     return 1
