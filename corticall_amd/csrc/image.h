@@ -1,6 +1,6 @@
 // Walks and searches over a HASH-SHARDED table: the local image.
 //
-// Every rank owns one shard of the sorted table (graph.cpp::k_owner: a 64-bit mix of the canonical k-mer's words, mod the number of
+// Every rank owns one shard of the sorted table (graph.cpp::k_owner: a 64-bit mix of the canonical k-mer's minimizer, mod the number of
 // ranks) with a GLOBAL neighbour index (shard.cpp: for each of a record's 8 possible neighbours the owner, the record number in
 // the owner's shard and the orientation — a routed findRecord memoised once at load).  A walk lives on the rank that was given its
 // seed; its visited set, link store, path and stopping rule never move.  What moves is ROWS: the rank keeps an IMAGE — a table of
