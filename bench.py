@@ -493,10 +493,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lookups", type=int, default=100000, help="c2: lookups per step (configs[1] says 100k)")
     ap.add_argument("--sharded", action="store_true", help="hash-shard the table over the ranks: c2 routes lookups with all-to-all, c3 walks over local images of the table")
-    ap.add_argument("--sharded-seeds", type=int, default=8192, help="--sharded: seeds per GPU and step")
-    ap.add_argument("--rows-per-owner", type=int, default=8192, help="--sharded: rows one rank may ask of one owner per round")
+    ap.add_argument("--sharded-seeds", type=int, default=50000, help="--sharded: seeds per GPU and step")
+    ap.add_argument("--rows-per-owner", type=int, default=65536, help="--sharded: rows one rank may ask of one owner per round")
     ap.add_argument("--check-every", type=int, default=16, help="--sharded: rounds between two looks at the 'anyone still walking' count")
-    ap.add_argument("--chain-depth", type=int, default=16, help="--sharded: row slots per request (the row asked for + rows around it its owner holds too)")
+    ap.add_argument("--chain-depth", type=int, default=32, help="--sharded: row slots per request (the row asked for + rows around it its owner holds too)")
     ap.add_argument("--workload", choices=["c3", "c4", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
     ap.add_argument("--stopper", default="DestinationStopper", help="c4: the stopping rule of the searches (SURVEY 8d also names ExplorationStopper)")

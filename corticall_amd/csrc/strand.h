@@ -52,6 +52,8 @@ struct WalkArgs {
     unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
     unsigned long long* st_gen;     // diagnostics: [n_strands][2] ticks spent before general steps (prepare + cooperative phases), their number
+    uint32_t yield_iters;           // over an image: loop iterations after which a wavefront ends its launch (0 = never): a bulk-synchronous round lasts as long as its
+                                    // slowest wavefront, and a strand deep in rows that are already there would keep every strand that waits for rows waiting
     unsigned long long* wave_cat;   // diagnostics: [n_workgroups][8] per wavefront: loop iterations and 100 MHz ticks by kind (table regrowth, run steps, lean runs, general part)
 #ifdef LDBG_LEAN_PROFILE
     unsigned long long* st_prof;
