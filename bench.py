@@ -250,8 +250,9 @@ def bench_c3_sharded(args, ca, prefix, st, seeds, rank, local_rank, world, dist)
             "warmup": args.warmup, "ms_per_step": m[0].item() / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic", "library": ca.default_lib().dll.ldbg_version().decode(),
             "config": {"workload": "configs[2] over the HASH-SHARDED table (configs[4]'s path): synthetic %.1f Mb 3-colour k=%d LdBG%s, table split over %d rank(s) by "
-                                   "mix64(canonical k-mer), link-guided ContigStopper walks BOTH/OR from %d seeds per GPU, maxLength %d; rows fetched from their "
-                                   "owners on demand into a local image (empty at the start of every step), RCCL all-to-all per bulk-synchronous round"
+                                   "the mixed minimizer of the canonical k-mer, link-guided ContigStopper walks BOTH/OR from %d seeds per GPU, maxLength %d; rows fetched from their "
+                                   "owners on demand into a local image (empty at the start of every step; an owner sends the rows around the one asked for along with it), "
+                                   "RCCL all-to-all per bulk-synchronous round"
                                    % (args.genome_len / 1e6, args.k, "" if args.no_links else " with child links (replicated on every rank)", world, len(mine), args.max_len),
                        "records": N, "records_per_rank": N // max(1, world), "rounds_per_step": rounds // max(1, args.steps), "ms_per_round": per_round_ms,
                        "rows_per_owner_and_round": args.rows_per_owner, "row_slots_per_request": args.chain_depth, "image_rows_used": eng.image_rows_used,
