@@ -702,7 +702,10 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
             active = true; begun = sv.begun != 0;
         }
     }
+    uint32_t wave_iterations = 0;
     while (wave_ballot((active && !suspended) || (!active && !exhausted)) != 0ull) {
+        if (IMG && a.w.yield_iters != 0u && wave_iterations >= a.w.yield_iters) break;      // (walk.cpp: a round lasts as long as its slowest wavefront)
+        wave_iterations++;
         if (!active && !exhausted) {
             const int64_t fi = (int64_t)atomic_add_u64(a.w.next_strand, 1ull);
             if (fi >= a.w.n_strands) exhausted = true;
@@ -1194,6 +1197,8 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
     a.w.ls = (LsElem*)d_ls_; a.w.ecap = ecap_;
     a.w.strand_c = nullptr; a.w.retry = nullptr; a.w.snap = nullptr;
     a.w.unfinished = d_ctr + 4;
+    a.w.yield_iters = sharded ? 128u : 0u;
+    if (const char* ev = getenv("LDBG_IMG_YIELD")) a.w.yield_iters = sharded ? (uint32_t)std::max(0, atoi(ev)) : 0u;
     // unbranched stretches in one step (dfs_run_step), for the rules that allow it and over a resident table
     if (!sharded && dfs_rule_has_closed_form(view.stopper)) {
         ensure_run_index();

@@ -123,8 +123,10 @@ ldbg_status ldbg_graph_find_dev(const ldbg_graph* g, const uint64_t* d_packed, i
                                 int64_t* d_idx_out, uint32_t* d_cov_out, uint8_t* d_edges_out, void* stream);
 
 /* ------------------------------------------------------------------ hash partitioning over devices
- * owner[i] = mix64(canonical k-mer i) mod world — the rule by which the sorted table is split into per-device
- * shards (each still sorted) and by which a lookup is routed to the shard that can answer it.  The _dev form
+ * owner[i] = mix64(minimizer of canonical k-mer i) mod world — the rule by which the sorted table is split into per-device
+ * shards (each still sorted) and by which a lookup is routed to the shard that can answer it.  The minimizer is the m-mer, m = (k + 2) / 3
+ * (k itself up to k = 8), taken in its own canonical orientation, whose mixed value is smallest: a k-mer and its reverse complement
+ * agree, and a run of consecutive k-mers of a walk shares it — their rows live on one shard and travel together (ldbg_image_serve_chain).  The _dev form
  * works on device buffers (d_canon, n x W canonical words, may be NULL) and is what the exchange step of
  * corticall_amd/distributed.py calls between its all-to-alls; the host form is used when the shards are cut. */
 ldbg_status ldbg_shard_owner_dev(int k, const uint64_t* d_packed, int64_t n, int world, uint64_t* d_canon, int32_t* d_owner, void* stream);
