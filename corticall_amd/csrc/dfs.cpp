@@ -1077,7 +1077,7 @@ DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, c
     if (cfg.connect_all_neighbors) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: connectAllNeighbors is not supported on the device path");
     rt::set_device(graph->device);
     materialize_pending();            // (the path pool is about to be reused: walks of the last batch keep their vertex lists)
-    build_roi_bits();
+    if (!sharded) build_roi_bits();      // (over an image the rules ask the ROI graph itself)
     const int k = graph->hdr.k, W = graph->hdr.W;
     std::vector<uint64_t> words((size_t)n * W);
     seed_valid_.resize((size_t)std::max<int64_t>(1, n));
@@ -1205,14 +1205,13 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         if (runs_) a.w.e.runs = runs_->view;
     }
     if (sharded) {
-        if (rois) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs over a sharded table: stopping rules that consult a ROI graph are not routed yet");
         a.w.img_on = 1;
         a.w.img = sharded->img->view((uint64_t*)view.links.rec_of);
         a.w.seed_slot = sharded->d_seed_slot + first;
     }
     a.env.rois = rois ? rois->view : GraphView{};
     if (!rois) a.env.rois.N = -1;
-    a.env.roi_bits = (const uint32_t*)d_roi_bits_;
+    a.env.roi_bits = sharded ? nullptr : (const uint32_t*)d_roi_bits_;      // (over an image the rules ask the ROI graph itself: stoppers.h roi_bit)
     a.env.sink_keys = d_sink_keys; a.env.sink_words = d_sink_words;
     a.sink_off = d_sink_off;
     a.max_depth = dfs_max_depth;

@@ -79,11 +79,19 @@ struct StopEval {
             no_in |= in == 0; no_out |= out == 0; busy |= in + out > 4;
         }
     }
+    // is the record of the current vertex a record of the ROI graph?  One bit per record of a resident table (k_roi_bits); over the
+    // image of a sharded table (roi_bits == nullptr: rows come and go) the ROI graph — small, held by every rank — is asked directly
+    LDBG_HOSTDEV bool roi_bit() {
+        if (env.roi_bits) return (env.roi_bits[cv.idx >> 5] >> (cv.idx & 31)) & 1u;
+        GraphView exact = env.rois;
+        exact.java_tiny = 0;           // set membership, not findRecord: no Q1 here
+        return graph_find_canonical<W>(exact, graph_key<W>(e.g, cv.idx)) >= 0;
+    }
     // rois.findRecord(<cursor k-mer>) != null, with the ROI graph's own Q1 behaviour
     LDBG_HOSTDEV bool rois_find_cur() {
         if (!need_rois()) return false;
         if (env.rois.java_tiny) return false;
-        if (cv.idx >= 0) return (env.roi_bits[cv.idx >> 5] >> (cv.idx & 31)) & 1u;
+        if (cv.idx >= 0) return roi_bit();
         bool fc;
         Kmer<W> c = kmer_canonical<W>(nullk, e.g.k, &fc);
         return graph_find_canonical<W>(env.rois, c) >= 0;
@@ -92,7 +100,7 @@ struct StopEval {
     LDBG_HOSTDEV bool roi_set_contains() {
         if (env.rois.N < 0) { status = ST_STOPPER_CONFIG; return false; }
         if (cv.idx < 0) return false;
-        return (env.roi_bits[cv.idx >> 5] >> (cv.idx & 31)) & 1u;
+        return roi_bit();
     }
     LDBG_HOSTDEV bool at_sink() {                                   // sinks.contains(cv.getKmerAsString())
         for (int64_t i = sink_lo; i < sink_hi; i++) {
@@ -158,7 +166,7 @@ struct StopEval {
             case LDBG_STOP_NAHR: {
                 if (S.flags & 1u) S.a++;
                 if (!need_rois() || !need_rec()) return false;
-                if (!env.rois.java_tiny && ((env.roi_bits[cv.idx >> 5] >> (cv.idx & 31)) & 1u)) { S.flags |= 1u; S.a++; }
+                if (!env.rois.java_tiny && roi_bit()) { S.flags |= 1u; S.a++; }
                 return (S.flags & 1u) && (S.a >= 1000 || s.depth >= 5 || s.adj == 0 || s.children_traversed);
             }
             case LDBG_STOP_NOVEL_KMER_AGGREGATION: {

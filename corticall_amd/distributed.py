@@ -250,7 +250,7 @@ class ShardedTraversalEngine:
     links: CortexLinks objects opened on `sgraph.shard` (each rank opens the link file against its own shard)."""
 
     def __init__(self, sgraph, traversal_colors, links=(), recruitment_colors=(), joining_colors=(), direction=0, op=0, max_branch_length=75000,
-                 stopping_rule=None, image_rows=None, rows_per_owner=4096, check_every=8, keep_image=False, chain_depth=16):
+                 stopping_rule=None, image_rows=None, rows_per_owner=4096, check_every=8, keep_image=False, chain_depth=16, rois=None):
         from .traversal import ContigStopper, TraversalEngineFactory
         self.g = sgraph
         if not sgraph.has_neighbour_index:
@@ -274,6 +274,8 @@ class ShardedTraversalEngine:
             f.joiningColors(*joining_colors)
         if links:
             f.links(*links)
+        if rois is not None:          # the ROI graph of the stopping rules: a whole (small) graph, opened by every rank on its own device
+            f.rois(rois)
         self.engine = f.make()
         self.rows_per_owner = int(rows_per_owner)
         self.chain_depth = max(1, int(chain_depth))      # row slots per request: the row asked for + rows around it its owner holds too

@@ -231,7 +231,7 @@ def test_sharded_link_walks_three_ranks(orc, tmp_path):
     _sharded_walk_case(orc, tmp_path, 31, with_links=True, world=3)
 
 
-def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs, expected):
+def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs, expected, roi_path=None, use=None):
     dist = _init(rank, world, port)
     try:
         import corticall_amd as ca
@@ -241,10 +241,16 @@ def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs
         lib = hostsim.load(rebuild=False)
         sg = ShardedCortexGraph(path, lib=lib, chunk_records=700)
         links = CortexLinks(link_path, sg.shard, lib=lib) if link_path else None
-        first, cnt = partition(len(sources), rank, world)
+        rois = ca.CortexGraph(roi_path, lib=lib) if roi_path else None
+        all_sources, all_sinks = sources, sinks
         for ci, (stopper, trav, direction, max_len, with_links) in enumerate(cfgs):
+            idx = use[ci] if use else list(range(len(all_sources)))
+            sources, sinks = [all_sources[i] for i in idx], [all_sinks[i] for i in idx]
+            first, cnt = partition(len(sources), rank, world)
             e = ShardedTraversalEngine(sg, trav, links=[links] if (with_links and links) else (), direction=direction, max_branch_length=max_len,
-                                       stopping_rule=stopper, rows_per_owner=64 if ci % 2 else 2048, check_every=4)
+                                       stopping_rule=stopper, rows_per_owner=64 if ci % 2 else 2048, check_every=4,
+                                       rois=rois if stopper.startswith(("Novel", "Nahr", "BubbleOpening")) else None,
+                                       joining_colors=[1, 2] if stopper.startswith(("Novel", "Nahr", "BubbleOpening")) else ())
             got = e.dfs_batch(sources[first:first + cnt], sinks[first:first + cnt])
             for j, gi in enumerate(got):
                 exp = expected[ci][first + j]
@@ -290,13 +296,29 @@ def test_sharded_dfs_two_ranks(orc, tmp_path, k):
     sources[3] = orc.revcomp(sources[3])
     sinks[5] = [sinks[5][0], "N" * k, pc.rand_seq(rng, k)]
     cfgs = [("DestinationStopper", [0], 1, 400, True), ("DestinationStopper", [0], 0, 400, False), ("ExplorationStopper", [0], 0, 150, True),
-            ("ContigStopper", [0, 1], 0, 300, True), ("DestinationStopper", [1], 2, 120, True)]
-    expected = []
+            ("ContigStopper", [0, 1], 0, 300, True), ("DestinationStopper", [1], 2, 120, True),
+            # rules that consult the ROI graph (the child's novel k-mers), which every rank holds whole
+            ("NovelContinuationStopper", [0], 0, 200, True), ("NovelKmerLimitedContigStopper", [0], 0, 200, False), ("NahrStopper", [0], 0, 200, True)]
+    parents = set()
+    for h in (base, dad):
+        parents |= {orc.canonical(h[i:i + k]) for i in range(len(h) - k + 1)}
+    novel = [kid[i:i + k] for i in range(len(kid) - k + 1) if orc.canonical(kid[i:i + k]) not in parents]
+    roi_path = str(tmp_path / "sd.rois.ctx")
+    orc.build_graph(roi_path, [("kid", novel or [kid[:k]])], k)
+    oroi = orc.Graph(roi_path, tuned=True)
+    sources = sources + novel[:6]
+    sinks = sinks + [[] for _ in novel[:6]]
+    expected, use = [], []
+    in_graph = [i for i in range(len(sources)) if og.find(sources[i])[0] >= 0]
     for stopper, trav, direction, max_len, wl in cfgs:
-        oe = orc.Engine(og, trav, links=[ol] if wl else [], direction=direction, max_length=max_len, stopper=stopper)
+        with_roi = stopper.startswith(("Novel", "Nahr", "BubbleOpening"))
+        oe = orc.Engine(og, trav, links=[ol] if wl else [], direction=direction, max_length=max_len, stopper=stopper,
+                        rois=oroi if with_roi else None, joining_colors=[1, 2] if with_roi else ())
         it0 = oe.kmers_traversed()
         per = []
-        for s_, sk in zip(sources, sinks):
+        # (the ROI rules dereference the record of the vertex they stand on: NullPointerException for a source that is not in the graph)
+        use.append(in_graph if with_roi else list(range(len(sources))))
+        for s_, sk in ((sources[i], sinks[i]) for i in use[-1]):
             r = oe.dfs(s_, sk)
             if r.is_null:
                 per.append(None)
@@ -305,4 +327,4 @@ def test_sharded_dfs_two_ranks(orc, tmp_path, k):
             r.free()
         per.append(oe.kmers_traversed() - it0)
         expected.append(per)
-    _spawn(_sharded_dfs_worker, (path, link_path, sources, sinks, cfgs, expected))
+    _spawn(_sharded_dfs_worker, (path, link_path, sources, sinks, cfgs, expected, roi_path, use))
