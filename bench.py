@@ -441,10 +441,10 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {
-                "workload": "configs[3]: same %.1f Mb 3-colour k=%d LdBG with child links; dfs with " + args.stopper + ", FORWARD, from %d seeds per GPU "
-                            "to the child k-mer 200-2000 bp downstream on the seed's contig; timed: the C-ABI call (kernel, log expansion and download, "
-                            "graph assembly on the host: results of one branch per direction are kept as packed vertex entries, the others "
-                            "as vertex and edge lists)" % (args.genome_len / 1e6, k, n, ),
+                "workload": ("configs[3]: same %.1f Mb 3-colour k=%d LdBG with child links; dfs with %s, FORWARD, from %d seeds per GPU "
+                             "to the child k-mer 200-2000 bp downstream on the seed's contig; timed: the C-ABI call (kernel, log expansion and download, "
+                             "graph assembly on the host: results of one branch per direction are kept as packed vertex entries, the others "
+                             "as vertex and edge lists)") % (args.genome_len / 1e6, k, args.stopper, n),
                 "records": N, "seeds_per_gpu": n, "kmers_traversed_per_step": traversed // args.steps, "sinks_reached": found,
                 "multi_gpu": "replicated graph, seeds partitioned, no data-path collective" if world > 1 else "single GPU",
                 "load_seconds": round(t_load, 2),
