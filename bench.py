@@ -500,7 +500,7 @@ def main():
     ap.add_argument("--chain-depth", type=int, default=32, help="--sharded: row slots per request (the row asked for + rows around it its owner holds too)")
     ap.add_argument("--workload", choices=["c3", "c4", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
-    ap.add_argument("--stopper", default="DestinationStopper", help="c4: the stopping rule of the searches (SURVEY 8d also names ExplorationStopper)")
+    ap.add_argument("--stopper", default="DestinationStopper", help="c4: the stopping rule of the searches (a rule that never fails, like ExplorationStopper, returns every branch it explored: use a small --max-len with it)")
     ap.add_argument("--use-seeds", type=int, default=0, help="experiment: walk only the first N seeds")
     ap.add_argument("--no-links", action="store_true", help="experiment: walk without the link annotations")
     ap.add_argument("--no-strict", action="store_true", help="experiment: CanonicalKmer.isFlipped by comparison (not Java-exact, Q6)")
