@@ -177,7 +177,7 @@ def _dfs_collection(engine, sources, sinks):
     for dg in batch:
         if dg is None:
             continue
-        g = Pseudograph.fromDfsGraph(dg)
+        g = dg if isinstance(dg, Pseudograph) else Pseudograph.fromDfsGraph(dg)
         if out is None:
             out = g
         else:
@@ -185,7 +185,7 @@ def _dfs_collection(engine, sources, sinks):
     return out
 
 
-def fillGaps(g, graph, links, colors, relabel=True):
+def fillGaps(g, graph, links, colors, relabel=True, engine_factory=None):
     """:235-315 — per colour: edges the colour has between joined vertices; vertices with an edge in the colour that leaves the
     graph are sources (outgoing) / sinks (incoming); DestinationStopper searches of at most 1000 vertices from every source towards
     the sinks (forward; if that returns nothing, backwards from the sinks) are merged in.
@@ -195,7 +195,10 @@ def fillGaps(g, graph, links, colors, relabel=True):
     so a filled stretch is joined to g at both ends.  relabel=False is the literal reading of the sources: Graphs.addGraph joins
     vertices that are equal, and CortexVertex.equals includes `index` — the source a search starts from comes back with index 0 while
     the same k-mer in g (a walk: index -1 / +1 either side of its seed) does not, so the stretch hangs on g at its far end only and the
-    test's strings do not come out."""
+    test's strings do not come out.
+
+    engine_factory(colour, direction) -> an object with dfs_batch(sources, sinks_per_source) (DfsGraph / Pseudograph / None per source) and
+    close(): where the searches run.  Default: the device engine over `graph`; the tests also run this function over the CPU oracle."""
     filled = Pseudograph()
     filled.addGraph(g)
     colors = list(colors)
@@ -222,6 +225,8 @@ def fillGaps(g, graph, links, colors, relabel=True):
         sources, sinks = java_string_set_order(sources), java_string_set_order(sinks)
 
         def engine(direction):
+            if engine_factory is not None:
+                return engine_factory(c, direction)
             f = (TraversalEngineFactory(lib=graph._lib).traversalColors(c).traversalDirection(direction).combinationOperator(OR)
                  .stoppingRule(DestinationStopper).maxBranchLength(1000).graph(graph))
             if links:

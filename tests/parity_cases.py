@@ -808,8 +808,9 @@ def test_ref_fill_gaps(orc, lib, tmp):                            # TraversalUti
               [("TGAGATT", "kid", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"), ("TGATATT", "mom", "TGGCTAGGTCATTATGATATTAAAATGCTAGCGC"),
                ("TGAGATT", "mom", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC")])]
     for ci, (haps, expected) in enumerate(cases):
-        # (a java.util.HashMap of the two sample names iterates "mom" before "kid": TempGraphAssembler gives mom colour 0)
-        cs = Case(orc, tmp, lib, [("mom", haps["mom"]), ("kid", haps["kid"])], 7, link_samples=["mom", "kid"], name="v13_%d" % ci)
+        # (a java.util.HashMap of the two sample names iterates "kid" before "mom": TempGraphAssembler gives kid colour 0)
+        order = orc.java_string_hashmap_order(["mom", "kid"])
+        cs = Case(orc, tmp, lib, [(s_, haps[s_]) for s_ in order], 7, link_samples=["mom", "kid"], name="v13_%d" % ci)
         colors = list(range(cs.g.getNumColors()))
         kid = cs.g.getColorForSampleName("kid")
         e = (TraversalEngineFactory(lib=lib).traversalColors(kid).traversalDirection(BOTH).combinationOperator(OR).stoppingRule("ContigStopper")
@@ -1285,6 +1286,51 @@ def case_sort_rewrites_header(orc, lib, tmp):
     g = CortexGraph(out, lib=lib)
     assert g.getSampleName(0) == "mom" and g.getNumRecords() == len(recs)
     g.close()
+
+
+def test_ref_collection(orc, lib, tmp):                          # T/utils/io/graph/collection/CortexCollectionTest.java:16-140 (all six tests)
+    from corticall_amd import CortexCollection
+    h1 = [("fred", ["ACCGTATGTA"]), ("wilma", ["ACCGCATGTA"]), ("barney", ["ACCGTATATA"])]
+    h2 = [("pebbles", ["AACGTATGTA"]), ("bam-bam", ["ACTGCATGTA"])]
+    p1, p2 = str(tmp / "cc1.ctx"), str(tmp / "cc2.ctx")
+    orc.build_graph(p1, h1, 3)
+    orc.build_graph(p2, h2, 3)
+    g0, g1 = CortexGraph(p1, lib=lib), CortexGraph(p2, lib=lib)
+    cc = CortexCollection(g0, g1)
+    assert g0.getNumRecords() > 2 and g1.getNumRecords() > 2
+    for c0 in g0:                                                   # testDynamicGraphMerging :38-67
+        c1 = g1.findRecord(c0.getKmerAsString())
+        cm = cc.findRecord(c0.getKmerAsString())
+        assert cm.getKmerAsString() == c0.getKmerAsString()
+        for c in range(3):
+            assert cm.getCoverage(c) == c0.getCoverage(c) and cm.getEdgesAsString(c) == c0.getEdgesAsString(c)
+        for c in range(2):
+            if c1 is None:
+                assert cm.getCoverage(3 + c) == 0 and cm.getEdgesAsString(3 + c) == "........"
+            else:
+                assert cm.getCoverage(3 + c) == c1.getCoverage(c) and cm.getEdgesAsString(3 + c) == c1.getEdgesAsString(c)
+    single = CortexCollection(p1, lib=lib)                          # testSingleFileCollection :70-84
+    for c0 in g0:
+        cm = single.findRecord(c0.getKmerAsString())
+        assert cm.getKmerAsString() == c0.getKmerAsString()
+        for c in range(2):
+            assert cm.getCoverage(c) == c0.getCoverage(c) and cm.getEdgesAsString(c) == c0.getEdgesAsString(c)
+    single.close()
+    kmers = sorted({r.getKmerAsString() for r in g0} | {r.getKmerAsString() for r in g1})     # testIteration :87-116 (TreeSet order)
+    seen = 0
+    for cr, esk in zip(cc, kmers):
+        assert cr.getKmerAsString() == esk
+        c0, c1 = g0.findRecord(esk), g1.findRecord(esk)
+        if c0 is not None:
+            assert cr.getCoverage(0) == c0.getCoverage(0) and cr.getEdgesAsString(0) == c0.getEdgesAsString(0)
+        if c1 is not None:
+            assert cr.getCoverage(3) == c1.getCoverage(0) and cr.getEdgesAsString(3) == c1.getEdgesAsString(0)
+        seen += 1
+    assert seen == len(kmers) == sum(1 for _ in cc)
+    assert cc.getNumColors() == g0.getNumColors() + g1.getNumColors() == 5                   # testNumColors, testColorNames, testColors
+    assert [cc.getSampleName(c) for c in range(5)] == [g0.getSampleName(0), g0.getSampleName(1), g0.getSampleName(2), g1.getSampleName(0), g1.getSampleName(1)]
+    assert [cc.getColor(c) for c in range(5)] == [g0.getColor(0), g0.getColor(1), g0.getColor(2), g1.getColor(0), g1.getColor(1)]
+    cc.close()
 
 
 def case_collection(orc, lib, tmp):

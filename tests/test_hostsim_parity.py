@@ -64,6 +64,9 @@ def test_join(orc, lib, tmp_path): pc.case_join(orc, lib, tmp_path)
 def test_collection(orc, lib, tmp_path): pc.case_collection(orc, lib, tmp_path)
 
 
+def test_ref_collection(orc, lib, tmp_path): pc.test_ref_collection(orc, lib, tmp_path)
+
+
 def test_big_link_stores(orc, lib, tmp_path): pc.case_big_link_stores(orc, lib, tmp_path)
 
 

@@ -233,6 +233,80 @@ def test_v13_link_guided_walk(orc, tmp_path, mom):
     assert e.walk("TGAGATT")[0] == kid[0]
 
 
+# ---- V13 (gap-filling part): T/utils/traversal/TraversalUtilsTest.java:48-54, 85-97 — toGraph + fillGaps + toWalk over the ORACLE's searches.
+# The container logic (corticall_amd/traversal_utils.py: pure Python, no device) is the same the product uses; here every
+# DestinationStopper search runs in the CPU oracle, so the five strings the reference asserts are pinned without a GPU.
+class _OracleSearches:
+    """what fillGaps needs from an engine: dfs_batch(sources, sinks per source) -> Pseudograph / None per source; close()"""
+
+    def __init__(self, orc, og, links, color, direction):
+        from corticall_amd.graph import CortexRecord
+        self.orc, self.og, self.CortexRecord = orc, og, CortexRecord
+        self.e = orc.Engine(og, [color], links=links, direction=direction, stopper="DestinationStopper", max_length=1000)
+
+    def graph_of(self, r):
+        from corticall_amd.traversal import CortexVertex
+        from corticall_amd.traversal_utils import CortexEdge, Pseudograph
+        if r.is_null:
+            return None
+        g, vs = Pseudograph(), []
+        for km, rec, ci, ix in r.vertices():
+            cr = None
+            if rec >= 0:
+                w, cov, ed = self.og.get_record(rec)
+                cr = self.CortexRecord(w, cov, ed, self.og.k, rec)
+            vs.append(CortexVertex(km, cr, ci, ix))
+            g.addVertex(vs[-1])
+        for s_, t_, c in r.edges():
+            g.addEdge(vs[s_], vs[t_], CortexEdge(vs[s_], vs[t_], c, 1.0))
+        return g
+
+    def dfs_batch(self, sources, sinks):
+        out = []
+        for s_, sk in zip(sources, sinks):
+            r = self.e.dfs(s_, sk)
+            out.append(self.graph_of(r))
+            r.free()
+        return out
+
+    def close(self):
+        self.e.close()
+
+
+@pytest.mark.parametrize("mom,expected", [
+    (["TGGCTAGGTCATTATGATATTAAAATGCTAGCGC"],
+     [("TGGCTAG", "kid", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"), ("TGGCTAG", "mom", "TGGCTAGGTCATTATGATATTAAAATGCTAGCGC")]),
+    (["TGGCTAGGTCATTATGATATTAAAATGCTAGCGC", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"],
+     [("TGAGATT", "kid", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"), ("TGATATT", "mom", "TGGCTAGGTCATTATGATATTAAAATGCTAGCGC"),
+      ("TGAGATT", "mom", "TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC")])])
+def test_v13_fill_gaps(orc, tmp_path, mom, expected):
+    from corticall_amd import traversal_utils as tu
+    kid = ["TGGCTAGGTCATTATGAGATTAAAATGCTAGCGC"]
+    order = orc.java_string_hashmap_order(["mom", "kid"])
+    haps = {"mom": mom, "kid": kid}
+    g = _graph(orc, tmp_path, [(s, haps[s]) for s in order], 7)
+    links = {}
+    for s in ("mom", "kid"):
+        p = str(tmp_path / (s + ".ctp.gz"))
+        orc.build_links(g, p, s, haps[s])
+        links[s] = orc.Links(p)
+    kc, mc = g.color_for_sample_name("kid"), g.color_for_sample_name("mom")
+    # e.walk("TGAGATT") = toWalk(dfs(seed)) :108-110
+    walker = orc.Engine(g, [kc], links=[links["kid"]], direction=orc.BOTH, stopper="ContigStopper")
+    searches = _OracleSearches(orc, g, [], kc, orc.BOTH)
+    r = walker.dfs("TGAGATT")
+    w = tu.toWalk(searches.graph_of(r), "TGAGATT", kc)
+    r.free()
+    searches.close()
+    assert tu.toContig(w) == kid[0]
+    colors = list(range(g.C))
+    gapped = tu.toGraph(w, colors)
+    factory = lambda c, direction: _OracleSearches(orc, g, [links["mom"], links["kid"]], c, direction)
+    filled = tu.fillGaps(gapped, None, None, colors, engine_factory=factory)
+    for seed, sample, hap in expected:
+        assert tu.toContig(tu.toWalk(filled, seed, g.color_for_sample_name(sample))) == hap, (seed, sample)
+
+
 # ---- V14: T/utils/sequence/SequenceUtilsTest.java:19-73
 def test_v14_sequence_utils(orc):
     for a, b in zip("ACGTN.acgt", "TGCAN.tgca"):
