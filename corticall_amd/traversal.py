@@ -271,9 +271,12 @@ class TraversalEngineFactory:
 
     def strictJavaFlip(self, b): self._strict = bool(b); return self
 
-    def make(self):
+    def make(self):       # TraversalEngineFactory.java:54-88: the checks in the reference's order
+        if len(self._trav) == 0:
+            raise _native.CortexJDKException("Traversal color(s) must be specified.")
         if self._graph is None:
-            raise _native.CortexJDKException("Must provide graph to traverse.")
+            # (the colour checks dereference getGraph() before the "Must provide graph to traverse." test at the end is reached)
+            raise _native.JavaNullPointerException("TraversalEngineFactory.make: no graph (the reference dereferences it while checking the colours)")
         return TraversalEngine(self)
 
 
@@ -300,7 +303,7 @@ class TraversalEngine:
                 arr[i] = c
             setattr(cfg, "n_" + name, len(vals))
         cfg.direction, cfg.combination_operator = f._dir, f._op
-        cfg.stopping_rule = STOPPING_RULES.index(f._stopper) if isinstance(f._stopper, str) else int(f._stopper)
+        cfg.stopping_rule = -1 if f._stopper is None else (STOPPING_RULES.index(f._stopper) if isinstance(f._stopper, str) else int(f._stopper))
         cfg.max_branch_length = f._maxlen
         cfg.connect_all_neighbors = 1 if f._connect else 0
         cfg.strict_java_flip = 1 if f._strict else 0

@@ -736,6 +736,30 @@ def case_dfs_run_steps(orc, lib, tmp, seed):
         compare_dfs(cs, seeds[:25], sinks=sinks[:25], trav=[0], stopper=stopper, links=["a"], max_len=rng.choice([333, 2500, 20000]))
 
 
+def case_factory_validation(orc, lib, tmp):
+    """TraversalEngineFactory.make() :54-88 — the configuration errors and their messages"""
+    rng = random.Random(12)
+    cs = Case(orc, tmp, lib, [("a", [rand_seq(rng, 80)]), ("b", [rand_seq(rng, 80)])], 11, name="cfg")
+    F = lambda: TraversalEngineFactory(lib=lib).graph(cs.g)
+
+    def message(f):
+        with pytest.raises(ca.CortexJDKException) as ex:
+            f.make()
+        return str(ex.value)
+    assert "Traversal color(s) must be specified." in message(F())
+    assert "Traversal colors must be between 0 and 2 (provided 2)" in message(F().traversalColors(2))
+    assert "Joining colors must be between 0 and 2 (provided 5)" in message(F().traversalColors(0).joiningColors(5))
+    assert "Joining colors must be between 0 and 2 (provided -1)" in message(F().traversalColors(0).joiningColors(-1))
+    assert "Recruitment colors must be between 0 and 2 (provided 2)" in message(F().traversalColors(0).recruitmentColors(2))
+    assert "Secondary colors must be between 0 and 2 (provided 7)" in message(F().traversalColors(1).secondaryColors(7))
+    assert "Must provide stopping rule for graph traversal" in message(F().traversalColors(0).stoppingRule(None))
+    with pytest.raises(ca.JavaNullPointerException):
+        TraversalEngineFactory(lib=lib).traversalColors(0).make()
+    assert "Traversal color(s) must be specified." in message(TraversalEngineFactory(lib=lib))
+    e = F().traversalColors(0, 1).joiningColors(1).recruitmentColors(1).make()      # a valid one
+    e.close()
+
+
 def case_dfs_packed_results(orc, lib, tmp):
     """results that are one branch per direction stay packed until their k-mers are asked for: sizes and the vertex / edge lists read
     from the packed form (ldbg_dfs_result_get without k-mer words) are those of the unpacked graphs"""

@@ -92,6 +92,9 @@ def test_ref_dfs_with_sinks(orc, lib, tmp_path): pc.test_ref_dfs_with_sinks(orc,
 def test_dfs_packed_results(orc, lib, tmp_path): pc.case_dfs_packed_results(orc, lib, tmp_path)
 
 
+def test_factory_validation(orc, lib, tmp_path): pc.case_factory_validation(orc, lib, tmp_path)
+
+
 def test_ref_fill_gaps(orc, lib, tmp_path): pc.test_ref_fill_gaps(orc, lib, tmp_path)
 
 
