@@ -198,7 +198,7 @@ def fillGaps(g, graph, links, colors, relabel=True, engine_factory=None):
     test's strings do not come out.
 
     engine_factory(colour, direction) -> an object with dfs_batch(sources, sinks_per_source) (DfsGraph / Pseudograph / None per source) and
-    close(): where the searches run.  Default: the device engine over `graph`; the tests also run this function over the CPU oracle."""
+    close(): where the searches run.  Default: the device engine over `graph` (the golden tests plug in their own checker)."""
     filled = Pseudograph()
     filled.addGraph(g)
     colors = list(colors)
