@@ -186,6 +186,65 @@ def test_sharded_walks_one_rank_rccl(orc, lib, tmp_path, k, with_links):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("k", [21, 32])
+def test_sharded_dfs_one_rank_rccl(orc, lib, tmp_path, k):
+    """dfs with stopping rules over a sharded table's local image on the device, RCCL collectives (one rank; two ranks on gloo in
+    tests/test_distributed.py): DestinationStopper towards a sink, ExplorationStopper, and rules that consult a ROI graph"""
+    import os
+    import random
+    import torch.distributed as dist
+    from corticall_amd import CortexGraph, CortexLinks
+    from corticall_amd.distributed import ShardedCortexGraph, ShardedTraversalEngine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29521")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        rng = random.Random(300 + k)
+        base = pc.genome_with_repeats(rng, 900, n_rep=5, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+        kid = pc.mutate(rng, base, snv=0.01, indel=0.003)
+        dad = pc.mutate(rng, base, snv=0.02, indel=0.003)
+        path = str(tmp_path / "sd.ctx")
+        orc.build_graph(path, [("kid", [kid]), ("mom", [base]), ("dad", [dad])], k)
+        og = orc.Graph(path, tuned=True)
+        rl = max(3 * k, 60)
+        link_path = str(tmp_path / "sd.kid.ctp.gz")
+        orc.build_links(og, link_path, "kid", [kid[i:i + rl] for i in range(0, max(1, len(kid) - rl + 1), max(1, rl // 4))] + [kid[-rl:]])
+        ol = orc.Links(link_path)
+        parents = set()
+        for h in (base, dad):
+            parents |= {orc.canonical(h[i:i + k]) for i in range(len(h) - k + 1)}
+        novel = [kid[i:i + k] for i in range(len(kid) - k + 1) if orc.canonical(kid[i:i + k]) not in parents]
+        roi_path = str(tmp_path / "sd.rois.ctx")
+        orc.build_graph(roi_path, [("kid", novel or [kid[:k]])], k)
+        oroi, rois = orc.Graph(roi_path, tuned=True), CortexGraph(roi_path, lib=lib)
+        pos = rng.sample(range(0, len(kid) - k - 200), 30)
+        sources = [kid[p:p + k] for p in pos] + novel[:6]
+        sinks = [[kid[p + d:p + d + k]] for p, d in ((p, rng.randint(20, 180)) for p in pos)] + [[] for _ in novel[:6]]
+        sg = ShardedCortexGraph(path, lib=lib)
+        links = CortexLinks(link_path, sg.shard, lib=lib)
+        for stopper, trav, direction, max_len, wl in (("DestinationStopper", [0], 1, 400, True), ("ExplorationStopper", [0], 0, 150, True),
+                                                     ("NovelContinuationStopper", [0], 0, 200, True), ("NahrStopper", [0], 0, 200, False)):
+            with_roi = stopper.startswith(("Novel", "Nahr"))
+            oe = orc.Engine(og, trav, links=[ol] if wl else [], direction=direction, max_length=max_len, stopper=stopper,
+                            rois=oroi if with_roi else None, joining_colors=[1, 2] if with_roi else ())
+            it0 = oe.kmers_traversed()
+            e = ShardedTraversalEngine(sg, trav, links=[links] if wl else (), direction=direction, max_branch_length=max_len, stopping_rule=stopper,
+                                       rows_per_owner=256, check_every=4, rois=rois if with_roi else None, joining_colors=[1, 2] if with_roi else ())
+            got = e.dfs_batch(sources, sinks)
+            for s_, sk, gi in zip(sources, sinks, got):
+                r = oe.dfs(s_, sk)
+                assert (gi is None) == r.is_null, (stopper, s_)
+                if gi is not None:
+                    assert [(km, rec >= 0, ci, ix) for km, rec, ci, ix in gi.vertex_tuples()] == [(km, rec >= 0, ci, ix) for km, rec, ci, ix in r.vertices()]
+                    assert gi.edge_tuples() == r.edges() and gi.walk_contig(s_, trav[0]) == r.walk(s_, trav[0])
+                r.free()
+            assert e.dfs_kmers_traversed == oe.kmers_traversed() - it0 and e.rounds > 0
+            e.close()
+        sg.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_dfs_step_limit(orc, lib, tmp_path, monkeypatch): pc.case_dfs_step_limit(orc, lib, tmp_path, monkeypatch)
 
 
