@@ -117,6 +117,30 @@ LDBG_KERNEL void k_img_insert(ImageView im, LinksView links, int k, uint32_t lin
         im.hvals[h] = (uint32_t)slot + 1u;                               // published last: a reader that sees the slot sees the row
     }
 }
+// After the rows of a round are in: every arrival links itself to the neighbours that are in the image by now (rows of the same round
+// were not published yet when k_img_insert looked) and its neighbours' entries to itself, so that a strand finds a chain of rows that
+// came together fully linked and takes its lean steps through it without stopping at every hop to patch an entry (image.h: rows_ready)
+LDBG_KERNEL void k_img_link(ImageView im, const uint8_t* rows, int rowb, int64_t n) {
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        const uint64_t key = ((const uint64_t*)(rows + (size_t)i * rowb))[0];
+        if (key == 0ull) continue;
+        const int64_t slot = img_lookup(im, key);
+        if (slot < 0) continue;
+        uint32_t* nb = (uint32_t*)(im.probe + (size_t)slot * (size_t)im.stride + im.nbr_off);
+        for (int j = 0; j < 8; j++) {
+            const uint64_t g = im.nbrg[(size_t)slot * 8 + j];
+            if (gid_key(g) == 0ull) continue;
+            const int64_t s = img_lookup(im, gid_key(g));
+            if (s < 0) continue;
+            nb[j] = (uint32_t)(s + 1) | ((g >> 63) ? 0x80000000u : 0u);
+            uint32_t* nbs = (uint32_t*)(im.probe + (size_t)s * (size_t)im.stride + im.nbr_off);
+            for (int q = 0; q < 8; q++) {
+                const uint64_t back = im.nbrg[(size_t)s * 8 + q];
+                if (gid_key(back) == key) nbs[q] = (uint32_t)(slot + 1) | ((back >> 63) ? 0x80000000u : 0u);
+            }
+        }
+    }
+}
 LDBG_KERNEL void k_img_lookup(ImageView im, const unsigned long long* keys, int64_t n, int32_t* slots) {
     for (int64_t i = global_tid(); i < n; i += global_nthreads())
         slots[i] = keys[i] ? (int32_t)img_lookup(im, gid_key(keys[i])) : -1;
@@ -226,6 +250,7 @@ void ShardImage::insert(const Engine* e, const uint8_t* d_rows, int64_t n, rt::s
         case 3: LDBG_LAUNCH(k_img_insert<3>, grid_of(n), 256, s, im, lv, k, mask, d_rows, rb, n, ovf); break;
         default: LDBG_LAUNCH(k_img_insert<4>, grid_of(n), 256, s, im, lv, k, mask, d_rows, rb, n, ovf); break;
     }
+    LDBG_LAUNCH(k_img_link, grid_of(n), 256, s, im, d_rows, rb, n);
 }
 void ShardImage::lookup(const unsigned long long* d_keys, int64_t n, int32_t* d_slots, rt::stream_t s) const {
     if (n <= 0) return;
