@@ -195,10 +195,12 @@ ShardImage::ShardImage(const Graph& shard, int64_t cap, int64_t global_records) 
     d_ctr_ = rt::dmalloc(64);
     req_cap_ = (uint32_t)std::min<int64_t>(std::max<int64_t>(1024, cap), 1 << 22);
     d_req_ = rt::dmalloc((size_t)req_cap_ * 8);
+    d_req_seen_ = rt::dmalloc((size_t)LDBG_REQ_SEEN * 8);
+    rt::dmemset(d_req_seen_, 0, (size_t)LDBG_REQ_SEEN * 8, graph_->stream);
     d_bcount_ = rt::dmalloc(256 * 8);
     clear();
 }
-ShardImage::~ShardImage() { rt::dfree(d_nbrg_); rt::dfree(d_gkey_); rt::dfree(d_hkeys_); rt::dfree(d_hvals_); rt::dfree(d_ctr_); rt::dfree(d_req_); rt::dfree(d_bcount_); rt::dfree(d_rec_of_own_); rt::dfree(d_plan_); }
+ShardImage::~ShardImage() { rt::dfree(d_nbrg_); rt::dfree(d_gkey_); rt::dfree(d_hkeys_); rt::dfree(d_hvals_); rt::dfree(d_ctr_); rt::dfree(d_req_); rt::dfree(d_bcount_); rt::dfree(d_rec_of_own_); rt::dfree(d_plan_); rt::dfree(d_req_seen_); }
 
 void ShardImage::clear() {
     rt::stream_t s = graph_->stream;
@@ -214,7 +216,7 @@ ImageView ShardImage::view(uint64_t* rec_of) const {
     im.nbrg = (uint64_t*)d_nbrg_; im.gkey = (uint64_t*)d_gkey_; im.rec_of = rec_of;
     im.hkeys = (unsigned long long*)d_hkeys_; im.hvals = (uint32_t*)d_hvals_; im.hmask = (uint32_t)(hcap_ - 1); im.cap = (uint32_t)cap_;
     unsigned long long* c = (unsigned long long*)d_ctr_;
-    im.n_rows = c; im.n_req = c + 1; im.req = (unsigned long long*)d_req_; im.req_cap = req_cap_;
+    im.n_rows = c; im.n_req = c + 1; im.req = (unsigned long long*)d_req_; im.req_cap = req_cap_; im.req_seen = (unsigned long long*)d_req_seen_;
     return im;
 }
 int ShardImage::row_bytes() const { return 72 + shard_.view.stride; }
@@ -268,7 +270,10 @@ void ShardImage::request(const unsigned long long* d_keys, int64_t n, rt::stream
     if (n <= 0) return;
     LDBG_LAUNCH(k_img_request, grid_of(n), 256, s, view(nullptr), d_keys, n);
 }
-void ShardImage::reset_requests(rt::stream_t s) { rt::dmemset((unsigned long long*)d_ctr_ + 1, 0, 8, s); }
+void ShardImage::reset_requests(rt::stream_t s) {
+    rt::dmemset((unsigned long long*)d_ctr_ + 1, 0, 8, s);
+    rt::dmemset(d_req_seen_, 0, (size_t)LDBG_REQ_SEEN * 8, s);
+}
 void ShardImage::counters(int64_t* n_rows, int64_t* n_req, int* overflow) const {
     unsigned long long c[4];
     rt::d2h(c, d_ctr_, 32, graph_->stream);

@@ -42,6 +42,7 @@ struct ImageView {
     unsigned long long* req;        // this round's requests (global id keys; duplicates allowed)
     unsigned long long* n_req;
     uint32_t req_cap;
+    unsigned long long* req_seen;   // [LDBG_REQ_SEEN] keys filed this round, direct mapped: the same row is usually wanted by several strands at once
 };
 
 LDBG_HOSTDEV uint32_t img_hash(uint64_t key) { uint64_t x = key * 0x9E3779B97F4A7C15ull; return (uint32_t)(x >> 29); }
@@ -57,7 +58,10 @@ LDBG_DEV int64_t img_lookup(const ImageView& im, uint64_t key) {
         h = (h + 1) & im.hmask;
     }
 }
+#define LDBG_REQ_SEEN 65536u
 LDBG_DEV void img_request(const ImageView& im, uint64_t key) {
+    // (a filter, not a set: a key pushed out by another is filed again, and a request that found no room this round is filed again next round)
+    if (atomic_exch_u64(&im.req_seen[img_hash(key) & (LDBG_REQ_SEEN - 1u)], (unsigned long long)key) == (unsigned long long)key) return;
     const unsigned long long at = atomic_add_u64(im.n_req, 1ull);
     if (at < im.req_cap) im.req[at] = key;             // (what does not fit is asked for again next round: the strand stays suspended)
 }

@@ -103,6 +103,7 @@ LDBG_DEV unsigned atomic_min_u32(unsigned* p, unsigned v) { return atomicMin(p, 
 LDBG_DEV unsigned atomic_or_u32(unsigned* p, unsigned v) { return atomicOr(p, v); }
 LDBG_DEV unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
 LDBG_DEV unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { return atomicCAS(p, cmp, v); }
+LDBG_DEV unsigned long long atomic_exch_u64(unsigned long long* p, unsigned long long v) { return atomicExch(p, v); }
 // wavefront primitives (64 lanes on gfx950); kernels that use them are launched with 64-thread blocks
 LDBG_DEV int wave_size() { return (int)blockDim.x; }   // wave kernels run one (possibly partial) wavefront per workgroup
 LDBG_DEV int wave_lane() { return (int)(threadIdx.x & 63u); }
@@ -181,6 +182,7 @@ inline unsigned atomic_min_u32(unsigned* p, unsigned v) { unsigned o = *p; if (v
 inline unsigned atomic_or_u32(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { unsigned long long o = *p; if (o == cmp) *p = v; return o; }
+inline unsigned long long atomic_exch_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
 // a simulated "wave" is a single lane
 inline int wave_size() { return 1; }
 inline int wave_lane() { return 0; }

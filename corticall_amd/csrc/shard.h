@@ -45,6 +45,7 @@ private:
     uint32_t req_cap_ = 0;
     void* d_nbrg_ = nullptr; void* d_gkey_ = nullptr; void* d_hkeys_ = nullptr; void* d_hvals_ = nullptr; void* d_ctr_ = nullptr; void* d_req_ = nullptr;
     void* d_rec_of_own_ = nullptr; void* d_bcount_ = nullptr;
+    void* d_req_seen_ = nullptr;
     mutable void* d_plan_ = nullptr; mutable size_t plan_bytes_ = 0;      // serve: the records picked for every request's slots
 };
 
