@@ -1261,7 +1261,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             unsigned long long c0[4] = {0, 0, 0, 0};
             rt::d2h(c0, d_ctr, 32, s);
             rt::stream_sync(s);
-            bool again = false;
+            bool again = getenv("LDBG_DFS_FORCE_RETRY") != nullptr;      // (test hook: take the second launch whatever the first one said)
             for (int64_t i = 0; i < ns; i++) again |= st0[(size_t)i] == ST_RETRY_PLAIN;
             if (again) {
                 vpool_dirty_ = c0[2];

@@ -87,6 +87,13 @@ def test_ref_dfs_with_sinks(orc, lib, tmp_path): pc.test_ref_dfs_with_sinks(orc,
 def test_dfs_packed_results(orc, lib, tmp_path): pc.case_dfs_packed_results(orc, lib, tmp_path)
 
 
+def test_dfs_second_launch_without_the_index(orc, lib, tmp_path, monkeypatch):
+    """a search the run steps hand back sends its chunk round again without the run index: forced here, the results must not change"""
+    monkeypatch.setenv("LDBG_DFS_FORCE_RETRY", "1")
+    pc.case_dfs_run_steps(orc, lib, tmp_path, 0)
+    pc.case_dfs_dense(orc, lib, tmp_path, 1)
+
+
 def test_factory_validation(orc, lib, tmp_path): pc.case_factory_validation(orc, lib, tmp_path)
 
 
