@@ -537,10 +537,37 @@ LDBG_KERNEL void k_contigs_rle(ContigRleArgs a) {
                     if (LDBG_PD_KIND(he) == LDBG_PD_RUN) {
                         const bool asc = (he >> 36) & 1ull, inv = (he >> 37) & 1ull;
                         const uint32_t first = (uint32_t)payload;
-                        for (uint32_t t = lane; t < len; t += WS) {
-                            const unsigned bb = a.runs.ubase[asc ? first + t : first - t];
-                            const unsigned b0 = !inv ? (bb & 3u) : 3u - ((bb >> 2) & 3u), b1 = !inv ? ((bb >> 2) & 3u) : 3u - (bb & 3u);
-                            o[place(hat + t)] = "ACGT"[fwd ? b1 : b0];
+                        // a run is a copy of `len` bytes of ubase with a per-byte map (which 2-bit field, complemented or not), forwards or
+                        // backwards: eight bytes per lane and access, four such accesses in flight per lane before the first store
+                        const uint8_t* ub = LDBG_GLOBAL(const uint8_t, a.runs.ubase);
+                        const unsigned shift = (fwd != inv) ? 2u : 0u, comp = inv ? 3u : 0u;
+                        auto ascii = [&](unsigned bb) -> unsigned { return (0x54474341u >> (8u * (((bb >> shift) & 3u) ^ comp))) & 0xFFu; };
+                        // low ends of the two byte ranges; same = both ascend with t or both descend
+                        const uint8_t* in_lo = asc ? ub + first : ub + first - (len - 1u);
+                        char* out_lo = LDBG_GLOBAL(char, o) + (fwd ? place(hat) : place(hat + len - 1u));
+                        const bool same = asc == fwd;
+                        const uint32_t nd = len / 8u;
+                        for (uint32_t base = 0; base < nd; base += 4u * WS) {      // (the trip count is the same for every lane)
+                            uint64_t w[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const uint32_t ci = base + (uint32_t)q * WS + lane;
+                                w[q] = 0;
+                                if (ci < nd) __builtin_memcpy(&w[q], in_lo + (same ? 8u * ci : len - 8u - 8u * ci), 8);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const uint32_t ci = base + (uint32_t)q * WS + lane;
+                                uint64_t v = 0;
+#pragma unroll
+                                for (int bI = 0; bI < 8; bI++) v |= (uint64_t)ascii((unsigned)(w[q] >> (8 * bI)) & 0xFFu) << (8 * bI);
+                                if (!same) v = __builtin_bswap64(v);
+                                if (ci < nd) __builtin_memcpy(out_lo + 8u * ci, &v, 8);
+                            }
+                        }
+                        for (uint32_t t = 8u * nd + lane; t < len; t += WS) {      // the last one to seven bytes
+                            const unsigned bb = in_lo[same ? t : len - 1u - t];
+                            out_lo[t] = (char)ascii(bb);
                         }
                     } else {                                   // REPEAT: the bases of the last recorded revolution, again and again
                         wave_fence();
