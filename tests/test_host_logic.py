@@ -1,3 +1,4 @@
+"""host-side helpers of the product package that need neither a GPU nor the host simulation"""
 
 
 def test_java_hashmap_order_matches_an_emulated_hashmap():
