@@ -202,38 +202,45 @@ template <int W>
 LDBG_DEV bool merged_vertices(const DfsArgs& a, DfsLane<W>& L, uint32_t start, uint32_t& count) {
     StrandState& st = L.st;
     const uint32_t end = st.pw.n;
-    uint32_t cap = 64;
-    while (cap < 2u * (end - start)) cap <<= 1;
-    for (uint32_t i = 0; i < cap; i++) if (!path_append(a.w, st.s, st.pw, 0ull)) { st.status = append_failure(a, st); return false; }
-    count = 0;
-    const uint64_t len_mask = 0x7FFFull;
+    // vertices the entries stand for (a RUN descriptor = a stretch of the run index: its vertices are counted one by one — siblings cut the
+    // same stretch in different places, so a stretch in one log can be single vertices, or part of a longer stretch, in another)
+    uint64_t total = 0;
     for (uint32_t pos = start; pos < end; pos++) {
         const uint64_t en = path_read(a.w, st.s, pos);
-        uint64_t key;
-        uint32_t len = 1;
-        if (en & DFS_MARK) {
-            if (en == DFS_KMER) { st.status = ST_MERGE_UNSUPPORTED; return false; }
-            if (LDBG_PD_KIND(en) != LDBG_PD_RUN) continue;                     // OPEN, CLOSE, PAD
-            const uint64_t payload = path_read(a.w, st.s, pos + 1);
-            pos++;
-            len = (uint32_t)(en & 0xFFFFFu);
-            // interiors always start at q_2: (first position, copyIndex, direction bits) names the stretch, the longest crossing counts
-            key = DFS_MARK | ((uint64_t)(uint32_t)payload << 15) | (((en >> 20) & 0x7FFFull) << 46) | (((en >> 36) & 3ull) << 61);
-        } else {
-            if (path_idx(en) < 0) { st.status = ST_MERGE_UNSUPPORTED; return false; }
-            key = en;
-        }
+        if (!(en & DFS_MARK)) { total++; continue; }
+        if (en == DFS_KMER) { st.status = ST_MERGE_UNSUPPORTED; return false; }
+        if (LDBG_PD_KIND(en) == LDBG_PD_RUN) { total += en & 0xFFFFFu; pos++; }
+    }
+    uint32_t cap = 64;
+    while ((uint64_t)cap < 2ull * total) cap <<= 1;
+    for (uint32_t i = 0; i < cap; i++) if (!path_append(a.w, st.s, st.pw, 0ull)) { st.status = append_failure(a, st); return false; }
+    count = 0;
+    auto insert = [&](uint64_t key) {                                    // key: (record + 1) | flip << 33 | copyIndex << 36, never 0
         uint32_t h = (uint32_t)(sig_mix(key) >> 20) & (cap - 1u);
         while (true) {
             const uint64_t cur = path_read(a.w, st.s, end + h);
-            if (cur == 0ull) { path_write(a.w, st.s, end + h, (en & DFS_MARK) ? (key | (uint64_t)len) : key); count += len; break; }
-            if (!(en & DFS_MARK)) { if (cur == key) break; }
-            else if ((cur & ~len_mask) == key) {
-                const uint32_t had = (uint32_t)(cur & len_mask);
-                if (len > had) { path_write(a.w, st.s, end + h, key | (uint64_t)len); count += len - had; }
-                break;
-            }
+            if (cur == 0ull) { path_write(a.w, st.s, end + h, key); count++; return; }
+            if (cur == key) return;
             h = (h + 1u) & (cap - 1u);
+        }
+    };
+    const uint64_t ident = ~((3ull << 34) | (1ull << 60));               // a vertex entry without the base it was reached by and the quirk note
+    for (uint32_t pos = start; pos < end; pos++) {
+        const uint64_t en = path_read(a.w, st.s, pos);
+        if (!(en & DFS_MARK)) {
+            if (path_idx(en) < 0) { st.status = ST_MERGE_UNSUPPORTED; return false; }
+            insert(en & ident);
+            continue;
+        }
+        if (LDBG_PD_KIND(en) != LDBG_PD_RUN) continue;                    // OPEN, CLOSE, PAD
+        const uint64_t payload = path_read(a.w, st.s, pos + 1);
+        pos++;
+        const uint32_t len = (uint32_t)(en & 0xFFFFFu), acopy = (uint32_t)(en >> 20) & 0xFFFFu, first = (uint32_t)payload;
+        const bool asc = (en >> 36) & 1ull, inv = (en >> 37) & 1ull;
+        const int copy = st.fwd ? (int)acopy : -(int)acopy;
+        for (uint32_t t = 0; t < len; t++) {                              // as k_expand_paths (walk.cpp) materialises them
+            const uint32_t u = LDBG_GLOBAL(const uint32_t, a.w.e.runs.uo)[asc ? first + t : first - t];
+            insert(path_pack((int64_t)(u & 0x7FFFFFFFu), ((u >> 31) != 0u) != inv, 0u, copy) & ident);
         }
     }
     path_truncate(a.w, st.s, st.pw, end);
@@ -246,6 +253,9 @@ LDBG_DEV void open_branch(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, con
     StrandState& st = L.st;
     const EngineView& e = a.w.e;
     if ((int)L.depth >= a.max_depth) { st.status = ST_DEPTH_OVERFLOW; return; }
+#ifdef LDBG_HOSTSIM
+    if (getenv("LDBG_DFS_TRACE")) fprintf(stderr, "P open depth %u size %u iters %u\n", L.depth, size, st.iters);
+#endif
     L.log_start = st.pw.n;
     L.size = size;
     L.nlin = 1;
@@ -275,6 +285,9 @@ template <int W>
 LDBG_DEV bool end_branch(const DfsArgs& a, DfsLane<W>& L, bool success) {
     StrandState& st = L.st;
     L.result = success;
+#ifdef LDBG_HOSTSIM
+    if (getenv("LDBG_DFS_TRACE")) fprintf(stderr, "P end depth %u success %d gV %u size %u iters %u\n", L.depth, (int)success, st.gV, L.size, st.iters);
+#endif
     if (L.depth == 0) {
         if (success) { if (!path_append(a.w, st.s, st.pw, DFS_CLOSE)) st.status = append_failure(a, st); }
         else { path_truncate(a.w, st.s, st.pw, 0); st.branch_null = true; }
@@ -397,6 +410,9 @@ LDBG_DEV int dfs_run_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int
     uint32_t keep; bool succ;
     dfs_rule_run<W>(a, L, pc, mode_a ? 0u : 1u, steps, keep, succ);
     if (keep == 0u) return 0;
+#ifdef LDBG_HOSTSIM
+    if (getenv("LDBG_DFS_TRACE")) fprintf(stderr, "P run depth %u mode %c n %u keep %u succ %d gV %u size %u iters %u S %u E %u q %u\n", L.depth, mode_a ? 'A' : 'B', n, keep, (int)succ, st.gV, L.size, st.iters, pc.S, pc.E, pc.q);
+#endif
     const bool full = keep >= steps;
     const uint32_t k = full ? steps : keep;
     Node y, z;
