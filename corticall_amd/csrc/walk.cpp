@@ -1122,7 +1122,8 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
         if (runs_ && !img) {
             // with the run index a strand's table holds the fringes of the stretches it crosses and the junction vertices between
             // them: a few entries per thousand k-mers.  Small tables = little to zero between batches (C3: 8.5 ms -> 0.3 ms)
-            a.vcap_init = std::min<uint32_t>(2048u, vcap_max);
+            // (C3, one step: 128 entries 10.05 ms, 256 9.96, 512 9.71, 1024 9.79, 2048 10.08)
+            a.vcap_init = std::min<uint32_t>(512u, vcap_max);
         } else {
             // Regrowing a table stalls the owner's whole wavefront (strand.h), and the regrowths of its 64 strands add up: start as large as
             // half of the pool allows when every strand of the batch takes one (C3: 65,536 entries, launch 291 -> 250 ms against 4,096)
