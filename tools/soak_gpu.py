@@ -25,7 +25,7 @@ for seed in range(first, first + count):
                      ("dfs_dense", lambda t: pc.case_dfs_dense(orc, lib, t, seed)), ("dense_cycles", lambda t: pc.case_dense_cycles(orc, lib, t, seed)),
                      ("findtips", lambda t: pc.case_findtips(orc, lib, t, k, seed, seed % 2 == 0)),
                      ("partition", lambda t: pc.case_partition(orc, lib, t, r.choice([21, 31, 47]), seed, seed % 2 == 1)),
-                     ("dfs_rules", lambda t: pc.case_dfs_rules(orc, lib, t, r.choice([9, 21, 31]), seed, seed % 2 == 0)),
+                     ("dfs_rules", lambda t: pc.case_dfs_rules(orc, lib, t, r.choice([21, 31]), seed, seed % 2 == 0)),      # (k = 9: some rules fork without end in the checker too)
                      ("random_walks", lambda t: pc.case_random_walks(orc, lib, t, r.choice([21, 31, 47, 64]), seed, seed % 2 == 0))):
         tmp = pathlib.Path(tempfile.mkdtemp(prefix="soak_"))
         try:
