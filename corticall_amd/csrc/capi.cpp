@@ -288,11 +288,12 @@ ldbg_status ldbg_graph_find_ascii(const ldbg_graph* g, const char* kmers, int64_
         std::vector<uint8_t> valid((size_t)n);
         ascii_batch_to_words(kmers, n, k, W, packed.data(), valid.data());      // Q4: a string with a non-ACGT byte never matches
         rt::stream_t s = g->g.stream;
-        uint64_t* dq = (uint64_t*)rt::dmalloc((size_t)n * W * 8);
-        uint8_t* dv = (uint8_t*)rt::dmalloc((size_t)n);
-        int64_t* di = (int64_t*)rt::dmalloc((size_t)n * 8);
-        uint32_t* dc = cov_out ? (uint32_t*)rt::dmalloc((size_t)n * C * 4) : nullptr;
-        uint8_t* de = edges_out ? (uint8_t*)rt::dmalloc((size_t)n * C) : nullptr;
+        struct Tmp { std::vector<void*> p; ~Tmp() { for (void* x : p) rt::dfree(x); } void* get(size_t nbytes) { void* x = rt::dmalloc(nbytes); p.push_back(x); return x; } } tmp;
+        uint64_t* dq = (uint64_t*)tmp.get((size_t)n * W * 8);
+        uint8_t* dv = (uint8_t*)tmp.get((size_t)n);
+        int64_t* di = (int64_t*)tmp.get((size_t)n * 8);
+        uint32_t* dc = cov_out ? (uint32_t*)tmp.get((size_t)n * C * 4) : nullptr;
+        uint8_t* de = edges_out ? (uint8_t*)tmp.get((size_t)n * C) : nullptr;
         rt::h2d(dq, packed.data(), (size_t)n * W * 8, s);
         rt::h2d(dv, valid.data(), (size_t)n, s);
         g->g.find_dev(dq, n, di, dc, de, s, dv);
@@ -300,7 +301,6 @@ ldbg_status ldbg_graph_find_ascii(const ldbg_graph* g, const char* kmers, int64_
         if (cov_out) rt::d2h(cov_out, dc, (size_t)n * C * 4, s);
         if (edges_out) rt::d2h(edges_out, de, (size_t)n * C, s);
         rt::stream_sync(s);
-        rt::dfree(dq); rt::dfree(dv); rt::dfree(di); rt::dfree(dc); rt::dfree(de);
     });
 }
 

@@ -818,6 +818,7 @@ LDBG_KERNEL void k_dfs_round_stats(const unsigned long long* ctr, int64_t ns, co
     const int64_t handed = (int64_t)ctr[0] < ns ? (int64_t)ctr[0] : ns;
     stats[0] = (int64_t)ctr[4] + (ns - handed);
     stats[1] = (int64_t)*n_req;
+    stats[2] = (int64_t)*(const unsigned*)(n_req + 1);      // the image's overflow flag (image.cpp: d_ctr_[2])
 }
 
 // sink keys over an image: the sink's record is known by its image slot (-1 = none; -2 = the string is not a k-mer)
@@ -1292,14 +1293,24 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         // carries the requests to their owners and the rows back, and says when no rank has a search left
         rt::stream_sync(s);
         rt::stream_t rs = sharded->stream ? sharded->stream : s;
-        for (int64_t round = 0;; round++) {
+        bool aborted = false;
+        while (true) {
             rt::dmemset(d_ctr + 4, 0, 8, rs);
             sharded->img->reset_requests(rs);
             launch(rs);
             LDBG_LAUNCH(k_dfs_round_stats, 1, 64, rs, (const unsigned long long*)d_ctr, ns, (const unsigned long long*)a.w.img.n_req, sharded->d_stats);
-            if (sharded->round_done(sharded->user)) break;
+            const int rd = sharded->round_done(sharded->user);
+            if (rd == 2) aborted = true;      // the caller gives the batch up on every rank (a full image: searches that wait for a row would wait for ever)
+            if (rd) break;
         }
         rt::stream_sync(rs);
+        if (aborted) {
+            unsigned long long c0[4] = {0, 0, 0, 0};
+            rt::d2h(c0, d_ctr, 32, s);
+            rt::stream_sync(s);
+            vpool_dirty_ = c0[2];
+            throw StatusError(LDBG_ERR_CAPACITY, "IMAGE_FULL");
+        }
     }
     e1.record(s);
     std::vector<uint32_t> strand_n(ns), status(ns), iters(ns);

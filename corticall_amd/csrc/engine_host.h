@@ -75,9 +75,9 @@ struct ShardedRun {
     ShardImage* img;
     const int32_t* d_seed_slot;    // [n] image slot of every source's record (-1 = none): the rows are in the image already
     const int32_t* d_sink_slot;    // [number of sinks] likewise
-    int (*round_done)(void* user);
+    int (*round_done)(void* user);  // 0 = another round, 1 = no rank has a search in progress, 2 = give the batch up ("IMAGE_FULL")
     void* user;
-    int64_t* d_stats;              // device, 2 x int64: searches of this rank not done yet, requests filed in the round
+    int64_t* d_stats;              // device, 3 x int64: searches of this rank not done yet, requests filed in the round, the image's overflow flag
     rt::stream_t stream;           // the stream the rounds are queued on (the callback's collectives use it too)
 };
 uint64_t vt_series(uint64_t init, uint64_t vmax);     // walk.cpp

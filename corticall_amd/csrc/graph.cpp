@@ -184,7 +184,8 @@ LDBG_HOSTDEV uint64_t shard_mix64(uint64_t x) {
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
     return x;
 }
-LDBG_HOSTDEV int shard_minimizer_len(int k) { return k <= 8 ? k : (k + 2) / 3; }
+// (at most 32 bases: the m-mer windows below are one 64-bit word — k >= 97 would otherwise shift by 64 bits and more)
+LDBG_HOSTDEV int shard_minimizer_len(int k) { const int m = k <= 8 ? k : (k + 2) / 3; return m > 32 ? 32 : m; }
 template <int W>
 LDBG_HOSTDEV uint64_t shard_minimizer_hash(const Kmer<W>& q, int k) {
     const int m = shard_minimizer_len(k);

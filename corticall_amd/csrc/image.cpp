@@ -79,18 +79,21 @@ LDBG_KERNEL void k_img_insert(ImageView im, LinksView links, int k, uint32_t lin
         const uint64_t* in = (const uint64_t*)(rows + (size_t)i * rowb);
         const uint64_t key = in[0];
         if (key == 0ull) continue;
+        // A full image takes no more keys: the flag ends the rounds on every rank (k_round_stats) and the host enlarges the image.  (Keys
+        // claimed without a slot would fill the hash map, and a probe of a map without a free slot would never end.)
+        if (LDBG_GLOBAL(const unsigned long long, im.n_rows)[0] >= (unsigned long long)im.cap) { *overflow = 1u; continue; }
         // claim the key (several strands may have asked for the same row in one round: the first copy is kept)
         uint32_t h = img_hash(key) & im.hmask;
         bool claimed = false;
-        while (true) {
+        for (uint32_t probes = 0; probes <= im.hmask; probes++) {          // (bounded: threads that passed the test above together may have filled the map)
             const unsigned long long prev = atomic_cas_u64(&im.hkeys[h], 0ull, (unsigned long long)key);
             if (prev == 0ull) { claimed = true; break; }
             if (prev == key) break;
             h = (h + 1) & im.hmask;
         }
-        if (!claimed) continue;
+        if (!claimed) { if (LDBG_GLOBAL(const unsigned long long, im.hkeys)[h] != key) *overflow = 1u; continue; }
         const unsigned long long slot = atomic_add_u64(im.n_rows, 1ull);
-        if (slot >= im.cap) { *overflow = 1u; continue; }                // (the key stays claimed without a slot: lookups miss; the host grows the image)
+        if (slot >= im.cap) { *overflow = 1u; continue; }                // (the key stays claimed without a slot: lookups miss until the host has enlarged the image)
         uint64_t* dst = (uint64_t*)(im.probe + (size_t)slot * im.stride);
         for (int w = 0; w < im.stride / 8; w++) dst[w] = in[9 + w];
         uint32_t* nb = (uint32_t*)((uint8_t*)dst + im.nbr_off);

@@ -48,7 +48,7 @@ struct ImageView {
 LDBG_HOSTDEV uint32_t img_hash(uint64_t key) { uint64_t x = key * 0x9E3779B97F4A7C15ull; return (uint32_t)(x >> 29); }
 LDBG_DEV int64_t img_lookup(const ImageView& im, uint64_t key) {
     uint32_t h = img_hash(key) & im.hmask;
-    while (true) {
+    for (uint32_t probes = 0; probes <= im.hmask; probes++) {      // (bounded: a map that an overflowing round has filled has no free slot to stop at)
         const unsigned long long k = LDBG_GLOBAL(const unsigned long long, im.hkeys)[h];
         if (k == 0ull) return -1;
         if (k == key) {
@@ -57,6 +57,7 @@ LDBG_DEV int64_t img_lookup(const ImageView& im, uint64_t key) {
         }
         h = (h + 1) & im.hmask;
     }
+    return -1;
 }
 #define LDBG_REQ_SEEN 65536u
 LDBG_DEV void img_request(const ImageView& im, uint64_t key) {

@@ -148,20 +148,27 @@ RunIndex::RunIndex(const EngineView& e, int device, rt::stream_t s) {
     rt::set_device(device);
     rt::Event e0, e1;
     e0.record(s);
-    d_uinfo_ = rt::dmalloc((size_t)N * 8);
-    d_uo_ = rt::dmalloc((size_t)N * 4);
-    d_ubase_ = rt::dmalloc((size_t)N);
-    uint32_t* succ = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
-    uint32_t* pred = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
-    unsigned long long* pd = (unsigned long long*)rt::dmalloc((size_t)n2 * 8);
-    uint32_t* tail = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
-    uint32_t* len = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
-    uint32_t* cnt = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
-    uint32_t* off = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
-    unsigned long long* sums = (unsigned long long*)rt::dmalloc((size_t)RUN_SCAN_OWNERS * 8);
-    unsigned long long* stats = (unsigned long long*)rt::dmalloc(64);
+    // Everything is allocated inside the try block (about 64 bytes per record of temporaries: 44 GB at 690 M records — the big tables are
+    // where an allocation fails); a failure THERE leaves the engine without an index (the walk kernel then steps k-mer by k-mer)
+    // instead of failing every walk.
+    uint32_t *succ = nullptr, *pred = nullptr, *tail = nullptr, *len = nullptr, *cnt = nullptr, *off = nullptr;
+    unsigned long long *pd = nullptr, *sums = nullptr, *stats = nullptr;
     auto free_tmp = [&] { rt::dfree(succ); rt::dfree(pred); rt::dfree(pd); rt::dfree(tail); rt::dfree(len); rt::dfree(cnt); rt::dfree(off); rt::dfree(sums); rt::dfree(stats); };
+    bool allocating = true;
     try {
+        d_uinfo_ = rt::dmalloc((size_t)N * 8);
+        d_uo_ = rt::dmalloc((size_t)N * 4);
+        d_ubase_ = rt::dmalloc((size_t)N);
+        succ = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
+        pred = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
+        pd = (unsigned long long*)rt::dmalloc((size_t)n2 * 8);
+        tail = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
+        len = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
+        cnt = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
+        off = (uint32_t*)rt::dmalloc((size_t)n2 * 4);
+        sums = (unsigned long long*)rt::dmalloc((size_t)RUN_SCAN_OWNERS * 8);
+        stats = (unsigned long long*)rt::dmalloc(64);
+        allocating = false;
         const int grid = grid_for(n2);
         rt::dmemset(stats, 0, 64, s);
         rt::dmemset(tail, 0, (size_t)n2 * 4, s);
@@ -209,6 +216,10 @@ RunIndex::RunIndex(const EngineView& e, int device, rt::stream_t s) {
         free_tmp();
         rt::dfree(d_uinfo_); rt::dfree(d_uo_); rt::dfree(d_ubase_);
         d_uinfo_ = d_uo_ = d_ubase_ = nullptr;
+        if (allocating) {
+            if (getenv("LDBG_HOST_TIMES")) fprintf(stderr, "[ldbg] run index: not enough device memory for the build (%lld records); walking without it\n", (long long)N);
+            return;
+        }
         throw;
     }
     free_tmp();

@@ -1049,6 +1049,7 @@ LDBG_KERNEL void k_round_stats(const unsigned long long* ctr, int64_t ns, const 
     const int64_t handed = (int64_t)ctr[0] < ns ? (int64_t)ctr[0] : ns;
     stats[0] = (int64_t)ctr[4] + (ns - handed);
     stats[1] = (int64_t)*n_req;
+    stats[2] = (int64_t)*(const unsigned*)(n_req + 1);      // the image's overflow flag (image.cpp: d_ctr_[2]): a full image ends the rounds on every rank
 }
 
 // img: the walk runs on the local image of a sharded table (image.h): strands suspend where a row is missing, seeds come as image slots
@@ -1417,7 +1418,8 @@ void Engine::sharded_abort() {
     }
     sharded_img_ = nullptr;
 }
-// d_stats (device, 2 x int64): strands of this rank still in progress after the round (suspended or not yet handed out), requests filed
+// d_stats (device, 3 x int64): strands of this rank still in progress after the round (suspended or not yet handed out), requests filed,
+// the image's overflow flag (a full image: the caller stops the rounds on every rank, enlarges the image and runs the batch again)
 void Engine::sharded_walk_round(int64_t* d_stats) {
     if (!sharded_run_) throw StatusError(LDBG_ERR_ARG, "sharded_walk_round without sharded_walk_begin");
     rt::set_device(graph->device);

@@ -244,6 +244,14 @@ class ShardedCortexGraph:
         self.shard.close()
 
 
+class _ImageFull(Exception):
+    """some rank's image of the sharded table is full (seen by every rank in the same round)"""
+
+
+class PeerRankFailed(RuntimeError):
+    """another rank of the group failed in a collective batch; this rank's own part had no fatal error"""
+
+
 class ShardedTraversalEngine:
     """TraversalEngine.walk over a ShardedCortexGraph — ContigStopper with or without link annotations, any k: every rank runs the
     walk kernel on its local image of the table (csrc/image.h); rows travel, walks do not.
@@ -251,32 +259,16 @@ class ShardedTraversalEngine:
 
     def __init__(self, sgraph, traversal_colors, links=(), recruitment_colors=(), joining_colors=(), direction=0, op=0, max_branch_length=75000,
                  stopping_rule=None, image_rows=None, rows_per_owner=4096, check_every=8, keep_image=False, chain_depth=16, rois=None):
-        from .traversal import ContigStopper, TraversalEngineFactory
         self.g = sgraph
         if not sgraph.has_neighbour_index:
             sgraph.build_neighbour_index()
-        lib, d = sgraph._lib, sgraph._d
-        self._lib, self._d = lib, d
-        cap = int(image_rows or min(max(sgraph.numRecords, 1024), 1 << 25))
-        self._img = C.c_void_p()
-        lib.check(d.ldbg_image_create(sgraph.shard._h, C.c_int64(cap), C.c_int64(sgraph.numRecords), C.byref(self._img)))
-        gh = C.c_void_p()
-        lib.check(d.ldbg_image_graph(self._img, C.byref(gh)))
-        self.image_graph = CortexGraph._from_handle(gh, lib, sgraph.path + "#image%d" % sgraph.rank, owner=self)
-        rb = C.c_int()
-        lib.check(d.ldbg_image_row_bytes(self._img, C.byref(rb)))
-        self.row_bytes = rb.value
-        f = (TraversalEngineFactory(lib=lib).traversalColors(*traversal_colors).graph(self.image_graph).stoppingRule(stopping_rule or ContigStopper)
-             .traversalDirection(direction).combinationOperator(op).maxBranchLength(max_branch_length))
-        if recruitment_colors:
-            f.recruitmentColors(*recruitment_colors)
-        if joining_colors:
-            f.joiningColors(*joining_colors)
-        if links:
-            f.links(*links)
-        if rois is not None:          # the ROI graph of the stopping rules: a whole (small) graph, opened by every rank on its own device
-            f.rois(rois)
-        self.engine = f.make()
+        self._lib, self._d = sgraph._lib, sgraph._d
+        self._make = dict(traversal_colors=tuple(traversal_colors), links=tuple(links), recruitment_colors=tuple(recruitment_colors), joining_colors=tuple(joining_colors),
+                          direction=direction, op=op, max_branch_length=max_branch_length, stopping_rule=stopping_rule, rois=rois)
+        self._img, self.engine = None, None
+        # sizing rule: an image never needs more rows than the table has records; it starts at min(records, 2^25) rows (5 GB at k <= 64) and
+        # DOUBLES — on every rank together — whenever a batch fills it (_ImageFull below), so its size is never the caller's problem
+        self._build(int(image_rows or min(max(sgraph.numRecords, 1024), 1 << 25)))
         self.rows_per_owner = int(rows_per_owner)
         self.chain_depth = max(1, int(chain_depth))      # row slots per request: the row asked for + rows around it its owner holds too
         self.check_every = int(check_every)
@@ -289,8 +281,47 @@ class ShardedTraversalEngine:
         self._recv = torch.zeros((w, cap_o), dtype=torch.int64, device=sgraph.device)
         self._rows_out = torch.zeros((w, cap_o, self.chain_depth, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
         self._rows_in = torch.zeros((w, cap_o, self.chain_depth, self.row_bytes), dtype=torch.uint8, device=sgraph.device)
-        self._stats = torch.zeros(2, dtype=torch.int64, device=sgraph.device)
+        self._stats = torch.zeros(3, dtype=torch.int64, device=sgraph.device)
         self._tstream = torch.cuda.Stream(device=sgraph.device) if sgraph.device.type == "cuda" else None
+
+    def _build(self, cap):
+        """(re)create the image with `cap` rows and the engine over it"""
+        from .traversal import ContigStopper, TraversalEngineFactory
+        sgraph, lib, d, mk = self.g, self._lib, self._d, self._make
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+        if self._img is not None:
+            d.ldbg_image_destroy(self._img)
+            self._img = None
+        self.image_rows = int(cap)
+        self._img = C.c_void_p()
+        lib.check(d.ldbg_image_create(sgraph.shard._h, C.c_int64(cap), C.c_int64(sgraph.numRecords), C.byref(self._img)))
+        gh = C.c_void_p()
+        lib.check(d.ldbg_image_graph(self._img, C.byref(gh)))
+        self.image_graph = CortexGraph._from_handle(gh, lib, sgraph.path + "#image%d" % sgraph.rank, owner=self)
+        rb = C.c_int()
+        lib.check(d.ldbg_image_row_bytes(self._img, C.byref(rb)))
+        self.row_bytes = rb.value
+        f = (TraversalEngineFactory(lib=lib).traversalColors(*mk["traversal_colors"]).graph(self.image_graph).stoppingRule(mk["stopping_rule"] or ContigStopper)
+             .traversalDirection(mk["direction"]).combinationOperator(mk["op"]).maxBranchLength(mk["max_branch_length"]))
+        if mk["recruitment_colors"]:
+            f.recruitmentColors(*mk["recruitment_colors"])
+        if mk["joining_colors"]:
+            f.joiningColors(*mk["joining_colors"])
+        if mk["links"]:
+            f.links(*mk["links"])
+        if mk["rois"] is not None:          # the ROI graph of the stopping rules: a whole (small) graph, opened by every rank on its own device
+            f.rois(mk["rois"])
+        self.engine = f.make()
+
+    def _grow_image(self):
+        """every rank doubles its image (collective by construction: _ImageFull is raised on all ranks together)"""
+        limit = max(self.g.numRecords, 1024)
+        if self.image_rows >= limit:
+            raise _native.LdbgError(7, "the image of the sharded table is full at %d rows although the table has only %d records" % (self.image_rows, self.g.numRecords))
+        self.image_grown = getattr(self, "image_grown", 0) + 1
+        self._build(min(limit, 2 * self.image_rows))
 
     def _stream(self):
         """the HIP stream every call of a round is queued on: the engine's own torch stream (a real stream handle — torch's default
@@ -314,38 +345,57 @@ class ShardedTraversalEngine:
         dist.all_to_all_single(rows_in, rows_out, group=g._group)
         lib.check(d.ldbg_image_insert(self._img, self.engine._h, P(rows_in), C.c_int64(n * self.chain_depth), stream))
 
-    def _all_done(self, local_count):
-        t = local_count.clone().reshape(1)
-        self.g._dist.all_reduce(t, group=self.g._group)
-        return int(t.item()) == 0
-
     def _round_state(self):
         """(no rank has a strand left, row requests per owner to provide for in the coming rounds) from the counters of the round that has
         just run: one small all-reduce (MAX) of (strands in progress, requests filed)"""
         t = self._stats.clone()
         self.g._dist.all_reduce(t, op=self.g._dist.ReduceOp.MAX, group=self.g._group)
         left, nreq = int(t[0].item()), int(t[1].item())
+        if int(t[2].item()):            # some rank's image is full: a strand that waits for a row it can never get would wait for ever
+            raise _ImageFull()
         want = max(64, -(-3 * nreq // max(1, self.g.world)))       # three times an even spread of the busiest rank's requests
         cap = 64
         while cap < want:
             cap *= 2
         return left == 0, min(self.rows_per_owner, cap)
 
+    # ---- a batch is a collective: every rank must leave it the same way.  Errors that depend on a rank's own seeds (a rule's
+    # NullPointerException, a full link store, an exhausted pool ...) are raised where every rank stands at the same point of the
+    # protocol — after the rounds — so they are CAUGHT there, the ranks agree on the worst outcome (one MAX all-reduce: 0 = done,
+    # 1 = run the batch again — a store or the image has been enlarged —, 2 = failed) and then all return, all retry or all raise.
+    _RETRYABLE = ("LINKSTORE_FULL", "LOG_FULL", "DEPTH_OVERFLOW")
+
+    def _collective_batch(self, once, attempts=10):
+        torch, dist = self.g._torch, self.g._dist
+        for attempt in range(attempts):
+            code, err, out, grow = 0, None, None, 0
+            try:
+                out = once()
+            except _ImageFull:
+                code, grow = 1, 1            # (raised on every rank together: the flag is all-reduced before anybody looks at it)
+            except _native.LdbgError as ex:
+                err = ex
+                if "IMAGE_FULL" in str(ex):
+                    code, grow = 1, 1
+                else:
+                    code = 1 if any(w in str(ex) for w in self._RETRYABLE) else 2     # the library has enlarged the store that was full
+            except Exception as ex:       # noqa: BLE001 — whatever it is, the other ranks must not be left waiting in a collective
+                code, err = 2, ex
+            t = torch.tensor([code, grow], dtype=torch.int64, device=self.g.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.g._group)
+            worst, grow = int(t[0].item()), int(t[1].item())
+            if worst == 0:
+                return out
+            if worst == 2 or attempt == attempts - 1:
+                if err is not None and (code == 2 or worst != 2):
+                    raise err
+                raise PeerRankFailed("a peer rank failed in this batch (this rank's own part was %s)" % ("fine" if err is None else "to be run again: %s" % err))
+            if grow:
+                self._grow_image()
+
     def walk_batch(self, seeds):
         """contigs of this rank's seeds (list of str); collective: every rank calls it (possibly with no seeds)"""
-        torch, dist = self.g._torch, self.g._dist
-        for attempt in range(6):
-            again = 0
-            try:
-                out = self._walk_batch_once(seeds)
-            except _native.LdbgError as ex:
-                if "LINKSTORE_FULL" not in str(ex) or attempt == 5:
-                    raise
-                again = 1                       # the library has enlarged this engine's link stores: every rank walks the batch again
-            t = torch.tensor([again], dtype=torch.int64, device=self.g.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.g._group)
-            if int(t.item()) == 0:
-                return out
+        return self._collective_batch(lambda: self._walk_batch_once(seeds))
 
     def _walk_batch_once(self, seeds):
         if self._tstream is None:
@@ -370,7 +420,13 @@ class ShardedTraversalEngine:
         slots = torch.full((max(1, n),), -1, dtype=torch.int32, device=g.device)[:n]
         while True:          # explicit requests, as many rounds as the per-owner blocks need
             missing = keys[(slots < 0) & (keys != 0)].contiguous() if n else keys
-            if self._all_done(torch.tensor(int(missing.shape[0]), dtype=torch.int64, device=g.device)):
+            ovf = C.c_int()
+            lib.check(d.ldbg_image_counters(self._img, None, None, C.byref(ovf)))
+            t = torch.tensor([int(missing.shape[0]), int(ovf.value)], dtype=torch.int64, device=g.device)
+            g._dist.all_reduce(t, op=g._dist.ReduceOp.MAX, group=g._group)
+            if int(t[1].item()):
+                raise _ImageFull()
+            if int(t[0].item()) == 0:
                 break
             lib.check(d.ldbg_image_request(self._img, P(missing), C.c_int64(int(missing.shape[0])), stream))
             self._exchange(stream)
@@ -411,8 +467,6 @@ class ShardedTraversalEngine:
         nrows, nreq, ovf = C.c_int64(), C.c_int64(), C.c_int()
         lib.check(d.ldbg_image_counters(self._img, C.byref(nrows), C.byref(nreq), C.byref(ovf)))
         self.image_rows_used = nrows.value
-        if ovf.value:
-            raise _native.LdbgError(7, "the image of the sharded table is full (%d rows): create the engine with a larger image_rows" % nrows.value)
         total, trav = C.c_int64(), C.c_int64()
         lib.check(d.ldbg_engine_sharded_walk_finish(self.engine._h, C.byref(total), C.byref(trav)))
         self.kmers_traversed = trav.value
@@ -428,20 +482,7 @@ class ShardedTraversalEngine:
     def dfs_batch(self, sources, sinks=None):
         """TraversalEngine.dfs(source, sinks...) for this rank's sources (the engine's stopping rule); sinks: per source a list of
         k-mers.  -> list of DfsGraph / None (a vertex's record index is its image slot: >= 0 means "has a record").  Collective."""
-        from .traversal import _DfsBatch
-        torch, dist = self.g._torch, self.g._dist
-        for attempt in range(8):
-            again, out = 0, None
-            try:
-                out = self._dfs_batch_once(sources, sinks)
-            except _native.LdbgError as ex:
-                if not any(w in str(ex) for w in ("LINKSTORE_FULL", "LOG_FULL", "DEPTH_OVERFLOW")) or attempt == 7:
-                    raise
-                again = 1
-            t = torch.tensor([again], dtype=torch.int64, device=self.g.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.g._group)
-            if int(t.item()) == 0:
-                return out
+        return self._collective_batch(lambda: self._dfs_batch_once(sources, sinks))
 
     def _dfs_batch_once(self, sources, sinks):
         from .traversal import _DfsBatch
@@ -477,9 +518,12 @@ class ShardedTraversalEngine:
                     state["gap"] = min(self.check_every, state["gap"] * 2)
                     done, state["cap"] = self._round_state()
                     return 1 if done else 0
+                except _ImageFull as ex:           # (every rank gets here in the same round: the library gives the batch up, "IMAGE_FULL")
+                    state["error"] = ex
+                    return 2
                 except BaseException as ex:        # never let an exception cross the C boundary
                     state["error"] = ex
-                    return 1
+                    return 2
             cb = C.CFUNCTYPE(C.c_int, C.c_void_p)(round_done)
             res = C.c_void_p()
             t0 = C.c_int64()

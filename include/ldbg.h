@@ -172,14 +172,17 @@ ldbg_status ldbg_image_insert(ldbg_image* im, const struct ldbg_engine* engine_o
 ldbg_status ldbg_image_lookup(const ldbg_image* im, const uint64_t* d_keys, int64_t n, int32_t* d_slots /* -1 = not in the image */, void* stream);
 ldbg_status ldbg_image_counters(const ldbg_image* im, int64_t* n_rows, int64_t* n_requests, int* overflow);   /* synchronises */
 /* TraversalEngine.walk over the image (ContigStopper; links bound to the shard graph).  begin: seeds (n x k ASCII, host) with the
- * image slots of their records (device, -1 = none; their rows are already in the image); round: d_stats (device, 2 x int64) =
- * {strands of this rank not done yet, requests filed}; finish: results as after ldbg_engine_walk_batch_run. */
+ * image slots of their records (device, -1 = none; their rows are already in the image); round: d_stats (device, 3 x int64) =
+ * {strands of this rank not done yet, requests filed, the image is full}; finish: results as after ldbg_engine_walk_batch_run.
+ * A full image never fills a request again: when the third value is set on any rank, every rank stops its rounds, enlarges its
+ * image and runs the batch again (begin drops a batch that was not finished). */
 ldbg_status ldbg_engine_sharded_walk_begin(struct ldbg_engine* e, ldbg_image* im, const char* seeds, int64_t n, const int32_t* d_seed_slot, void* stream);
 ldbg_status ldbg_engine_sharded_walk_round(struct ldbg_engine* e, int64_t* d_stats);
 ldbg_status ldbg_engine_sharded_walk_finish(struct ldbg_engine* e, int64_t* total_contig_bytes, int64_t* kmers_traversed);
 /* TraversalEngine.dfs(source, sinks...) over the image, any stopping rule that does not consult a ROI graph.  The library runs the
  * rounds and calls round_done(user) after each: the caller makes the round's exchange there (bucket, all-to-all, serve, all-to-all,
- * insert) and returns non-zero once no rank has a search in progress (d_stats as above).  d_seed_slot / d_sink_slot: image slots of the
+ * insert) and returns 1 once no rank has a search in progress, 2 to give the batch up on every rank (d_stats as above: a full image;
+ * the call then fails with LDBG_ERR_CAPACITY "IMAGE_FULL"), 0 otherwise.  d_seed_slot / d_sink_slot: image slots of the
  * sources' and sinks' records (-1 = none), their rows already in the image.  Capacity errors ("LINKSTORE_FULL", "LOG_FULL",
  * "DEPTH_OVERFLOW") enlarge the engine's stores: run the batch again on every rank.  Result: as ldbg_engine_dfs_batch; `rec` of a
  * vertex is its image slot (>= 0: the vertex has a record). */

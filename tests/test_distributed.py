@@ -22,6 +22,9 @@ def _free_port():
 
 def _init(rank, world, port):
     import torch.distributed as dist
+    if os.environ.get("LDBG_TEST_DUMP"):          # debugging aid: where is a rank that hangs?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LDBG_TEST_DUMP"]), exit=True)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -149,7 +152,7 @@ def test_replicas_two_ranks(orc, tmp_path):
     _spawn(_replica_worker, (cs.path, str(tmp_path / "rep.a.ctp.gz"), seeds, expected))
 
 
-def _sharded_walk_worker(rank, world, port, path, link_path, seeds, cfgs, expected):
+def _sharded_walk_worker(rank, world, port, path, link_path, seeds, cfgs, expected, image_rows=None):
     dist = _init(rank, world, port)
     try:
         from corticall_amd import CortexLinks
@@ -162,7 +165,7 @@ def _sharded_walk_worker(rank, world, port, path, link_path, seeds, cfgs, expect
         first, cnt = partition(len(seeds), rank, world)
         for ci, (trav, direction, op, max_len, with_links) in enumerate(cfgs):
             e = ShardedTraversalEngine(sg, trav, links=[links] if (with_links and links) else (), direction=direction, op=op,
-                                       max_branch_length=max_len, rows_per_owner=64 if ci % 2 else 4096, check_every=4)
+                                       max_branch_length=max_len, rows_per_owner=64 if ci % 2 else 4096, check_every=4, image_rows=image_rows)
             for rep in range(2):                                # the second batch starts from an empty image again
                 mine = e.walk_batch(seeds[first:first + cnt])
                 got = gather_strings(mine)
@@ -173,13 +176,15 @@ def _sharded_walk_worker(rank, world, port, path, link_path, seeds, cfgs, expect
                 dist.all_reduce(t)
                 assert int(t.item()) == expected[ci][1], (int(t.item()), expected[ci][1])
                 assert e.rounds > 0
+            if image_rows:       # the image was too small for the batch: it has grown (on every rank together), nobody hung, results unchanged
+                assert e.image_grown >= 1 and e.image_rows > image_rows
             e.close()
         sg.close()
     finally:
         dist.destroy_process_group()
 
 
-def _sharded_walk_case(orc, tmp_path, k, with_links, world=2):
+def _sharded_walk_case(orc, tmp_path, k, with_links, world=2, image_rows=None, n_cfgs=None):
     from tests import parity_cases as pc
     rng = random.Random(100 + k + (7 if with_links else 0))
     base = pc.genome_with_repeats(rng, 900, n_rep=5, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
@@ -207,7 +212,9 @@ def _sharded_walk_case(orc, tmp_path, k, with_links, world=2):
         it0 = oe.kmers_traversed()
         contigs = [oe.walk(s)[0] for s in seeds]
         expected.append((contigs, oe.kmers_traversed() - it0))
-    _spawn(_sharded_walk_worker, (path, link_path, seeds, cfgs, expected), world=world)
+    if n_cfgs:
+        cfgs, expected = cfgs[:n_cfgs], expected[:n_cfgs]
+    _spawn(_sharded_walk_worker, (path, link_path, seeds, cfgs, expected, image_rows), world=world)
 
 
 @pytest.mark.timeout(900)
@@ -231,7 +238,14 @@ def test_sharded_link_walks_three_ranks(orc, tmp_path):
     _sharded_walk_case(orc, tmp_path, 31, with_links=True, world=3)
 
 
-def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs, expected, roi_path=None, use=None):
+@pytest.mark.timeout(900)
+def test_sharded_walks_image_overflow_two_ranks(orc, tmp_path):
+    """an image that is too small for the batch: every rank sees the overflow flag in the same round (it travels in the all-reduced
+    round statistics), leaves the rounds, doubles its image and walks the batch again — no rank waits for a row that can never come"""
+    _sharded_walk_case(orc, tmp_path, 21, with_links=True, image_rows=40, n_cfgs=2)
+
+
+def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs, expected, roi_path=None, use=None, image_rows=None, poison=None):
     dist = _init(rank, world, port)
     try:
         import corticall_amd as ca
@@ -250,7 +264,17 @@ def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs
             e = ShardedTraversalEngine(sg, trav, links=[links] if (with_links and links) else (), direction=direction, max_branch_length=max_len,
                                        stopping_rule=stopper, rows_per_owner=64 if ci % 2 else 2048, check_every=4,
                                        rois=rois if stopper.startswith(("Novel", "Nahr", "BubbleOpening")) else None,
-                                       joining_colors=[1, 2] if stopper.startswith(("Novel", "Nahr", "BubbleOpening")) else ())
+                                       joining_colors=[1, 2] if stopper.startswith(("Novel", "Nahr", "BubbleOpening")) else (), image_rows=image_rows)
+            if poison is not None:
+                # ONE rank's batch holds a source the rule dereferences a missing record for (NullPointerException in the reference): that rank
+                # raises it, every other rank raises PeerRankFailed — nobody is left waiting in a collective — and the next batch runs as usual
+                from corticall_amd import _native
+                from corticall_amd.distributed import PeerRankFailed
+                bad_s = sources[first:first + cnt] + ([poison] if rank == 1 else [])
+                bad_k = sinks[first:first + cnt] + ([[]] if rank == 1 else [])
+                with pytest.raises(_native.JavaNullPointerException if rank == 1 else PeerRankFailed) as ei:
+                    e.dfs_batch(bad_s, bad_k)
+                assert "NullPointer" in str(ei.value) if rank == 1 else "peer rank failed" in str(ei.value), str(ei.value)
             got = e.dfs_batch(sources[first:first + cnt], sinks[first:first + cnt])
             for j, gi in enumerate(got):
                 exp = expected[ci][first + j]
@@ -266,6 +290,8 @@ def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs
             dist.all_reduce(t)
             assert int(t.item()) == expected[ci][-1], (cfgs[ci], int(t.item()), expected[ci][-1])
             assert e.rounds > 0
+            if image_rows:
+                assert e.image_grown >= 1 and e.image_rows > image_rows
             e.close()
         sg.close()
     finally:
@@ -273,8 +299,8 @@ def _sharded_dfs_worker(rank, world, port, path, link_path, sources, sinks, cfgs
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("k", [21, 32])
-def test_sharded_dfs_two_ranks(orc, tmp_path, k):
+@pytest.mark.parametrize("k,mode", [(21, "plain"), (32, "plain"), (21, "overflow"), (21, "poison")])
+def test_sharded_dfs_two_ranks(orc, tmp_path, k, mode):
     """dfs(source, sinks) with a stopping rule over the sharded table (TraversalEngine.java:64-106, 356-482): DestinationStopper towards a
     sink downstream (the gap-closing configuration, Call.java:759-779), ExplorationStopper, ContigStopper — graphs (vertices and edges in
     insertion order), toWalk/toContig of them, and the k-mers traversed against the oracle on the whole graph"""
@@ -327,4 +353,12 @@ def test_sharded_dfs_two_ranks(orc, tmp_path, k):
             r.free()
         per.append(oe.kmers_traversed() - it0)
         expected.append(per)
-    _spawn(_sharded_dfs_worker, (path, link_path, sources, sinks, cfgs, expected, roi_path, use))
+    if mode == "overflow":        # an image of 40 rows: the searches fill it, every rank gives the batch up in the same round, grows, runs it again
+        keep = [0, 2, 5]
+        _spawn(_sharded_dfs_worker, (path, link_path, sources, sinks, [cfgs[i] for i in keep], [expected[i] for i in keep], roi_path, [use[i] for i in keep], 40))
+    elif mode == "poison":        # a rank-local NullPointerException (a ROI rule on a source without a record) must fail the batch on every rank
+        keep = [7]
+        _spawn(_sharded_dfs_worker, (path, link_path, sources, sinks, [cfgs[i] for i in keep], [expected[i] for i in keep], roi_path, [use[i] for i in keep], None,
+                                     pc.rand_seq(random.Random(4242), k)))
+    else:
+        _spawn(_sharded_dfs_worker, (path, link_path, sources, sinks, cfgs, expected, roi_path, use))
