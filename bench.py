@@ -184,6 +184,26 @@ def bench_c2(args, ca, rank, local_rank, world, dist):
         per_launch = n if not args.sharded else n       # every rank's shard answers about n lookups per step
         achieved = per_launch * b_find / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         found = int((idx >= 0).sum().item()) if not args.sharded else int(g.find_batch(q)[0].sum())
+        cpu = parity = None
+        if not args.no_cpu_baseline:
+            # the reference's findRecord (ASCII 3-point binary search + 1 M-entry LRU, CortexGraph.java:272-317) restated in oracle/, one core,
+            # on a bounded sample of the same queries; its answers check the device's
+            from oracle import pyoracle as orc
+            og = orc.Graph(prefix + ".ctx", use_cache=True, tuned=False)
+            m = min(n, 200000)
+            t2 = time.time()
+            done = 0
+            ref = np.empty(0, dtype=np.int64)
+            while done < m and time.time() - t2 < args.cpu_seconds:
+                part = og.find_batch(q[done:done + 20000])
+                ref = np.concatenate([ref, part])
+                done += len(part)
+            dtc = time.time() - t2
+            cpu = {"value": done / dtc, "unit": "lookups/s", "cores": 1, "kind": "port",
+                   "sample": "the first %d of the step's %d queries in %.1f s, oracle in faithful mode (ASCII 3-point search + LRU)" % (done, n, dtc)}
+            if not args.sharded:
+                dev_idx = idx[:done].cpu().numpy()
+                parity = "%d/%d sampled lookups identical to the oracle's (record index, -1 = absent)" % (int((dev_idx == ref).sum()), done)
         print(json.dumps({
             "metric": "random-access lookups/sec (configs[1]; not the headline metric)", "value": world * n * args.steps / max_dt, "unit": "lookups/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
@@ -194,6 +214,7 @@ def bench_c2(args, ca, rank, local_rank, world, dist):
             "roofline": {"bound": "hbm", "kernel": "k_find<%d>" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_lookup": b_find,
                          "avg_launch_ms": avg_ms, "launches": launches},
+            "cpu_baseline": cpu, "parity": parity,
         }))
     if dist is not None:
         dist.barrier()
@@ -460,24 +481,62 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
             og = orc.Graph(prefix + ".ctx", use_cache=True, tuned=False)
             ol = orc.Links(prefix + ".ctp.gz")
             oe = orc.Engine(og, [0], links=[ol], stopper=args.stopper, max_length=args.max_len, direction=orc.FORWARD)
+            pick = np.random.default_rng(20261004).permutation(n)
             t1 = time.time()
             i = mism = 0
             while i < n and time.time() - t1 < args.cpu_seconds:
-                r = oe.dfs(seeds[i].tobytes().decode(), [sink[i].tobytes().decode()])
-                gi = b.graph(i)
+                j = int(pick[i])
+                r = oe.dfs(seeds[j].tobytes().decode(), [sink[j].tobytes().decode()])
+                gi = b.graph(j)
                 same = (gi is None) == r.is_null and (r.is_null or (gi.vertex_tuples() == r.vertices() and gi.edge_tuples() == r.edges()))
                 mism += 0 if same else 1
                 r.free()
                 i += 1
             dtc = time.time() - t1
             out["cpu_baseline"] = {"value": oe.kmers_traversed() / dtc, "unit": "k-mers traversed/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d seeds (%d k-mers traversed in %.1f s), oracle in faithful mode" % (i, oe.kmers_traversed(), dtc),
+                                   "sample": "%d searches drawn at random (seed 20261004) from the batch (%d k-mers traversed in %.1f s), oracle in faithful mode" % (i, oe.kmers_traversed(), dtc),
                                    "contigs_per_s": i / dtc}
             out["parity"] = "%d/%d sampled dfs graphs bit-exact vs oracle (vertices and edges in insertion order)" % (i - mism, i)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N without torchrun: N child processes, one per GPU, RCCL rendezvous on 127.0.0.1"""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    sys.exit(rc)
+
+
+# ---- byte model of the walk kernel (DESIGN.md §4 "What a step must move"): HBM bytes each kind of step REQUIRES, whatever the caches do
+WALK_STEP_BYTES = {
+    # run step: the two far fringe rows (2 x 64) + their run-index entries (2 x 8) + uo/ubase at the two positions (2 x 5) + three table
+    # probe rounds of four slots (y, z, the piece entry: 3 x 32) + five entries written (cv, t, piece, y, z: 5 x 8) + path: t, RUN head,
+    # payload, y (4 x 8)
+    "run": 2 * 64 + 2 * 8 + 2 * 5 + 3 * 32 + 5 * 8 + 4 * 8,
+    # lean step: the next row (64) + its run-index entry (8) + one probe round (32) + the seen mark and the visit count (2 x 8) + one path entry (8)
+    "lean": 64 + 8 + 32 + 2 * 8 + 8,
+    # general step: what a lean step moves, for the vertex it steps onto (its junction work is counted per link-store element and per choice)
+    "general": 64 + 8 + 32 + 2 * 8 + 8,
+    # a link-store element: its junction record (20) + the share of the record-range word of its k-mer (8); the store itself lives in LDS
+    "add": 20 + 8,
+    # a junction choice: the chosen child's row, run-index entry and probe round; junction bases are cached 8 per element (1 byte per 8 positions)
+    "choice": 64 + 8 + 32 + 1,
+}
 
 
 def main():
@@ -506,9 +565,15 @@ def main():
     ap.add_argument("--no-strict", action="store_true", help="experiment: CanonicalKmer.isFlipped by comparison (not Java-exact, Q6)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # asked for N GPUs but not started by a launcher: start one fresh child process per GPU (nothing in THIS process has touched
+        # the GPU yet), rank 0 prints the line; never run one rank and call it N
+        return spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree" % (args.gpus, world))
     import numpy as np
     import torch
     dist = None
@@ -564,7 +629,16 @@ def main():
     if args.workload == "c4":
         return bench_c4(args, ca, g, links, eng, seeds, st, prefix, rank, world, dist, sync, t_load)
 
-    for _ in range(args.warmup):
+    # the FIRST batch of an engine builds its run index (the records in unitig order): a caller that runs one batch per engine pays it
+    sync()
+    first_batch_ms = None
+    if args.warmup >= 1:
+        t_first = time.time()
+        eng.walk_batch_arrays(seeds, fetch=False)
+        sync()
+        first_batch_ms = (time.time() - t_first) * 1e3
+    run_index_ms, _ = ca.profile_get("run_index")
+    for _ in range(max(0, args.warmup - 1)):
         eng.walk_batch_arrays(seeds, fetch=False)
     ca.profile_reset()
     sync()
@@ -577,15 +651,24 @@ def main():
     dt = time.time() - t0
     walk_ms, walk_launches = ca.profile_get("walk")
     contig_ms, _ = ca.profile_get("contig")
+    kinds = {nm: ca.profile_get("walk_" + nm)[0] / max(1, walk_launches) for nm in
+             ("steps_run", "run_vertices", "steps_lean", "steps_general", "link_adds", "choices", "wave_iterations", "wave_general",
+              "busiest_general", "busiest_iterations", "wavefronts")}
     # the same steps with every contig downloaded to the caller (what the reference's walk() hands over): reported beside `value`
+    eng.walk_batch_arrays(seeds, fetch=True, pinned=True)        # (the page-locked arena is allocated once, like every other buffer of the engine)
     sync()
     t1 = time.time()
     fetched_bytes = 0
     for _ in range(args.steps):
-        arena, _, _ = eng.walk_batch_arrays(seeds, fetch=True)
+        arena, _, _ = eng.walk_batch_arrays(seeds, fetch=True, pinned=True)
         fetched_bytes += len(arena)
     sync()
     dt_fetch = time.time() - t1
+    t1 = time.time()
+    for _ in range(min(3, args.steps)):
+        eng.walk_batch_arrays(seeds, fetch=True)               # into a fresh pageable array: staged through page-locked buffers by the library
+    sync()
+    dt_fetch_pageable = (time.time() - t1) / min(3, args.steps)
 
     tot_trav, tot_seeds, max_dt = traversed, len(seeds) * args.steps, dt
     if dist is not None:
@@ -605,15 +688,24 @@ def main():
         per_launch_units = traversed / max(1, walk_launches)
         avg_ms = walk_ms / max(1, walk_launches)
         achieved = per_launch_units * (b_find + b_link) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC passes of tools/profile_walk.sh (FETCH_SIZE, WRITE_SIZE); only trusted when they were
-        # taken on this very build of the library
+        if run_index_ms == 0.0:
+            run_index_ms, _ = ca.profile_get("run_index")          # (--warmup 0: the build fell into the timed region)
+        # HBM bytes per launch from the PMC passes of tools/profile_walk.sh (FETCH_SIZE, WRITE_SIZE): reported only when they were taken on
+        # this very build of the library (the digest in ldbg_version), else null
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02_walk_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r03_walk_traffic.json")
         if os.path.exists(tf):
             tj = json.load(open(tf))
             if tj.get("library") == ca.default_lib().dll.ldbg_version().decode():
                 traffic = tj.get("hbm_bytes_per_launch")
         measured = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None
+        # the model: bytes the steps of THIS launch required (step-kind counters of the kernel x WALK_STEP_BYTES)
+        B = WALK_STEP_BYTES
+        model_bytes = (kinds["steps_run"] * B["run"] + kinds["steps_lean"] * B["lean"] + kinds["steps_general"] * B["general"]
+                       + kinds["link_adds"] * B["add"] + kinds["choices"] * B["choice"])
+        model_gbs = model_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        contig_bytes = 2.0 * eng.last_total_bytes               # k_contigs_rle: one byte read (ubase) and one written per contig base
+        contig_ms_step = contig_ms / max(1, args.steps)
         out = {
             "metric": "k-mers traversed/sec (whole node) + contigs/sec, k=47 3-color LdBG",
             "value": tot_trav / max_dt, "unit": "k-mers traversed/s", "contigs_per_s": tot_seeds / max_dt,
@@ -627,22 +719,44 @@ def main():
                 "records": N, "record_bytes": 8 * W + 5 * C, "link_kmers": links.numKmersWithLinks, "links": links.numLinks,
                 "seeds_per_gpu": len(seeds), "kmers_traversed_per_step": traversed // args.steps,
                 "multi_gpu": "replicated graph, seeds partitioned, no data-path collective" if world > 1 else "single GPU",
-                "load_seconds": round(t_load, 2),
+                "load_seconds": round(t_load, 2), "run_index_build_ms": run_index_ms, "first_batch_ms": first_batch_ms,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_walk<%d>" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_kmer": b_find + b_link, "avg_launch_ms": avg_ms, "launches": walk_launches,
-                "frac_b_find_only": per_launch_units * b_find / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
+                "bound": "hbm", "kernel": "k_walk<%d>" % W, "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": model_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "avg_launch_ms": avg_ms, "launches": walk_launches,
+                "model": {
+                    "bytes_per_launch": model_bytes, "bytes_per_step_kind": B,
+                    "per_launch": {"run_steps": kinds["steps_run"], "vertices_crossed_by_run_steps": kinds["run_vertices"], "lean_steps": kinds["steps_lean"],
+                                   "general_steps": kinds["steps_general"], "link_store_elements_added": kinds["link_adds"], "junction_choices": kinds["choices"]},
+                    "note": "achieved = sum over step kinds of (steps counted by the kernel in this run x HBM bytes that kind of step must move, "
+                            "DESIGN.md 4) / launch time: a bandwidth fraction of the kernel that runs (run index: an unbranched stretch is ONE step)",
+                },
+                "latency_bound": {
+                    "wavefronts": kinds["wavefronts"], "loop_iterations_avg": kinds["wave_iterations"] / max(1.0, kinds["wavefronts"]),
+                    "with_general_part_avg": kinds["wave_general"] / max(1.0, kinds["wavefronts"]),
+                    "busiest_wavefront_iterations": kinds["busiest_iterations"], "busiest_wavefront_with_general_part": kinds["busiest_general"],
+                    "us_per_iteration_of_the_busiest_wavefront": avg_ms * 1e3 / kinds["busiest_iterations"] if kinds["busiest_iterations"] else None,
+                    "note": "the launch lasts as long as its busiest wavefront: dependent steps x their latency, not bytes, bound it",
+                },
+                "frac_reference_algorithm": achieved / HBM_PEAK_GBS,
+                "reference_algorithm_note": "k-mers traversed x the REFERENCE's per-k-mer search bytes (SURVEY 8d: %d B) / launch time / peak: what a "
+                                            "k-mer-by-k-mer binary-search walk would have to sustain to match this launch; above 1 because the run index "
+                                            "removes those searches — a speed-up figure, NOT a bandwidth fraction" % (b_find + b_link),
                 "measured_gbs": measured, "measured_frac": measured / HBM_PEAK_GBS if measured else None,
-                "note": "achieved = k-mers traversed x the reference's per-k-mer search bytes (SURVEY 8d) / launch time: the run index "
-                        "(records in unitig order) crosses an unbranched stretch in one step, so the kernel no longer performs those "
-                        "searches and the algorithmic figure exceeds the HBM peak; measured_gbs is the kernel's real HBM traffic",
-                "contig_kernels_ms_per_step": contig_ms / max(1, args.steps),
+                "contig_kernel": {"kernel": "k_contigs_rle<%d>" % W, "ms_per_step": contig_ms_step, "bytes_per_step": contig_bytes,
+                                  "achieved": contig_bytes / (contig_ms_step * 1e-3) / 1e9 if contig_ms_step > 0 else None,
+                                  "frac": contig_bytes / (contig_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS if contig_ms_step > 0 else None},
+                "whole_step_floor": {"bytes": contig_bytes, "ms_at_peak": contig_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                                     "frac": contig_bytes / (HBM_PEAK_GBS * 1e9) / (max_dt / args.steps) if max_dt > 0 else None,
+                                     "note": "a step must at least read one base byte and write one contig byte per k-mer"},
             },
             "with_contigs_fetched": {"value": tot_trav / max_dt * dt / dt_fetch if dt_fetch > 0 else None, "ms_per_step": dt_fetch / args.steps * 1e3,
                                      "bytes_per_step": fetched_bytes // max(1, args.steps),
-                                     "note": "rank 0's steps again with all contigs copied to host memory (PCIe)"},
+                                     "note": "rank 0's steps again with all contigs downloaded into the engine's page-locked arena (ldbg_host_alloc): what a host "
+                                             "that reads the strings sees",
+                                     "pageable_ms_per_step": dt_fetch_pageable * 1e3,
+                                     "pageable_note": "the same into a fresh pageable array (staged through the library's page-locked buffers)"},
         }
         if not args.no_cpu_baseline:
             pick = np.random.default_rng(20261004).choice(len(seeds), min(2000, len(seeds)), replace=False)

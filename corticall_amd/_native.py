@@ -9,6 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libldbg.so")
+if os.environ.get("LDBG_DIAG_LIB") == "1":
+    # the same sources built with the walk kernel's timers compiled in (make -C corticall_amd/csrc diag): profiling sessions only (tools/)
+    LIB_PATH = os.path.join(_HERE, "_build_diag", "libldbg.so")
 
 LDBG_OK = 0
 STATUS_NAMES = {
@@ -68,7 +71,7 @@ EXPORTS = [
     "ldbg_engine_sharded_walk_begin", "ldbg_engine_sharded_walk_round", "ldbg_engine_sharded_walk_finish", "ldbg_engine_sharded_dfs_batch",
     "ldbg_links_open", "ldbg_links_close", "ldbg_links_index", "ldbg_links_source", "ldbg_links_info", "ldbg_links_sample_name", "ldbg_links_get",
     "ldbg_engine_config_default", "ldbg_engine_create", "ldbg_engine_destroy",
-    "ldbg_engine_walk_batch", "ldbg_engine_walk_batch_run", "ldbg_engine_walk_batch_fetch", "ldbg_engine_walk_vertices", "ldbg_engine_walk_roi_hits",
+    "ldbg_engine_walk_batch", "ldbg_engine_walk_batch_run", "ldbg_engine_walk_batch_fetch", "ldbg_host_alloc", "ldbg_host_free", "ldbg_engine_walk_vertices", "ldbg_engine_walk_roi_hits",
     "ldbg_engine_dfs_batch", "ldbg_dfs_result_sizes", "ldbg_dfs_result_get", "ldbg_dfs_result_walk", "ldbg_dfs_result_free",
     "ldbg_engine_dfs_kmers_traversed",
     "ldbg_engine_seek", "ldbg_engine_has_next", "ldbg_engine_has_previous", "ldbg_engine_next", "ldbg_engine_previous",

@@ -382,6 +382,10 @@ ldbg_status ldbg_engine_walk_batch_run(ldbg_engine* e, const char* seeds, int64_
         }
     });
 }
+ldbg_status ldbg_host_alloc(int64_t bytes, void** out) {
+    return guard([&] { *out = nullptr; if (bytes < 0) throw StatusError(LDBG_ERR_ARG, "ldbg_host_alloc: negative size"); *out = rt::hmalloc_pinned((size_t)bytes); });
+}
+ldbg_status ldbg_host_free(void* p) { return guard([&] { rt::hfree_pinned(p); }); }
 ldbg_status ldbg_engine_walk_batch_fetch(ldbg_engine* e, char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len) {
     return guard([&] { e->e.walk_batch_fetch(arena, cap, offsets, walk_len); });
 }

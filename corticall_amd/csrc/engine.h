@@ -590,6 +590,7 @@ struct StepPre {
     bool choice_ok;
     unsigned ch;
     bool has_child;
+    uint16_t n_added;    // link-store elements the cooperative phase added for this lane (step-kind counters of the walk kernel)
     Node child;          // the single successor of the vertex stepped onto, located ahead of the link-store phases
 };
 // next()/previous() (TraversalEngine.java:241-319); requires cu.has.  Returns the vertex stepped onto.

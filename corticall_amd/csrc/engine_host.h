@@ -143,6 +143,8 @@ private:
     void ensure_run_index();           // the run index of this engine's colour masks (runs.h), built on first use
     void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks, uint64_t table_floor = 0);   // table_floor: entries the table pool holds at least
     uint64_t table_floor_ = 0;
+    void* h_stage_[2] = {nullptr, nullptr};              // page-locked staging buffers of downloads into pageable memory (walk.cpp: download)
+    void download(char* dst, const void* d_src, size_t bytes);
     uint64_t* h_log_ = nullptr; size_t h_log_cap_ = 0;   // page-locked landing buffer of the dfs logs (dfs.cpp)
     void release_scratch();
     // result buffers of a cleared batch are kept for the next one: allocating and freeing GBs costs milliseconds per batch

@@ -43,15 +43,14 @@ LDBG_DEV void lsw_store_header(LinkStoreDev& s, const LsHdr& h) {
     s.n = h.n; s.java_cap = h.java_cap; s.nkeys = h.nkeys; s.next_seq = h.next_seq; s.age = h.age; s.n_new = h.n_new; s.overflow = h.overflow;
 }
 
-// what an owner lane fetched for its add before the wavefront turns to it (all owners fetch at once)
-struct AddPre { uint32_t jlo, jhi; JuncRec r0, r1; };
-LDBG_DEV AddPre add_prefetch(const LinksView& Lk, uint64_t m) {      // m = rec_of entry: first | count << 32
-    AddPre p;
-    p.jlo = (uint32_t)m; p.jhi = (uint32_t)m + (uint32_t)(m >> 32);
-    p.r0 = Lk.junc[p.jlo];
-    p.r1 = Lk.junc[p.jlo + 1 < p.jhi ? p.jlo + 1 : p.jlo];
-    return p;
-}
+// The junction records an add needs are fetched by the WHOLE wavefront in one load before the cooperative phase: the records of all
+// owners of this iteration are dealt out to consecutive lanes (owner after owner, `start` = the lane that holds an owner's first
+// record); the add then reads them out of the lanes' registers.  (Fetched record by record inside the add — the owner lane had only
+// the first two — every further record was a dependent trip to memory that 63 lanes waited for: 1.6 us per owner, half of a general
+// step, profiles/r03_walk_general_split.log.)  Records that find no lane (more than a wavefront's worth in one iteration) are read
+// from memory as before.
+#define LDBG_NOT_GATHERED 0xFFFFFFFFu
+struct AddPre { uint32_t jlo, jhi, start; };
 LDBG_DEV JuncRec bcast_junc(const JuncRec& r, int L) {
     JuncRec o;
     o.str_off = wave_bcast_u32(r.str_off, L); o.len = wave_bcast_u32(r.len, L);
@@ -59,18 +58,12 @@ LDBG_DEV JuncRec bcast_junc(const JuncRec& r, int L) {
     o.is_fw = wave_bcast_u32(r.is_fw, L);
     return o;
 }
-LDBG_DEV AddPre bcast_addpre(const AddPre& p, int L) {
-    AddPre o;
-    o.jlo = wave_bcast_u32(p.jlo, L); o.jhi = wave_bcast_u32(p.jhi, L);
-    o.r0 = bcast_junc(p.r0, L); o.r1 = bcast_junc(p.r1, L);
-    return o;
-}
 
 // LinkStore.add (:17-35) of a merged link record (junction records [pre.jlo, pre.jhi)) into the owner's store
-LDBG_DEV void coop_add(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, const AddPre& pre, bool query_flipped, bool fwd) {
+LDBG_DEV void coop_add(const LinksView& Lk, const LsWave& v, int L, LsHdr& h, const AddPre& pre, const JuncRec& gathered, bool query_flipped, bool fwd) {
     const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
     for (uint32_t j = pre.jlo; j < pre.jhi; j++) {
-        const JuncRec jr = j == pre.jlo ? pre.r0 : (j == pre.jlo + 1 ? pre.r1 : Lk.junc[j]);
+        const JuncRec jr = pre.start != LDBG_NOT_GATHERED ? bcast_junc(gathered, (int)(pre.start + (j - pre.jlo))) : Lk.junc[j];
         const bool lgf = ((jr.is_fw & 1u) != 0) != query_flipped;     // recordOrientationMatchesKmer == cjr.isForward() :24
         if (lgf != fwd) continue;
         LsElem x;
@@ -243,11 +236,162 @@ LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHd
     return true;
 }
 
+// ---- FOUR owners at a time.  The cooperative operations above give one owner all 64 lanes, yet a link store rarely holds more
+// than a dozen elements: 48 lanes idle while the other owners of the iteration wait their turn (4.9 owners of adds and 2.7 of
+// choices per general iteration at C3: 8 of its 14 us, profiles/r03_walk_general_split.log).  Here the wavefront works as four GROUPS
+// of 16 lanes, each group carrying out one owner's operation — same instruction stream, per-group data: ballots are cut into
+// 16-bit group masks, broadcasts are lane permutes (ds_bpermute) from a per-group source lane, the owner's header travels to
+// its group and back the same way.  An owner qualifies when its store (after the adds) fits one element per lane of a group
+// and all its junction records were gathered; the others take the whole-wavefront path as before.  Semantics: those of
+// coop_add / the one-element-per-lane branch of coop_next_choice, statement by statement.
+#ifndef LDBG_HOSTSIM
+#define LDBG_GS 16u
+LDBG_DEV uint32_t grp_shfl(uint32_t v, uint32_t src_lane) { return (uint32_t)__shfl((int)v, (int)(src_lane & 63u), 64); }
+LDBG_DEV uint32_t grp_mask(unsigned long long ballot, uint32_t g) { return (uint32_t)(ballot >> (LDBG_GS * g)) & 0xFFFFu; }
+struct GrpTake { uint32_t myL; bool gv; int myq; };
+// the next (up to) four owners of `todo` (wave-uniform): which owner this lane's group works for, and — for an owner lane of this
+// batch — the group that works for it (myq, else -1)
+LDBG_DEV GrpTake grp_take(unsigned long long& todo) {
+    const uint32_t lane = (uint32_t)wave_lane(), g = lane >> 4;
+    GrpTake t;
+    t.myL = 0; t.gv = false; t.myq = -1;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        if (!todo) break;
+        const int L = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (g == q) { t.myL = (uint32_t)L; t.gv = true; }
+        if ((int)lane == L) t.myq = (int)q;
+    }
+    return t;
+}
+
+LDBG_DEV void group_adds(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls, unsigned long long todo, uint64_t m_cur, uint64_t m_nxt,
+                         uint32_t start_cur, uint32_t start_nxt, uint32_t flags, const JuncRec& gathered, StepPre& pre) {
+    const uint32_t lane = (uint32_t)wave_lane(), g = lane >> 4, sub = lane & 15u;
+    while (todo) {
+        const GrpTake t = grp_take(todo);
+        uint32_t n = grp_shfl(ls.n, t.myL), java_cap = grp_shfl(ls.java_cap, t.myL), nkeys = grp_shfl(ls.nkeys, t.myL), next_seq = grp_shfl(ls.next_seq, t.myL);
+        uint32_t n_new = grp_shfl(ls.n_new, t.myL);
+        const uint32_t age = grp_shfl(ls.age, t.myL), cap = grp_shfl(ls.cap, t.myL);
+        const uint32_t cnt_cur = grp_shfl(m_cur == ~0ull ? 0u : (uint32_t)(m_cur >> 32), t.myL), cnt_nxt = grp_shfl(m_nxt == ~0ull ? 0u : (uint32_t)(m_nxt >> 32), t.myL);
+        const uint32_t sc = grp_shfl(start_cur, t.myL), sn = grp_shfl(start_nxt, t.myL), fl = grp_shfl(flags, t.myL);
+        const uint32_t R = t.gv ? cnt_cur + cnt_nxt : 0u;
+        uint32_t maxR = wave_bcast_u32(R, 0);
+        { const uint32_t r1 = wave_bcast_u32(R, 16), r2 = wave_bcast_u32(R, 32), r3 = wave_bcast_u32(R, 48); maxR = maxR > r1 ? maxR : r1; maxR = maxR > r2 ? maxR : r2; maxR = maxR > r3 ? maxR : r3; }
+        LsElem y;
+        y.str_off = 0; y.birth = 0; y.hash = 0; y.key_seq = 0; y.len = 0; y.pos = 0; y.comp = 0; y.nxn = 0; y.nx = 0;
+        if (t.gv && sub < n) y = lsw_get(v, (int)t.myL, sub);
+        bool ovf = false;
+        const bool fwd = (fl & 4u) != 0;
+        for (uint32_t r = 0; r < maxR; r++) {
+            const bool in_cur = r < cnt_cur;
+            const uint32_t src = in_cur ? sc + r : sn + (r - cnt_cur);
+            JuncRec jr;
+            jr.str_off = grp_shfl(gathered.str_off, src); jr.len = grp_shfl(gathered.len, src);
+            jr.hash_asis = (int32_t)grp_shfl((uint32_t)gathered.hash_asis, src); jr.hash_comp = (int32_t)grp_shfl((uint32_t)gathered.hash_comp, src);
+            jr.is_fw = grp_shfl(gathered.is_fw, src);
+            const bool qf = in_cur ? (fl & 1u) != 0 : (fl & 2u) != 0;
+            const bool lgf = ((jr.is_fw & 1u) != 0) != qf;                        // :24
+            const bool use = t.gv && r < R && !ovf && lgf == fwd;
+            LsElem x;
+            x.str_off = jr.str_off; x.birth = age; x.hash = lgf ? jr.hash_asis : jr.hash_comp;
+            x.len = (uint16_t)jr.len; x.pos = 0; x.comp = lgf ? 0 : 1; x.key_seq = 0;
+            ls_first_nx(jr, x);
+            const bool match = use && sub < n && ls_same_string(Lk, y, x);
+            const uint32_t gm = grp_mask(wave_ballot(match), g);
+            const uint32_t top = gm ? 31u - (uint32_t)__builtin_clz(gm) : 0u;        // the newest element filed under the same junction string
+            const uint32_t ks = grp_shfl(y.key_seq, (g << 4) + top);
+            if (use) {
+                if (gm) x.key_seq = ks;
+                else {
+                    x.key_seq = next_seq++;
+                    nkeys++;
+                    if (java_cap == 0) java_cap = 16;
+                    if (nkeys > java_cap * 3 / 4) java_cap *= 2;
+                }
+                if (n >= cap || jr.len >= 65535u || n >= 0x7FFFu) ovf = true;
+                else {
+                    if (sub == n) { y = x; lsw_set(v, (int)t.myL, n, x); }
+                    n++; n_new++;
+                }
+            }
+        }
+        wave_fence();
+        // the headers go back to their owners
+        const uint32_t back = t.myq >= 0 ? (uint32_t)t.myq << 4 : lane;
+        const uint32_t rn = grp_shfl(n, back), rcap = grp_shfl(java_cap, back), rkeys = grp_shfl(nkeys, back), rseq = grp_shfl(next_seq, back), rnew = grp_shfl(n_new, back);
+        const uint32_t rovf = grp_shfl(ovf ? 1u : 0u, back);
+        if (t.myq >= 0) {
+            pre.n_added = (uint16_t)(rn - ls.n);
+            ls.n = rn; ls.java_cap = rcap; ls.nkeys = rkeys; ls.next_seq = rseq; ls.n_new = rnew; ls.overflow = ls.overflow || rovf != 0u;
+        }
+    }
+}
+
+// getNextJunctionChoice for (up to) four owners at once; every owner in `todo` has 1 <= n <= 16 elements
+LDBG_DEV void group_choices(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls, unsigned long long todo, StepPre& pre) {
+    const uint32_t lane = (uint32_t)wave_lane(), g = lane >> 4, sub = lane & 15u;
+    while (todo) {
+        const GrpTake t = grp_take(todo);
+        const uint32_t n = grp_shfl(ls.n, t.myL), java_cap = grp_shfl(ls.java_cap, t.myL), age = grp_shfl(ls.age, t.myL);
+        uint32_t nkeys = grp_shfl(ls.nkeys, t.myL);
+        const bool valid = t.gv && sub < n;
+        LsElem x;
+        x.str_off = 0; x.birth = 0; x.hash = 0; x.key_seq = 0; x.len = 0; x.pos = 0; x.comp = 0; x.nxn = 0; x.nx = 0;
+        if (valid) x = lsw_get(v, (int)t.myL, sub);
+        const uint32_t minbirth0 = grp_shfl(x.birth, g << 4);                    // births never decrease along the array: element 0 is among the oldest
+        const unsigned c = ls_cur(x);
+        const unsigned c0 = grp_shfl(c, g << 4);
+        const bool old = valid && x.birth == minbirth0;
+        const bool ok = t.gv && grp_mask(wave_ballot(old && c != c0), g) == 0u;  // the oldest links must agree (:92-119)
+        // first of the oldest links in HashMap iteration order (bucket, key insertion order): minimum over the group
+        const uint32_t hh = (uint32_t)x.hash;
+        uint64_t best = old ? (((uint64_t)((hh ^ (hh >> 16)) & (java_cap - 1u)) << 32) | x.key_seq) : ~0ull;
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, m, 16), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), m, 16);
+            const uint64_t o = ((uint64_t)hi << 32) | lo;
+            best = o < best ? o : best;
+        }
+        const uint32_t seq1 = (uint32_t)best;
+        const uint32_t kbm = grp_mask(wave_ballot(valid && x.key_seq == seq1), g);       // the last element filed under that key supplies the choice (:129-133)
+        const unsigned ch1 = grp_shfl(c, (g << 4) + (kbm ? 31u - (uint32_t)__builtin_clz(kbm) : 0u));
+        const bool keep = valid && lsw_keeps(x, ch1);
+        // keys whose last element expires leave the HashMap (:84-88)
+        const unsigned long long deadb = wave_ballot(ok && valid && !keep);
+        const uint32_t dead_g = grp_mask(deadb, g);
+        uint32_t any = (uint32_t)((deadb | (deadb >> 16) | (deadb >> 32) | (deadb >> 48)) & 0xFFFFull);
+        while (any) {
+            const uint32_t sd = (uint32_t)__builtin_ctz(any);
+            any &= any - 1u;
+            const uint32_t ks = grp_shfl(x.key_seq, (g << 4) + sd);
+            const bool hit = valid && x.key_seq == ks && sub != sd && (sub < sd || keep);
+            const uint32_t hm = grp_mask(wave_ballot(hit), g);
+            if (((dead_g >> sd) & 1u) && hm == 0u) nkeys--;
+        }
+        LsElem xa = x;
+        if (ok && keep) ls_advance(Lk, xa);
+        const uint32_t kb = grp_mask(wave_ballot(ok && keep), g);
+        if (ok && keep) lsw_set(v, (int)t.myL, (uint32_t)__builtin_popcount(kb & ((1u << sub) - 1u)), xa);
+        const uint32_t nn = grp_mask(wave_ballot(ok && keep && x.birth == age), g);
+        wave_fence();
+        const uint32_t back = t.myq >= 0 ? (uint32_t)t.myq << 4 : lane;
+        const uint32_t rok = grp_shfl(ok ? 1u : 0u, back), rch = grp_shfl(ch1, back), rkeys = grp_shfl(nkeys, back);
+        const uint32_t rn = grp_shfl((uint32_t)__builtin_popcount(kb), back), rnew = grp_shfl((uint32_t)__builtin_popcount(nn), back);
+        if (t.myq >= 0) {
+            pre.choice_done = true; pre.choice_ok = rok != 0u; pre.ch = rch;
+            if (rok) { ls.n = rn; ls.n_new = rnew; ls.nkeys = rkeys; }
+        }
+    }
+}
+#endif
+
 // The link-store part of one cursor step (TraversalEngine.java:241-276) for every lane of the wavefront that is in cursor
 // mode: per-lane prefetch, cooperative adds, cooperative junction choices.  `pre` then carries the results into
 // cursor_step<W, true>.  Every lane of the wavefront must call this (cur_mode false where it does not apply).
 template <int W>
-LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreDev& ls, const LsWave& lw, bool cur_mode, StepPre& pre) {
+LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreDev& ls, const LsWave& lw, bool cur_mode, StepPre& pre, unsigned long long* tdiag = nullptr) {
     // Two independent chains of dependent loads start here: (links) rec_of -> offsets -> junction records of the
     // vertex about to be stepped onto, and (graph) its neighbour pointer -> the next row + its table slot.  They are
     // issued stage by stage so that they overlap.
@@ -259,28 +403,79 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
     if (flagged) m_nxt = e.links.rec_of[st.cu.nxt.idx];
     if (one_child) child_ent = st.cu.nxt.e1 ? st.cu.nxt.ent1 : node_child_entry(e, st.cu.nxt, st.fwd, lowbit4(nmask));
     if (cur_mode && st.cu.first && (st.cu.cur.lflags & e.link_flag_mask)) m_cur = e.links.rec_of[st.cu.cur.idx];
-    AddPre ap_cur, ap_nxt;      // read only by the lanes that filled them (the flags below say which)
-    if (m_nxt != ~0ull) { ap_nxt.jlo = (uint32_t)m_nxt; ap_nxt.jhi = (uint32_t)m_nxt + (uint32_t)(m_nxt >> 32); }
+    pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0; pre.n_added = 0;
+    // deal the owners' junction records out to the lanes (cur's records first, then nxt's: the order of the adds), one load for all
+    const unsigned long long owners = wave_ballot(m_cur != ~0ull || m_nxt != ~0ull);
+    uint32_t start_cur = LDBG_NOT_GATHERED, start_nxt = LDBG_NOT_GATHERED, my_j = LDBG_NOT_GATHERED;
+    {
+        const uint32_t lane = (uint32_t)wave_lane(), WS = (uint32_t)wave_size();
+        uint32_t base = 0;
+        for (unsigned long long ob = owners; ob; ob &= ob - 1) {
+            const int L = __builtin_ctzll(ob);
+#pragma unroll
+            for (int which = 0; which < 2; which++) {
+                const uint64_t m = wave_bcast_u64(which == 0 ? m_cur : m_nxt, L);
+                if (m == ~0ull) continue;
+                const uint32_t jlo = (uint32_t)m, cnt = (uint32_t)(m >> 32);
+                if (base + cnt > WS) continue;                       // (no lanes left: these records are read inside the add)
+                if (lane >= base && lane < base + cnt) my_j = jlo + (lane - base);
+                if ((int)lane == L) { if (which == 0) start_cur = base; else start_nxt = base; }
+                base += cnt;
+            }
+        }
+    }
+    JuncRec gathered;
+    gathered.str_off = 0; gathered.len = 0; gathered.hash_asis = 0; gathered.hash_comp = 0; gathered.is_fw = 0;
+    if (my_j != LDBG_NOT_GATHERED) gathered = e.links.junc[my_j];
+    // (the graph chain goes on while the records are on their way)
     pre.has_child = one_child;
     if (one_child) node_from_entry(e, st.vt, st.cu.nxt, child_ent, lowbit4(nmask), st.fwd, pre.child);
-    if (m_nxt != ~0ull) {
-        ap_nxt.r0 = e.links.junc[ap_nxt.jlo];
-        ap_nxt.r1 = e.links.junc[ap_nxt.jlo + 1 < ap_nxt.jhi ? ap_nxt.jlo + 1 : ap_nxt.jlo];
+    unsigned long long need = owners;
+#ifdef LDBG_WALK_DIAG
+    if (tdiag) { tdiag[0] = __builtin_amdgcn_s_memrealtime(); tdiag[2] = (unsigned long long)__builtin_popcountll(need); }
+#endif
+#ifndef LDBG_HOSTSIM
+    if (wave_size() == 64 && lw.fast_cap >= LDBG_GS) {
+        // owners whose store, with everything this step may add, is one element per lane of a 16-lane group: four of them at a time
+        const uint32_t r_cur = m_cur == ~0ull ? 0u : (uint32_t)(m_cur >> 32), r_nxt = m_nxt == ~0ull ? 0u : (uint32_t)(m_nxt >> 32);
+        const bool mine = (m_cur != ~0ull || m_nxt != ~0ull) && !ls.overflow && ls.n + r_cur + r_nxt <= LDBG_GS &&
+                          (m_cur == ~0ull || start_cur != LDBG_NOT_GATHERED) && (m_nxt == ~0ull || start_nxt != LDBG_NOT_GATHERED);
+        const unsigned long long grouped = wave_ballot(mine);
+        if (grouped) {
+            const uint32_t flags = (st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u);
+            group_adds(e.links, lw, ls, grouped, m_cur, m_nxt, start_cur, start_nxt, flags, gathered, pre);
+            need &= ~grouped;
+        }
     }
-    if (m_cur != ~0ull) ap_cur = add_prefetch(e.links, m_cur);
-    pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0;
-    unsigned long long need = wave_ballot(m_cur != ~0ull || m_nxt != ~0ull);
+#endif
     while (need) {
         const int L = __builtin_ctzll(need);
         need &= need - 1;
         LsHdr h = lsw_header(ls, L);
         const uint32_t flags = wave_bcast_u32((st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u) |
                                               (m_cur != ~0ull ? 8u : 0u) | (m_nxt != ~0ull ? 16u : 0u), L);
-        if (flags & 8u) coop_add(e.links, lw, L, h, bcast_addpre(ap_cur, L), (flags & 1u) != 0, (flags & 4u) != 0);
-        if ((flags & 16u) && !h.overflow) coop_add(e.links, lw, L, h, bcast_addpre(ap_nxt, L), (flags & 2u) != 0, (flags & 4u) != 0);
-        if (wave_lane() == L) lsw_store_header(ls, h);
+        if (flags & 8u) {
+            const uint64_t m = wave_bcast_u64(m_cur, L);
+            const AddPre ap{(uint32_t)m, (uint32_t)m + (uint32_t)(m >> 32), wave_bcast_u32(start_cur, L)};
+            coop_add(e.links, lw, L, h, ap, gathered, (flags & 1u) != 0, (flags & 4u) != 0);
+        }
+        if ((flags & 16u) && !h.overflow) {
+            const uint64_t m = wave_bcast_u64(m_nxt, L);
+            const AddPre ap{(uint32_t)m, (uint32_t)m + (uint32_t)(m >> 32), wave_bcast_u32(start_nxt, L)};
+            coop_add(e.links, lw, L, h, ap, gathered, (flags & 2u) != 0, (flags & 4u) != 0);
+        }
+        if (wave_lane() == L) { pre.n_added = (uint16_t)(h.n - ls.n); lsw_store_header(ls, h); }
     }
     need = wave_ballot(cur_mode && popc4(nmask) > 1);
+#ifdef LDBG_WALK_DIAG
+    if (tdiag) { tdiag[1] = __builtin_amdgcn_s_memrealtime(); tdiag[2] |= (unsigned long long)__builtin_popcountll(need) << 32; }
+#endif
+#ifndef LDBG_HOSTSIM
+    if (wave_size() == 64 && lw.fast_cap >= LDBG_GS) {
+        const unsigned long long grouped = wave_ballot(cur_mode && popc4(nmask) > 1 && ls.n >= 1u && ls.n <= LDBG_GS);
+        if (grouped) { group_choices(e.links, lw, ls, grouped, pre); need &= ~grouped; }
+    }
+#endif
     while (need) {                                    // junction choices (:266-272)
         const int L = __builtin_ctzll(need);
         need &= need - 1;

@@ -57,6 +57,12 @@ inline void* dmalloc(size_t n) { void* p = nullptr; check(hipMalloc(&p, n ? n : 
 inline void dfree(void* p) { if (p) (void)hipFree(p); }
 inline void* hmalloc_pinned(size_t n) { void* p = nullptr; check(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault), "hipHostMalloc"); return p; }
 inline void hfree_pinned(void* p) { if (p) (void)hipHostFree(p); }
+// is p page-locked host memory the runtime knows (ldbg_host_alloc, hipHostMalloc, hipHostRegister)?  Copies to it run at the bus rate.
+inline bool host_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
 typedef hipStream_t stream_t;
 inline stream_t stream_create() { hipStream_t s; check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); return s; }
 inline void stream_destroy(stream_t s) { if (s) (void)hipStreamDestroy(s); }
@@ -77,6 +83,7 @@ struct Event {
     Event(const Event&) = delete;
     Event& operator=(const Event&) = delete;
     void record(stream_t s) { check(hipEventRecord(e, s), "hipEventRecord"); }
+    void wait() { check(hipEventSynchronize(e), "hipEventSynchronize"); }
     static float elapsed_ms(Event& a, Event& b) {
         check(hipEventSynchronize(b.e), "hipEventSynchronize");
         float ms = 0;
@@ -154,6 +161,7 @@ inline void* dmalloc(size_t n) { return calloc(n ? n : 1, 1); }
 inline void dfree(void* p) { free(p); }
 inline void* hmalloc_pinned(size_t n) { return malloc(n ? n : 1); }
 inline void hfree_pinned(void* p) { free(p); }
+inline bool host_is_pinned(const void*) { return getenv("LDBG_HOSTSIM_PAGEABLE") == nullptr; }     // (the test hook sends copies through the staging path)
 typedef void* stream_t;
 inline stream_t stream_create() { return nullptr; }
 inline void stream_destroy(stream_t) {}
@@ -169,6 +177,7 @@ inline void mem_info(size_t* free_b, size_t* total_b) {      // LDBG_HOSTSIM_MEM
 }
 struct Event {
     void record(stream_t) {}
+    void wait() {}
     static float elapsed_ms(Event&, Event&) { return 0.0f; }
 };
 }  // namespace rt

@@ -49,7 +49,9 @@ struct WalkArgs {
     const int32_t* seed_slot;  // [n] image slot of each seed's record (-1 = the seed has no record); the rows are in the image before the first round
     struct StrandSave* save;   // [n_slots] the strand a lane is working on, kept from one bulk-synchronous round to the next
     unsigned long long* unfinished;   // strands that were still in progress when the round's launch ended
-    unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES): [n_wg][2] start / end of every workgroup (100 MHz clock)
+    unsigned long long* kinds;      // walk kernel, or nullptr: [0] run steps [1] vertices they crossed [2] lean steps [3] general steps [4] link-store elements added
+                                    // [5] junction choices [6] wavefront loop iterations [7] those with a general part [8] the busiest wavefront's (general << 32 | iterations)
+    unsigned long long* wg_times;   // diagnostics (LDBG_WG_TIMES; timers exist in the -DLDBG_WALK_DIAG build only): [n_wg][2] start / end of every workgroup (100 MHz clock)
     unsigned long long* st_times;   // diagnostics: [n_strands][2] begin / finish of every strand
     unsigned long long* st_gen;     // diagnostics: [n_strands][2] ticks spent before general steps (prepare + cooperative phases), their number
     uint32_t yield_iters;           // over an image: loop iterations after which a wavefront ends its launch (0 = never): a bulk-synchronous round lasts as long as its
@@ -166,7 +168,7 @@ LDBG_DEV void strand_finish(const WalkArgs& a, StrandState& st) {
     a.status[st.s] = st.status != ST_OK ? st.status : (st.branch_null ? (uint32_t)ST_BRANCH_NULL : (uint32_t)ST_OK);
     a.iters[st.s] = st.iters;
     a.quirk[st.s] = st.quirk ? 1 : 0;
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
     if (a.st_times) a.st_times[2 * st.s + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
@@ -188,7 +190,7 @@ template <int W>
 LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, int64_t s) {
     const EngineView& e = a.e;
     st.s = s;
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
     if (a.st_times) a.st_times[2 * s] = __builtin_amdgcn_s_memrealtime();
 #endif
     st.fwd = (s & 1) != 0;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <numeric>
+#include <thread>
 
 #include "lscoop.h"
 #include "runs.h"
@@ -117,9 +118,12 @@ template <int W, int BS, bool IMG>
 LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     const int64_t slot = global_tid();
     if (slot >= a.n_slots) return;
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
     if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
+    // step-kind counters of this lane over all its strands (summed per wavefront when it ends: ldbg_profile_get "walk_steps_*" — the
+    // inputs of the byte model in DESIGN.md / bench.py), and this wavefront's loop iterations with a general part
+    uint32_t kc_run = 0, kc_runv = 0, kc_lean = 0, kc_gen = 0, kc_add = 0, kc_choice = 0, wave_general = 0;
     // link store: the first LDBG_LS_FAST elements of every lane live in LDS ([element][lane]), the rest in HBM
 #ifndef LDBG_HOSTSIM
     __shared__ LsElem lds_store[LDBG_LS_FAST * BS];
@@ -158,7 +162,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             active = true; begun = sv.begun != 0;
         }
     }
-    unsigned long long wave_iterations = 0;
+    uint32_t wave_iterations = 0;
     // all lanes of a wavefront stay in the loop until every one of them has run out of strands: the table
     // regrowth below is a wave-wide operation
     while (wave_ballot((active && !suspended) || (!active && !exhausted)) != 0ull) {
@@ -212,12 +216,12 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             }
         }
         const bool running = active && begun && !suspended;
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
         unsigned long long tc0 = 0;
         if (a.wave_cat) tc0 = __builtin_amdgcn_s_memrealtime();
 #endif
         wave_grow_tables(a, st, running);
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
         unsigned long long tc1 = 0;
         if (a.wave_cat) tc1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -228,10 +232,13 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             const bool mb = !ma && run_mode_b(a, st, rs);
             if (ma || mb) {
                 stepped = true;
-                if (run_step<W>(a, st, ls, rs, ma)) { walk_finish(a, st); active = false; }
+                const uint32_t it0 = st.iters;
+                const bool ended = run_step<W>(a, st, ls, rs, ma);
+                kc_run++; kc_runv += st.iters - it0;
+                if (ended) { walk_finish(a, st); active = false; }
             }
         }
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
         unsigned long long tc2 = 0;
         if (a.wave_cat) tc2 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -243,22 +250,23 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             const uint32_t used0 = st.vt.used;
 #pragma unroll 1
             do { lean_step<W>(a, st, ls, rs); } while (++r < a.lean_run && lean_again(a, st, rs));     // one copy of the step: the loop lives in the instruction cache
+            kc_lean += (uint32_t)r;
             rs.seen_marks += st.vt.used - used0;
             st.cu.cur = st.cv;                         // the cursor stands on the walk's current vertex
         }
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
         if (a.wave_cat && threadIdx.x == 0) {
             const unsigned long long tc3 = __builtin_amdgcn_s_memrealtime();
-            unsigned long long* wc = a.wave_cat + 8 * blockIdx.x;
+            unsigned long long* wc = a.wave_cat + 16 * blockIdx.x;
             wc[0] += 1; wc[1] += tc1 - tc0; wc[2] += tc2 - tc1; wc[3] += tc3 - tc2;
         }
 #endif
-        if (wave_ballot(running && active && !lean && !stepped) == 0ull) continue;          // the whole wavefront took a lean or a run step (or waits for rows)
-#ifndef LDBG_HOSTSIM
-        unsigned long long tc4 = 0;
+        const unsigned long long general_lanes = wave_ballot(running && active && !lean && !stepped);
+        if (general_lanes == 0ull) continue;          // the whole wavefront took a lean or a run step (or waits for rows)
+        wave_general++;
+#ifdef LDBG_WALK_DIAG
+        unsigned long long tc4 = 0, tprep[3] = {0, 0, 0};
         if (a.wave_cat) tc4 = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifndef LDBG_HOSTSIM
         const unsigned long long t_general = a.st_gen ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
@@ -266,21 +274,32 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
         const bool cur_mode = general && st.status == ST_OK && a.e.cursor_on && st.cu.has;
         StepPre pre;
         const uint32_t used1 = st.vt.used;
-        coop_step_prepare<W>(a.e, st, ls, lw, cur_mode, pre);
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
+        coop_step_prepare<W>(a.e, st, ls, lw, cur_mode, pre, a.wave_cat ? tprep : nullptr);
         if (a.st_gen && general) {       // diagnostics: time this strand spends in general steps (prepare + cooperative phases + step)
             a.st_gen[2 * st.s] += __builtin_amdgcn_s_memrealtime() - t_general;
             a.st_gen[2 * st.s + 1] += 1;
         }
+        unsigned long long tc5 = 0;
+        if (a.wave_cat) tc5 = __builtin_amdgcn_s_memrealtime();
+#else
+        coop_step_prepare<W>(a.e, st, ls, lw, cur_mode, pre);
 #endif
+        kc_add += pre.n_added; kc_choice += pre.choice_done ? 1u : 0u;
         if (general) {
+            kc_gen++;
             bool ended = strand_step<W>(a, st, ls, pre, rs);
             rs.seen_marks += st.vt.used - used1;
             if (!ended && a.snap && pre.choice_done && st.status == ST_OK) ended = periodic_check(a, st, ls, rs, a.snap + (size_t)slot * LDBG_SNAP_CAP);
             if (ended) { walk_finish(a, st); active = false; }
         }
-#ifndef LDBG_HOSTSIM
-        if (a.wave_cat && threadIdx.x == 0) { unsigned long long* wc = a.wave_cat + 8 * blockIdx.x; wc[4] += 1; wc[5] += __builtin_amdgcn_s_memrealtime() - tc4; }
+#ifdef LDBG_WALK_DIAG
+        if (a.wave_cat && threadIdx.x == 0) {       // general part: [5] all of it, [6] per-lane prefetch, [7] cooperative adds, [8] cooperative choices, [9] the step itself;
+            unsigned long long* wc = a.wave_cat + 16 * blockIdx.x;      // [10] lanes with a general step, [11] owners of adds, [12] owners of choices
+            const unsigned long long tc6 = __builtin_amdgcn_s_memrealtime();
+            wc[4] += 1; wc[5] += tc6 - tc4; wc[6] += tprep[0] - tc4; wc[7] += tprep[1] - tprep[0]; wc[8] += tc5 - tprep[1]; wc[9] += tc6 - tc5;
+            wc[10] += (unsigned long long)__builtin_popcountll(general_lanes); wc[11] += tprep[2] & 0xFFFFFFFFull; wc[12] += tprep[2] >> 32;
+        }
 #endif
     }
     if constexpr (IMG) {
@@ -294,10 +313,29 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             atomic_add_u64(a.unfinished, 1ull);
         }
     }
-#ifndef LDBG_HOSTSIM
+#ifdef LDBG_WALK_DIAG
     if (a.wg_times && threadIdx.x == 0) a.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) atomic_add_u64(a.vnext + 1, wave_iterations);     // diagnostics: loop iterations of all wavefronts
 #endif
+    if (a.kinds) {
+        // one sum per counter and wavefront, one atomic each; and the wavefront's own iteration counts (the latency side of the model)
+        const uint32_t kc[6] = {kc_run, kc_runv, kc_lean, kc_gen, kc_add, kc_choice};
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const uint32_t tot = wave_incl_scan_u32(kc[q]);
+            if (wave_lane() == wave_size() - 1 && tot) atomic_add_u64(a.kinds + q, (unsigned long long)tot);
+        }
+        if (wave_lane() == 0) {
+            atomic_add_u64(a.kinds + 6, (unsigned long long)wave_iterations);
+            atomic_add_u64(a.kinds + 7, (unsigned long long)wave_general);
+            unsigned long long* mx = a.kinds + 8;           // busiest wavefront: most iterations with a general part | its iterations
+            const unsigned long long mine = ((unsigned long long)wave_general << 32) | (unsigned long long)wave_iterations;
+#ifndef LDBG_HOSTSIM
+            atomicMax(mx, mine);
+#else
+            if (mine > *mx) *mx = mine;
+#endif
+        }
+    }
 }
 
 // ---- result assembly -------------------------------------------------------------------------
@@ -711,7 +749,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
 }
 
-Engine::~Engine() { sharded_abort(); clear_batch(); drop_spares(); rt::hfree_pinned(h_log_); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
+Engine::~Engine() { sharded_abort(); clear_batch(); drop_spares(); rt::hfree_pinned(h_log_); rt::hfree_pinned(h_stage_[0]); rt::hfree_pinned(h_stage_[1]); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
 
 // ROI hits of the walks of the last batch: offsets[n+1] into hits (ROI record numbers, order within a walk arbitrary),
 // has_null[i] = the dfs graph of seed i holds a vertex without a record
@@ -1075,8 +1113,8 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
     d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
     d_quirk = (uint8_t*)rt::dmalloc((size_t)ns);
-    d_ctr = (unsigned long long*)rt::dmalloc(64);
-    rt::dmemset(d_ctr, 0, 64, s);
+    d_ctr = (unsigned long long*)rt::dmalloc(256);      // [0..7] queue / pool cursors, [8..] the step-kind counters (strand.h: WalkArgs::kinds)
+    rt::dmemset(d_ctr, 0, 256, s);
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
 
     laps.lap("small allocations");
@@ -1087,6 +1125,7 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
     a.img_on = img ? 1 : 0;
     a.seed_slot = d_seed_slot;
     a.save = nullptr; a.unfinished = d_ctr + 4;
+    a.kinds = d_ctr + 8;
     if (img) {
         a.img = img->view((uint64_t*)view.links.rec_of);
         r.d_save = rt::dmalloc((size_t)std::max<int64_t>(64, n_slots_) * sizeof(StrandSave));
@@ -1138,7 +1177,11 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
     if (const char* ev = getenv("LDBG_IMG_YIELD")) a.yield_iters = img ? (uint32_t)std::max(0, atoi(ev)) : 0u;
 
     a.wg_times = nullptr; a.st_times = nullptr; a.st_gen = nullptr; a.wave_cat = nullptr;
+#ifdef LDBG_WALK_DIAG
     const bool want_times = r.want_times = getenv("LDBG_WG_TIMES") != nullptr && !img;
+#else
+    const bool want_times = r.want_times = false;       // (the timers are compiled into the -DLDBG_WALK_DIAG build only: make diag)
+#endif
     // one (partial) wavefront per workgroup; every workgroup must be resident (lanes refill from the strand queue):
     // LDBG_LS_FAST x block x 24 B of LDS each, at most 32 wavefronts per CU
     // (measured at C3, profiles/r01_exp_block.log: 64 lanes 0.51 s, 32 lanes 0.60 s, 16 lanes 0.63 s per launch — smaller
@@ -1158,7 +1201,7 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
         a.wg_times = (unsigned long long*)rt::dmalloc((size_t)grid * 16); rt::dmemset(a.wg_times, 0, (size_t)grid * 16, s);
         a.st_times = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_times, 0, (size_t)ns * 16, s);
         a.st_gen = (unsigned long long*)rt::dmalloc((size_t)ns * 16); rt::dmemset(a.st_gen, 0, (size_t)ns * 16, s);
-        a.wave_cat = (unsigned long long*)rt::dmalloc((size_t)grid * 64); rt::dmemset(a.wave_cat, 0, (size_t)grid * 64, s);
+        a.wave_cat = (unsigned long long*)rt::dmalloc((size_t)grid * 128); rt::dmemset(a.wave_cat, 0, (size_t)grid * 128, s);
 #ifdef LDBG_LEAN_PROFILE
         a.st_prof = (unsigned long long*)rt::dmalloc((size_t)ns * 32); rt::dmemset(a.st_prof, 0, (size_t)ns * 32, s);
 #endif
@@ -1220,9 +1263,17 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
     rt::d2h(iters.data(), d_iters, (size_t)ns * 4, s);
     rt::d2h(out.walk_len.data(), d_walk_len, (size_t)n * 8, s);
     rt::d2h(out.seed_ok.data(), d_seed_ok, (size_t)n, s);
-    unsigned long long ctr[4] = {0, 0, 0, 0};
-    rt::d2h(ctr, d_ctr, 32, s);
+    unsigned long long ctr[20] = {0};
+    rt::d2h(ctr, d_ctr, 160, s);
     rt::stream_sync(s);
+    {
+        static const char* const kind_names[8] = {"walk_steps_run", "walk_run_vertices", "walk_steps_lean", "walk_steps_general", "walk_link_adds", "walk_choices",
+                                                  "walk_wave_iterations", "walk_wave_general"};
+        for (int q = 0; q < 8; q++) profile_add(kind_names[q], (double)ctr[8 + q]);
+        profile_add("walk_busiest_general", (double)(ctr[16] >> 32));
+        profile_add("walk_busiest_iterations", (double)(ctr[16] & 0xFFFFFFFFull));
+        profile_add("walk_wavefronts", (double)grid);
+    }
     if (want_times) {
         std::vector<unsigned long long> t((size_t)grid * 2);
         rt::d2h(t.data(), a.wg_times, (size_t)grid * 16, s);
@@ -1237,19 +1288,22 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
                 grid, ss[0], ss[grid / 2], ss[grid * 9 / 10], ss[grid - 1], ee[0], ee[grid / 2], ee[grid * 9 / 10], ee[grid - 1]);
         rt::dfree(a.wg_times);
         {
-            std::vector<unsigned long long> wc((size_t)grid * 8);
-            rt::d2h(wc.data(), a.wave_cat, (size_t)grid * 64, s);
+            std::vector<unsigned long long> wc((size_t)grid * 16);
+            rt::d2h(wc.data(), a.wave_cat, (size_t)grid * 128, s);
             rt::stream_sync(s);
             rt::dfree(a.wave_cat);
-            unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long sum[16] = {0};
             int slowest = 0;
-            for (int i = 0; i < grid; i++) { for (int q = 0; q < 8; q++) sum[q] += wc[8 * i + q]; if (en[i] > en[slowest]) slowest = i; }
+            for (int i = 0; i < grid; i++) { for (int q = 0; q < 16; q++) sum[q] += wc[16 * i + q]; if (en[i] > en[slowest]) slowest = i; }
             auto line = [&](const char* who, const unsigned long long* w, double div) {
                 fprintf(stderr, "[ldbg] %s: %.0f loop iterations; table regrowth %.2f ms, run steps %.2f ms, lean runs %.2f ms; %.0f with a general part, %.2f ms (%.1f us each)\n", who,
                         w[0] / div, w[1] / 1e5 / div, w[2] / 1e5 / div, w[3] / 1e5 / div, w[4] / div, w[5] / 1e5 / div, w[4] ? w[5] / 100.0 / w[4] : 0.0);
+                const double g = w[4] ? (double)w[4] : 1.0;
+                fprintf(stderr, "[ldbg] %s: general part per iteration: prefetch %.2f us, adds %.2f us, choices %.2f us, step %.2f us; lanes %.1f, add owners %.2f, choice owners %.2f\n", who,
+                        w[6] / 100.0 / g, w[7] / 100.0 / g, w[8] / 100.0 / g, w[9] / 100.0 / g, w[10] / g, w[11] / g, w[12] / g);
             };
             line("average wavefront", sum, (double)grid);
-            line("slowest wavefront", &wc[8 * (size_t)slowest], 1.0);
+            line("slowest wavefront", &wc[16 * (size_t)slowest], 1.0);
         }
         std::vector<unsigned long long> tt((size_t)ns * 2);
         rt::d2h(tt.data(), a.st_times, (size_t)ns * 16, s);
@@ -1297,7 +1351,7 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
         }
         double tot_ms = 0; for (int64_t i = 0; i < ns; i++) tot_ms += (tt[2 * i + 1] - tt[2 * i]) / 1e5;
         fprintf(stderr, "[ldbg] sum of strand durations %.1f s over %lld strands; %llu wavefront loop iterations in %d wavefronts\n", tot_ms / 1e3, (long long)ns,
-                ctr[3], grid);
+                ctr[14], grid);
         rt::dfree(a.st_times);
     }
     vpool_dirty_ = ctr[2];
@@ -1463,6 +1517,37 @@ bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, i
     } catch (...) { r.free_tmp(); throw; }
 }
 
+// Device -> caller's host buffer.  Into page-locked memory (ldbg_host_alloc) the copy runs at the bus rate as it is.  Into pageable memory
+// the runtime's own copy manages about 10 GB/s (780 MB of contigs: 76 ms of an 86 ms step), so it goes through two page-locked staging
+// buffers instead: chunk i + 1 crosses the bus while a few host threads move chunk i to its place.
+#define LDBG_STAGE_BYTES ((size_t)32 << 20)
+void Engine::download(char* dst, const void* d_src, size_t bytes) {
+    rt::stream_t s = graph->stream;
+    if (bytes == 0) return;
+    if (bytes < ((size_t)4 << 20) || rt::host_is_pinned(dst)) { rt::d2h(dst, d_src, bytes, s); rt::stream_sync(s); return; }
+    for (int b = 0; b < 2; b++) if (!h_stage_[b]) h_stage_[b] = rt::hmalloc_pinned(LDBG_STAGE_BYTES);
+    const size_t nchunks = (bytes + LDBG_STAGE_BYTES - 1) / LDBG_STAGE_BYTES;
+    rt::Event landed[2];
+    auto scatter = [&](size_t c) {             // staging buffer of chunk c -> its place, on 4 threads
+        const size_t off = c * LDBG_STAGE_BYTES, len = std::min(LDBG_STAGE_BYTES, bytes - off);
+        const char* src = (const char*)h_stage_[c & 1];
+        const int T = 4;
+        std::thread th[T - 1];
+        auto part = [&](int t) { const size_t lo = len * (size_t)t / T, hi = len * (size_t)(t + 1) / T; memcpy(dst + off + lo, src + lo, hi - lo); };
+        for (int t = 1; t < T; t++) th[t - 1] = std::thread(part, t);
+        part(0);
+        for (int t = 1; t < T; t++) th[t - 1].join();
+    };
+    for (size_t c = 0; c < nchunks; c++) {
+        const size_t off = c * LDBG_STAGE_BYTES, len = std::min(LDBG_STAGE_BYTES, bytes - off);
+        rt::d2h(h_stage_[c & 1], (const char*)d_src + off, len, s);
+        landed[c & 1].record(s);
+        if (c > 0) { landed[(c - 1) & 1].wait(); scatter(c - 1); }       // (the buffer chunk c + 1 will land in is free again after this)
+    }
+    landed[(nchunks - 1) & 1].wait();
+    scatter(nchunks - 1);
+}
+
 void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len) {
     rt::set_device(graph->device);
     if (offsets) {
@@ -1476,10 +1561,9 @@ void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_
     if (arena) {
         int64_t o = 0;
         for (auto& c : chunks) {
-            rt::d2h(arena + o, c.d_contigs, (size_t)c.contig_off.back(), graph->stream);
+            download(arena + o, c.d_contigs, (size_t)c.contig_off.back());
             o += c.contig_off.back();
         }
-        rt::stream_sync(graph->stream);
     }
 }
 

@@ -321,7 +321,21 @@ class TraversalEngine:
         raw = arena.tobytes()
         return [raw[offs[i]:offs[i + 1]].decode() for i in range(len(wl))], wl
 
-    def walk_batch_arrays(self, seeds, fetch=True):
+    def _arena(self, nbytes):
+        """page-locked result arena of this engine (ldbg_host_alloc), kept from batch to batch and grown when needed"""
+        if getattr(self, "_pin_cap", 0) < nbytes:
+            if getattr(self, "_pin_ptr", None):
+                self._d.ldbg_host_free(self._pin_ptr)
+            cap = int(nbytes * 1.25) + 4096
+            p = C.c_void_p()
+            self._lib.check(self._d.ldbg_host_alloc(C.c_int64(cap), C.byref(p)))
+            self._pin_ptr, self._pin_cap = p, cap
+            self._pin_np = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cap,))
+        return self._pin_np[:nbytes]
+
+    def walk_batch_arrays(self, seeds, fetch=True, pinned=False):
+        """-> (contig arena u8[total], offsets i64[n+1], walk lengths i64[n]).  pinned=True: the arena is this engine's page-locked block
+        (the download runs at the bus rate); it is valid until the next batch of this engine."""
         k = self._graph.getKmerSize()
         if isinstance(seeds, np.ndarray):
             a = np.ascontiguousarray(seeds, dtype=np.uint8)
@@ -335,7 +349,7 @@ class TraversalEngine:
         self.last_total_bytes = total.value
         if not fetch:
             return None, None, None
-        arena = np.empty(max(1, total.value), dtype=np.uint8)
+        arena = self._arena(max(1, total.value)) if pinned else np.empty(max(1, total.value), dtype=np.uint8)
         offs = np.zeros(n + 1, dtype=np.int64)
         wl = np.zeros(max(1, n), dtype=np.int64)
         self._lib.check(self._d.ldbg_engine_walk_batch_fetch(self._h, arena.ctypes.data_as(C.c_char_p), C.c_int64(total.value),
@@ -435,6 +449,10 @@ class TraversalEngine:
     def previous(self): return self._step(self._d.ldbg_engine_previous)   # :281-319
 
     def close(self):
+        if getattr(self, "_pin_ptr", None):
+            self._pin_np = None
+            self._d.ldbg_host_free(self._pin_ptr)
+            self._pin_ptr, self._pin_cap = None, 0
         if getattr(self, "_h", None):
             self._lib.check(self._d.ldbg_engine_destroy(self._h))
             self._h = None

@@ -261,6 +261,11 @@ ldbg_status ldbg_engine_walk_batch_run(ldbg_engine* e, const char* seeds, int64_
                                        int64_t* total_contig_bytes, int64_t* kmers_traversed);
 ldbg_status ldbg_engine_walk_batch_fetch(ldbg_engine* e, char* contig_arena, int64_t arena_capacity,
                                          int64_t* offsets, int64_t* walk_len);
+/* Page-locked host memory for result arenas (contig_arena above): a download into it runs at the bus rate (C3: 780 MB of contigs in
+ * about 16 ms); into ordinary memory the library stages the copy through its own page-locked buffers (about twice as long).  A JNI
+ * host wraps the block in a direct ByteBuffer (NewDirectByteBuffer) and reads the contigs in place. */
+ldbg_status ldbg_host_alloc(int64_t bytes, void** out);
+ldbg_status ldbg_host_free(void* p);
 /* vertices of walk i of the last batch: packed k-mer words (len × W), record index (-1 = null
  * CortexRecord), copyIndex, index (CortexVertex.java:20-35) */
 ldbg_status ldbg_engine_walk_vertices(ldbg_engine* e, int64_t walk, int64_t capacity, int64_t* len,
