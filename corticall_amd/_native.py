@@ -72,7 +72,7 @@ EXPORTS = [
     "ldbg_links_open", "ldbg_links_close", "ldbg_links_index", "ldbg_links_source", "ldbg_links_info", "ldbg_links_sample_name", "ldbg_links_get",
     "ldbg_engine_config_default", "ldbg_engine_create", "ldbg_engine_destroy",
     "ldbg_engine_walk_batch", "ldbg_engine_walk_batch_run", "ldbg_engine_walk_batch_fetch", "ldbg_host_alloc", "ldbg_host_free", "ldbg_engine_walk_vertices", "ldbg_engine_walk_roi_hits",
-    "ldbg_engine_dfs_batch", "ldbg_dfs_result_sizes", "ldbg_dfs_result_get", "ldbg_dfs_result_walk", "ldbg_dfs_result_free",
+    "ldbg_engine_dfs_batch", "ldbg_dfs_result_sizes", "ldbg_dfs_result_get", "ldbg_dfs_result_walk", "ldbg_dfs_result_merge", "ldbg_dfs_result_free", "ldbg_engine_neighbours_batch", "ldbg_engine_assemble",
     "ldbg_engine_dfs_kmers_traversed",
     "ldbg_engine_seek", "ldbg_engine_has_next", "ldbg_engine_has_previous", "ldbg_engine_next", "ldbg_engine_previous",
     "ldbg_profile_reset", "ldbg_profile_get",

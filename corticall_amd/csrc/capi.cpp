@@ -489,13 +489,26 @@ ldbg_status ldbg_dfs_result_walk(const ldbg_dfs_result* r, int64_t i, const char
         memcpy(contig, c.c_str(), c.size() + 1);
     });
 }
+ldbg_status ldbg_dfs_result_merge(ldbg_dfs_result* r, const int64_t* which, int64_t m, ldbg_dfs_result** out) {
+    return guard([&] {
+        *out = nullptr;
+        std::unique_ptr<DfsBatch> b(dfs_merge(*r->b, which, m));
+        *out = new ldbg_dfs_result{std::move(b)};
+    });
+}
 ldbg_status ldbg_dfs_result_free(ldbg_dfs_result* r) { delete r; return LDBG_OK; }
+ldbg_status ldbg_engine_neighbours_batch(ldbg_engine* e, const char* kmers, int64_t n, int forward, int64_t* offsets, uint64_t* kmer_words, int64_t* rec, int64_t capacity) {
+    return guard([&] { e->e.neighbours_batch(kmers, n, forward != 0, offsets, kmer_words, rec, capacity); });
+}
 ldbg_status ldbg_engine_dfs_kmers_traversed(const ldbg_engine* e, int64_t* n) { return guard([&] { *n = e->e.dfs_traversed(); }); }
 
 // ---- cursor
 static CursorHost& cursor_of(ldbg_engine* e) {
     if (!e->cursor) e->cursor.reset(new CursorHost(e->e));
     return *e->cursor;
+}
+ldbg_status ldbg_engine_assemble(ldbg_engine* e, const char* seed, int64_t capacity, int64_t* len, uint64_t* kmer_words, int64_t* rec) {
+    return guard([&] { cursor_of(e).assemble(seed, capacity, len, kmer_words, rec); });
 }
 ldbg_status ldbg_engine_seek(ldbg_engine* e, const char* kmer) { return guard([&] { cursor_of(e).seek(kmer); }); }
 ldbg_status ldbg_engine_has_next(ldbg_engine* e, int* yes) { return guard([&] { *yes = cursor_of(e).has(true) ? 1 : 0; }); }

@@ -48,11 +48,9 @@ LDBG_KERNEL void k_cursor_seek(EngineView e, CursorStateDev<W>* stp, const uint6
     cs_reseek<W>(e, st, vtab, vcap);
 }
 
+// one next() / previous() on the device-resident state
 template <int W>
-LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, uint64_t* vtab, uint32_t vcap, LsElem* els, uint32_t ecap) {
-    if (global_tid() != 0) return;
-    CursorStateDev<W>& st = *stp;
-    const bool fwd = fwd_i != 0;
+LDBG_DEV void cs_step(const EngineView& e, CursorStateDev<W>& st, bool fwd, uint64_t* vtab, uint32_t vcap, LsElem* els, uint32_t ecap) {
     st.status = ST_OK;
     if (st.first || (st.go_forward != 0) != fwd) {      // :243-248 / :283-288
         st.go_forward = fwd ? 1 : 0;
@@ -94,6 +92,31 @@ LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, 
     st.vt_used = vt.used;
     for (int i = 0; i < W; i++) { st.out_words[i] = tk.w[i]; st.cur_words[i] = tk.w[i]; }
     st.out_rec = t.idx;
+}
+template <int W>
+LDBG_KERNEL void k_cursor_step(EngineView e, CursorStateDev<W>* stp, int fwd_i, uint64_t* vtab, uint32_t vcap, LsElem* els, uint32_t ecap) {
+    if (global_tid() != 0) return;
+    cs_step<W>(e, *stp, fwd_i != 0, vtab, vcap, els, ecap);
+}
+// assemble(seed, goForward) (TraversalEngine.java:125-145) after a seek(seed): next() / previous() for as long as the cursor has one and
+// fewer than max_len vertices have been collected, all in ONE launch; out_n[0] = vertices, out_n[1] = status of the last step
+template <int W>
+LDBG_KERNEL void k_cursor_assemble(EngineView e, CursorStateDev<W>* stp, int fwd_i, uint64_t* vtab, uint32_t vcap, LsElem* els, uint32_t ecap, int64_t max_len,
+                                   uint64_t* out_words, int64_t* out_rec, int64_t* out_n) {
+    if (global_tid() != 0) return;
+    CursorStateDev<W>& st = *stp;
+    const bool fwd = fwd_i != 0;
+    int64_t n = 0;
+    uint32_t status = st.status;
+    while (status == ST_OK && (fwd ? st.has_next : st.has_prev) && n < max_len) {
+        cs_step<W>(e, st, fwd, vtab, vcap, els, ecap);
+        status = st.status;
+        if (status != ST_OK) break;
+        for (int i = 0; i < W; i++) out_words[n * W + i] = st.out_words[i];
+        out_rec[n] = st.out_rec;
+        n++;
+    }
+    out_n[0] = n; out_n[1] = (int64_t)status;
 }
 
 // ------------------------------------------------------------------ host
@@ -176,12 +199,83 @@ void CursorHost::peek(bool* has_next, bool* has_prev, uint32_t* status, uint64_t
 #undef LDBG_PEEK
 }
 
+int64_t CursorHost::cur_record() {
+    rt::stream_t s = eng_.graph->stream;
+    int64_t idx = -1;
+#define LDBG_CUR(WW) { CursorStateDev<WW> h; read_state<WW>(impl_->d_state, h, s); idx = h.cur.idx; }
+    switch (eng_.graph->hdr.W) { case 1: LDBG_CUR(1) break; case 2: LDBG_CUR(2) break; case 3: LDBG_CUR(3) break; default: LDBG_CUR(4) break; }
+#undef LDBG_CUR
+    return idx;
+}
+
 bool CursorHost::has(bool fwd) {
     rt::set_device(eng_.graph->device);
     if (!impl_->sought) return false;
     bool hn, hp; uint32_t st;
     peek(&hn, &hp, &st, nullptr, nullptr);
     return fwd ? hn : hp;
+}
+
+// TraversalEngine.assemble(seed) (:112-123): [previous() ... in contig order] + the seed's vertex + [next() ...]
+void CursorHost::assemble(const char* seed, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec) {
+    rt::set_device(eng_.graph->device);
+    const int W = eng_.graph->hdr.W;
+    rt::stream_t s = eng_.graph->stream;
+    const int64_t max_len = std::max<int64_t>(0, eng_.cfg.max_branch_length);
+    // the cursor's `seen` table holds every vertex stepped onto since the seek (load <= 1/2)
+    uint32_t need = 1u << 17;
+    while ((uint64_t)need < 2ull * (uint64_t)(max_len + 16)) need <<= 1;
+    if (need > impl_->vcap) {
+        rt::dfree(impl_->d_vtab);
+        impl_->d_vtab = nullptr;
+        impl_->d_vtab = rt::dmalloc((size_t)need * 8);
+        impl_->vcap = need;
+        rt::dmemset(impl_->d_vtab, 0, (size_t)need * 8, s);
+    }
+    struct Tmp { std::vector<void*> p; ~Tmp() { for (void* x : p) rt::dfree(x); } void* get(size_t nbytes) { void* x = rt::dmalloc(nbytes); p.push_back(x); return x; } } tmp;
+    uint64_t* d_w = (uint64_t*)tmp.get((size_t)std::max<int64_t>(1, max_len) * W * 8);
+    int64_t* d_r = (int64_t*)tmp.get((size_t)std::max<int64_t>(1, max_len) * 8);
+    int64_t* d_n = (int64_t*)tmp.get(16);
+    std::vector<uint64_t> part_w[2];
+    std::vector<int64_t> part_r[2];
+    std::vector<uint64_t> seed_w(W);
+    int64_t seed_rec = -1;
+    for (int dir = 1; dir >= 0; dir--) {                 // forward first, as the reference does
+        seek(seed);
+        if (dir == 1) {
+            // the seed's own vertex: bases(seed), record(findRecord(seed))
+            const bool ok = ascii_to_words(seed, eng_.graph->hdr.k, seed_w.data(), W);
+            if (!ok) std::fill(seed_w.begin(), seed_w.end(), 0ull);
+            seed_rec = cur_record();                     // (the seek has just looked the seed up)
+        }
+#define LDBG_ASM(WW) LDBG_LAUNCH(k_cursor_assemble<WW>, 1, 64, s, eng_.view, (CursorStateDev<WW>*)impl_->d_state, dir, (uint64_t*)impl_->d_vtab, impl_->vcap, \
+                                 (LsElem*)impl_->d_ls, impl_->ecap, max_len, d_w, d_r, d_n)
+        switch (W) { case 1: LDBG_ASM(1); break; case 2: LDBG_ASM(2); break; case 3: LDBG_ASM(3); break; default: LDBG_ASM(4); break; }
+#undef LDBG_ASM
+        int64_t hn[2] = {0, 0};
+        rt::d2h(hn, d_n, 16, s);
+        rt::stream_sync(s);
+        check_status((uint32_t)hn[1]);
+        part_w[dir].resize((size_t)hn[0] * W);
+        part_r[dir].resize((size_t)hn[0]);
+        rt::d2h(part_w[dir].data(), d_w, (size_t)hn[0] * W * 8, s);
+        rt::d2h(part_r[dir].data(), d_r, (size_t)hn[0] * 8, s);
+        rt::stream_sync(s);
+    }
+    const int64_t nr = (int64_t)part_r[0].size(), nf = (int64_t)part_r[1].size();
+    *len = nr + 1 + nf;
+    if (capacity < *len) throw StatusError(LDBG_ERR_CAPACITY, "vertex buffers too small: need " + std::to_string(*len));
+    for (int64_t i = 0; i < nr; i++) {                   // contig.add(0, cv): the last one stepped onto comes first
+        const int64_t from = nr - 1 - i;
+        if (words) for (int w = 0; w < W; w++) words[i * W + w] = part_w[0][(size_t)from * W + w];
+        if (rec) rec[i] = part_r[0][(size_t)from];
+    }
+    if (words) for (int w = 0; w < W; w++) words[nr * W + w] = seed_w[(size_t)w];
+    if (rec) rec[nr] = seed_rec;
+    for (int64_t i = 0; i < nf; i++) {
+        if (words) for (int w = 0; w < W; w++) words[(nr + 1 + i) * W + w] = part_w[1][(size_t)i * W + w];
+        if (rec) rec[nr + 1 + i] = part_r[1][(size_t)i];
+    }
 }
 
 void CursorHost::step(bool fwd, char* kmer_out, int64_t* rec_out) {

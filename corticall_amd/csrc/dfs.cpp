@@ -19,6 +19,9 @@
 //    (vertex/edge insertion order, Graphs.addGraph merges, index relabelling, OR/AND combination, :75-99) are
 //    replayed on the host from that log (assemble_* below).
 #include <algorithm>
+#include <map>
+#include <set>
+#include <tuple>
 #include <chrono>
 #include <functional>
 #include <unordered_map>
@@ -1059,6 +1062,141 @@ void java_small_sort(std::vector<T>& v, Cmp cmp) {
 }
 
 }  // namespace
+
+// ---- getNextVertices / getPrevVertices for a batch of k-mers (TraversalEngine.java:147-239): the neighbour vertices of every query in
+// the iteration order of the HashSet<CortexVertex> the reference returns (order_children), at most four each.  One query per thread.
+template <int W>
+LDBG_KERNEL void k_neighbours(DfsArgs a, const uint64_t* words, const uint8_t* valid, int64_t n, int fwd, uint8_t* cnt, uint64_t* out_words, int64_t* out_rec,
+                              uint32_t* status) {
+    const EngineView& e = a.w.e;
+    for (int64_t i = global_tid(); i < n; i += global_nthreads()) {
+        Node v;
+        Kmer<W> sk;
+#pragma unroll
+        for (int w = 0; w < W; w++) sk.w[w] = words[i * W + w];
+        if (valid[i]) node_find<W>(e, sk, v); else node_null(e, v);
+        cnt[i] = 0; status[i] = ST_OK;
+        if (v.npe) { status[i] = ST_NULLPTR; continue; }      // no record, and recruitment colours are set: prevKmers.get(c) on a null map (Q14)
+        if (v.idx < 0) continue;
+        const uint32_t mask = fwd ? v.next_mask : v.prev_mask;
+        if (!mask) continue;
+        uint8_t ord[4];
+        VisitedTable none;
+        none.tab = nullptr; none.mask = 0; none.used = 0;
+        const int nn = order_children<W>(a, none, v, fwd != 0, mask, ord);
+        for (int c = 0; c < nn; c++) {
+            const Kmer<W> ck = child_kmer<W>(e, v, fwd != 0, ord[c]);
+            Node x;
+            node_child(e, v, fwd != 0, ord[c], x);
+            for (int w = 0; w < W; w++) out_words[(i * 4 + c) * W + w] = kmer_word<W>(ck, w);
+            out_rec[i * 4 + c] = x.idx;
+        }
+        cnt[i] = (uint8_t)nn;
+    }
+}
+
+void Engine::neighbours_batch(const char* kmers, int64_t n, bool forward, int64_t* offsets, uint64_t* kmer_words, int64_t* rec, int64_t capacity) {
+    rt::set_device(graph->device);
+    rt::stream_t s = graph->stream;
+    const int k = graph->hdr.k, W = graph->hdr.W;
+    offsets[0] = 0;
+    if (n <= 0) return;
+    std::vector<uint64_t> words((size_t)n * W);
+    std::vector<uint8_t> valid((size_t)n);
+    ascii_batch_to_words(kmers, n, k, W, words.data(), valid.data());
+    struct Tmp { std::vector<void*> p; ~Tmp() { for (void* x : p) rt::dfree(x); } void* get(size_t nbytes) { void* x = rt::dmalloc(nbytes); p.push_back(x); return x; } } tmp;
+    uint64_t* d_words = (uint64_t*)tmp.get((size_t)n * W * 8);
+    uint8_t* d_valid = (uint8_t*)tmp.get((size_t)n);
+    uint8_t* d_cnt = (uint8_t*)tmp.get((size_t)n);
+    uint64_t* d_out = (uint64_t*)tmp.get((size_t)n * 4 * W * 8);
+    int64_t* d_rec = (int64_t*)tmp.get((size_t)n * 4 * 8);
+    uint32_t* d_status = (uint32_t*)tmp.get((size_t)n * 4);
+    rt::h2d(d_words, words.data(), (size_t)n * W * 8, s);
+    rt::h2d(d_valid, valid.data(), (size_t)n, s);
+    DfsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w.e = view;
+    a.n_trav = 0;
+    for (int i = 0; i < cfg.n_traversal; i++) {        // traversal colours in LinkedHashSet order
+        bool dup = false;
+        for (int j = 0; j < a.n_trav; j++) dup |= a.trav_order[j] == (uint8_t)cfg.traversal_colors[i];
+        if (!dup) a.trav_order[a.n_trav++] = (uint8_t)cfg.traversal_colors[i];
+    }
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096));
+    switch (W) {
+        case 1: LDBG_LAUNCH(k_neighbours<1>, grid, 256, s, a, (const uint64_t*)d_words, (const uint8_t*)d_valid, n, forward ? 1 : 0, d_cnt, d_out, d_rec, d_status); break;
+        case 2: LDBG_LAUNCH(k_neighbours<2>, grid, 256, s, a, (const uint64_t*)d_words, (const uint8_t*)d_valid, n, forward ? 1 : 0, d_cnt, d_out, d_rec, d_status); break;
+        case 3: LDBG_LAUNCH(k_neighbours<3>, grid, 256, s, a, (const uint64_t*)d_words, (const uint8_t*)d_valid, n, forward ? 1 : 0, d_cnt, d_out, d_rec, d_status); break;
+        default: LDBG_LAUNCH(k_neighbours<4>, grid, 256, s, a, (const uint64_t*)d_words, (const uint8_t*)d_valid, n, forward ? 1 : 0, d_cnt, d_out, d_rec, d_status); break;
+    }
+    std::vector<uint8_t> cnt((size_t)n);
+    std::vector<uint32_t> status((size_t)n);
+    std::vector<uint64_t> ow((size_t)n * 4 * W);
+    std::vector<int64_t> orec((size_t)n * 4);
+    rt::d2h(cnt.data(), d_cnt, (size_t)n, s);
+    rt::d2h(status.data(), d_status, (size_t)n * 4, s);
+    rt::d2h(ow.data(), d_out, (size_t)n * 4 * W * 8, s);
+    rt::d2h(orec.data(), d_rec, (size_t)n * 4 * 8, s);
+    rt::stream_sync(s);
+    for (int64_t i = 0; i < n; i++)
+        if (status[(size_t)i] == ST_NULLPTR)
+            throw StatusError(LDBG_ERR_NULLPOINTER, std::string(forward ? "getNextVertices" : "getPrevVertices") + ": record missing while recruitment colours are set (k-mer " + std::to_string(i) + ")");
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) { total += cnt[(size_t)i]; offsets[i + 1] = total; }
+    if (total > capacity) throw StatusError(LDBG_ERR_CAPACITY, "neighbour buffers too small: need " + std::to_string(total));
+    for (int64_t i = 0; i < n; i++)
+        for (int c = 0; c < cnt[(size_t)i]; c++) {
+            const int64_t o = offsets[i] + c;
+            if (kmer_words) for (int w = 0; w < W; w++) kmer_words[o * W + w] = ow[((size_t)i * 4 + c) * W + w];
+            if (rec) rec[o] = orec[(size_t)i * 4 + c];
+        }
+}
+
+// ---- dfs(Collection<String> sources, Collection<String> sinks) (TraversalEngine.java:37-62): the graphs of the sources that returned one,
+// merged in source order — the first as it is, every further one with Graphs.addGraph (its vertices that the merged graph does not hold
+// yet, in their order; then its edges, each refused when an equal CortexEdge — same end points either way round, same colour — is there)
+DfsBatch* dfs_merge(DfsBatch& b, const int64_t* which, int64_t m) {
+    b.materialize();
+    const int W = b.W, C = b.C;
+    std::unique_ptr<DfsBatch> out(new DfsBatch);
+    out->k = b.k; out->W = W; out->C = C; out->graph = b.graph; out->color = b.color; out->materialized = true;
+    out->results.resize(1);
+    DfsGraphHost& g = out->results[0];
+    struct Key { int64_t rec; uint64_t flip_copy_index; std::string null_kmer; bool operator<(const Key& o) const {
+        if (rec != o.rec) return rec < o.rec; if (flip_copy_index != o.flip_copy_index) return flip_copy_index < o.flip_copy_index; return null_kmer < o.null_kmer; } };
+    std::map<Key, int> vmap;
+    std::set<std::tuple<int, int, int>> emap;        // (min end, max end, colour)
+    for (int64_t q = 0; q < m; q++) {
+        if (which[q] < 0 || which[q] >= (int64_t)b.results.size()) throw StatusError(LDBG_ERR_ARG, "dfs_merge: result index out of range");
+        const DfsGraphHost& s = b.results[(size_t)which[q]];
+        if (s.is_null) continue;
+        if (s.packed) throw StatusError(LDBG_ERR_HIP, "dfs_merge: a result is still packed after materialize()");
+        g.is_null = false;
+        std::vector<int> local((size_t)s.verts.size());
+        for (size_t i = 0; i < s.verts.size(); i++) {
+            const DfsVertex& v = s.verts[i];
+            Key key{v.rec, 0ull, std::string()};
+            key.flip_copy_index = ((uint64_t)v.flip << 63) | ((uint64_t)(uint32_t)v.copy << 24) | (uint64_t)((uint32_t)v.index & 0xFFFFFFu);
+            if (v.rec < 0) key.null_kmer.assign((const char*)&s.words[i * (size_t)W], (size_t)W * 8);
+            auto it = vmap.find(key);
+            if (it == vmap.end()) {
+                it = vmap.emplace(key, (int)g.verts.size()).first;
+                DfsVertex nv = v;
+                nv.slot = -1;
+                g.verts.push_back(nv);
+                g.words.insert(g.words.end(), s.words.begin() + (ptrdiff_t)(i * (size_t)W), s.words.begin() + (ptrdiff_t)((i + 1) * (size_t)W));
+                g.cov.insert(g.cov.end(), s.cov.begin() + (ptrdiff_t)(i * (size_t)C), s.cov.begin() + (ptrdiff_t)((i + 1) * (size_t)C));
+            }
+            local[i] = it->second;
+        }
+        for (const DfsEdge& e : s.edges) {
+            const int a = local[(size_t)e.src], c = local[(size_t)e.dst];
+            if (!emap.insert(std::make_tuple(std::min(a, c), std::max(a, c), e.color)).second) continue;
+            g.edges.push_back({a, c, e.color});
+        }
+    }
+    return out.release();
+}
 
 // ------------------------------------------------------------------ host: Engine::dfs_batch
 static uint32_t next_pow2_u(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)std::min<uint64_t>(p, 1ull << 31); }

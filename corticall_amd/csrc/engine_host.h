@@ -67,6 +67,8 @@ struct DfsBatch {
     std::string walk_contig(int64_t i, const char* seed, int color);
 };
 
+DfsBatch* dfs_merge(DfsBatch& b, const int64_t* which, int64_t m);     // Graphs.addGraph over results of one batch (dfs.cpp)
+
 struct WalkRun;
 class ShardImage;
 // a dfs batch over the local image of a hash-sharded table (image.h): the library runs the rounds, the caller's callback makes the
@@ -106,6 +108,8 @@ public:
     void sharded_abort();
     // dfs(source, sinks...) for n sources; sinks as CSR over ASCII k-mers (sink_offsets may be nullptr)
     DfsBatch* dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets, const ShardedRun* sharded = nullptr);
+    // getNextVertices / getPrevVertices of n k-mers as CSR (dfs.cpp)
+    void neighbours_batch(const char* kmers, int64_t n, bool forward, int64_t* offsets, uint64_t* kmer_words, int64_t* rec, int64_t capacity);
     int dfs_max_depth = 64;
     int dfs_log_blocks = 64;          // path blocks (1024 entries) one strand's dfs log may use
     int64_t dfs_traversed() const { return dfs_traversed_; }

@@ -142,6 +142,16 @@ class FindTips:
         self.numTipChains = 0
         self.tips = []                 # ROI record numbers of the tip k-mers, ascending
 
+    @staticmethod
+    def _neighbour_counts(e, kmers, forward):
+        """sizes of getNextVertices / getPrevVertices (TraversalEngine.java:147-239) of every k-mer (u8[m, k]): ldbg_engine_neighbours_batch"""
+        m = kmers.shape[0]
+        offs = np.zeros(m + 1, dtype=np.int64)
+        a = np.ascontiguousarray(kmers)
+        e._lib.check(e._d.ldbg_engine_neighbours_batch(e._h, a.ctypes.data_as(C.c_char_p), C.c_int64(m), C.c_int(1 if forward else 0),
+                                                       offs.ctypes.data_as(C.c_void_p), None, None, C.c_int64(4 * m)))
+        return offs[1:] - offs[:-1]
+
     def execute(self, out=None):
         g, roi = self.GRAPH, self.ROI
         k = g.getKmerSize()
@@ -182,23 +192,18 @@ class FindTips:
                 rc = comp[ends[:, ::-1]]
                 lower = rc.view("S%d" % k).ravel() < ends.view("S%d" % k).ravel()
                 canon = np.where(lower[:, None], rc, ends)
-                # CanonicalKmer.isFlipped(): by hash inequality (Q6), which is what getPrev/NextVertices orient the record by
-                flipped = java_bytes_hash(canon) != java_bytes_hash(ends)
                 if n > 2:
                     ridx, _, _ = roi.find_batch(np.ascontiguousarray(canon), with_payload=False)
                     novel = ridx >= 0
                 else:       # (used.containsKey is a HashMap lookup; findRecord never finds anything in a graph of <= 2 records, Q1)
                     keys = {seeds[j].tobytes() for j in range(n)}
                     novel = np.array([canon[j].tobytes() in keys for j in range(len(canon))], dtype=bool)
-                gidx, _, gedges = g.find_batch(np.ascontiguousarray(ends))
+                gidx, _, _ = g.find_batch(np.ascontiguousarray(ends), with_payload=False)
                 novel = novel & (gidx >= 0)                                  # CortexVertex.getCanonicalKmer() is null without a record (:45)
-                eb = gedges[:, child].astype(np.uint32)
-                pop4 = np.array([bin(x).count("1") for x in range(16)], dtype=np.uint8)
-                n_in, n_out = pop4[eb >> 4], pop4[eb & 15]
-                n_prev = np.where(flipped, n_out, n_in)
-                n_next = np.where(flipped, n_in, n_out)
-                n_prev[gidx < 0] = 0                                         # no record: no neighbours (no recruitment colours here)
-                n_next[gidx < 0] = 0
+                # e.getPrevVertices(first).size() / e.getNextVertices(last).size() (:85-88): the engine's own neighbourhood (traversal colour,
+                # Java-hash orientation of the record, Q6), asked for all ends in one launch each
+                n_prev = self._neighbour_counts(e, ends, False)
+                n_next = self._neighbour_counts(e, ends, True)
                 left = novel[0::2] & (n_prev[0::2] == 0)
                 right = novel[1::2] & (n_next[1::2] == 0)
                 tip_of[walked] = left | right

@@ -388,15 +388,26 @@ class TraversalEngine:
         self.walk_batch_arrays([seed], fetch=False)
         return self.walk_vertices(0)
 
-    def dfs(self, source, *sinks):   # :64-106
-        """-> DfsGraph, or None where the reference returns null"""
+    def dfs(self, source, *sinks):   # :64-106, and the Collection form :37-62
+        """dfs(String source, String... sinks) -> DfsGraph, or None where the reference returns null.
+        dfs(Collection<String> sources[, Collection<String> sinks]) — source is a list / tuple / set: every source is searched (all of them
+        towards all the sinks, in one device batch) and the graphs that came back are merged in source order with Graphs.addGraph."""
+        if not isinstance(source, (str, bytes)):
+            sources = list(source)
+            all_sinks = list(sinks[0]) if (len(sinks) == 1 and sinks[0] is not None and not isinstance(sinks[0], (str, bytes))) else [x for x in sinks if x is not None]
+            n = len(sources)
+            if n == 0:
+                return None
+            batch = self.dfs_batch_arrays(*self._dfs_arrays(sources, [all_sinks] * n))
+            which = np.arange(n, dtype=np.int64)
+            res = C.c_void_p()
+            self._lib.check(self._d.ldbg_dfs_result_merge(batch.h, which.ctypes.data_as(C.c_void_p), C.c_int64(n), C.byref(res)))
+            return _DfsBatch(self, res).graph(0)
         if len(sinks) == 1 and not isinstance(sinks[0], (str, bytes)):
             sinks = tuple(sinks[0])
         return self.dfs_batch([source], [list(sinks)])[0]
 
-    def dfs_batch(self, sources, sinks=None):
-        """dfs(source, sinks...) for every source in one device launch; sinks: per source a list of k-mers (or None).
-        -> list of DfsGraph / None"""
+    def _dfs_arrays(self, sources, sinks):
         n = len(sources)
         src = np.frombuffer(b"".join(_as_bytes(s) for s in sources), dtype=np.uint8)
         sink_buf, off = None, None
@@ -405,7 +416,62 @@ class TraversalEngine:
             off = np.zeros(n + 1, dtype=np.int64)
             off[1:] = np.cumsum([len(ss) for ss in sinks])
             sink_buf = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8)
-        batch = self.dfs_batch_arrays(src, n, sink_buf, off)
+        return src, n, sink_buf, off
+
+    # ---- neighbourhood and assemble
+    def neighbours_batch(self, kmers, forward=True):
+        """getNextVertices / getPrevVertices (:147-239) of every k-mer in one launch -> list (per k-mer) of lists of CortexVertex, each in
+        the iteration order of the HashSet the reference returns"""
+        k, W = self._graph.getKmerSize(), self._graph.getKmerBits()
+        if isinstance(kmers, np.ndarray):
+            a = np.ascontiguousarray(kmers, dtype=np.uint8).reshape(-1, k)
+        else:
+            a = np.frombuffer(b"".join(_as_bytes(s) for s in kmers), dtype=np.uint8).reshape(len(kmers), k)
+        n = a.shape[0]
+        offs = np.zeros(n + 1, dtype=np.int64)
+        words = np.zeros((max(1, 4 * n), W), dtype=np.uint64)
+        rec = np.zeros(max(1, 4 * n), dtype=np.int64)
+        P = lambda x: x.ctypes.data_as(C.c_void_p)
+        self._lib.check(self._d.ldbg_engine_neighbours_batch(self._h, a.ctypes.data_as(C.c_char_p), C.c_int64(n), C.c_int(1 if forward else 0), P(offs), P(words), P(rec),
+                                                             C.c_int64(4 * n)))
+        out, cache = [], {}
+        for i in range(n):
+            vs = []
+            for j in range(int(offs[i]), int(offs[i + 1])):
+                r = int(rec[j])
+                if r >= 0 and r not in cache:
+                    cache[r] = self._graph.getRecord(r)
+                vs.append(CortexVertex(CortexRecord(words[j], [0], [0], k).getKmerAsString(), cache.get(r)))
+            out.append(vs)
+        return out
+
+    def getNextVertices(self, sk): return self.neighbours_batch([sk], True)[0]     # :195-239
+    def getPrevVertices(self, sk): return self.neighbours_batch([sk], False)[0]    # :147-193
+
+    def assemble(self, seed):    # :112-145
+        """seek(seed), next() while hasNext(), previous() while hasPrevious() — on the device in two launches -> list[CortexVertex]"""
+        k, W = self._graph.getKmerSize(), self._graph.getKmerBits()
+        ln = C.c_int64()
+        st = self._d.ldbg_engine_assemble(self._h, _as_bytes(seed), C.c_int64(0), C.byref(ln), None, None)
+        if st not in (0, 7):
+            self._lib.check(st)
+        n = ln.value
+        words = np.zeros((max(1, n), W), dtype=np.uint64)
+        rec = np.zeros(max(1, n), dtype=np.int64)
+        self._lib.check(self._d.ldbg_engine_assemble(self._h, _as_bytes(seed), C.c_int64(n), C.byref(ln), words.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p)))
+        out, cache = [], {}
+        for j in range(ln.value):
+            r = int(rec[j])
+            if r >= 0 and r not in cache:
+                cache[r] = self._graph.getRecord(r)
+            out.append(CortexVertex(CortexRecord(words[j], [0], [0], k).getKmerAsString(), cache.get(r)))
+        return out
+
+    def dfs_batch(self, sources, sinks=None):
+        """dfs(source, sinks...) for every source in one device launch; sinks: per source a list of k-mers (or None).
+        -> list of DfsGraph / None"""
+        n = len(sources)
+        batch = self.dfs_batch_arrays(*self._dfs_arrays(sources, sinks))
         return [batch.graph(i) for i in range(n)]
 
     def dfs_batch_arrays(self, src, n, sink_buf=None, sink_off=None):

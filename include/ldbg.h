@@ -293,11 +293,27 @@ ldbg_status ldbg_dfs_result_get(const ldbg_dfs_result* r, int64_t i,
 /* TraversalUtils.toWalk(g, seed, colour) + toContig on result i    TraversalUtils.java:367-488 */
 ldbg_status ldbg_dfs_result_walk(const ldbg_dfs_result* r, int64_t i, const char* seed, int color,
                                  char* contig, int64_t capacity, int64_t* len);
+/* dfs(Collection<String> sources, Collection<String> sinks)            TraversalEngine.java:37-62
+ * = ldbg_engine_dfs_batch with every source given all the sinks, then this: the graphs of results which[0..m) of `r` that are not null,
+ * merged in that order — the first as it is, each further one with Graphs.addGraph (vertices the merged graph does not hold yet; edges
+ * refused when an equal CortexEdge is present).  *out is a result with ONE graph (index 0; null when every source returned null). */
+ldbg_status ldbg_dfs_result_merge(struct ldbg_dfs_result* r, const int64_t* which, int64_t m, struct ldbg_dfs_result** out);
 ldbg_status ldbg_dfs_result_free(ldbg_dfs_result* r);
 ldbg_status ldbg_engine_dfs_kmers_traversed(const ldbg_engine* e, int64_t* n);
 
 /* cursor: seek / next / previous / hasNext / hasPrevious          TraversalEngine.java:241-339
  * (stateful, batch of one; each call runs on the device) */
+/* getNextVertices / getPrevVertices of n k-mers (n x k ASCII)            TraversalEngine.java:147-239
+ * as CSR: offsets[n+1]; vertex j: packed k-mer words kmer_words[j*W .. ], rec[j] (record index, -1 = null CortexRecord).  The vertices of
+ * one query come in the iteration order of the HashSet<CortexVertex> the reference returns.  capacity: vertices the arrays hold (4 n is
+ * always enough).  A k-mer without a record has no neighbours — NullPointerException (Q14) when recruitment colours are configured. */
+ldbg_status ldbg_engine_neighbours_batch(struct ldbg_engine* e, const char* kmers, int64_t n, int forward, int64_t* offsets,
+                                         uint64_t* kmer_words, int64_t* rec, int64_t capacity);
+/* assemble(seed)                                                        TraversalEngine.java:112-145
+ * seek(seed), next() while hasNext() and fewer than maxBranchLength vertices; the same with previous(); result in contig order:
+ * the previous() vertices (last one first), the seed's own vertex, the next() vertices.  *len = vertices; LDBG_ERR_CAPACITY with *len set
+ * when the arrays are too small (call with capacity 0 to learn the length). */
+ldbg_status ldbg_engine_assemble(struct ldbg_engine* e, const char* seed, int64_t capacity, int64_t* len, uint64_t* kmer_words, int64_t* rec);
 ldbg_status ldbg_engine_seek(ldbg_engine* e, const char* kmer);
 ldbg_status ldbg_engine_has_next(ldbg_engine* e, int* yes);
 ldbg_status ldbg_engine_has_previous(ldbg_engine* e, int* yes);

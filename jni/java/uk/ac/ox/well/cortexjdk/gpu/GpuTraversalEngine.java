@@ -4,6 +4,7 @@ import org.jgrapht.graph.DirectedWeightedPseudograph;
 import uk.ac.ox.well.cortexjdk.utils.exceptions.CortexJDKException;
 import uk.ac.ox.well.cortexjdk.utils.io.graph.cortex.CortexRecord;
 import uk.ac.ox.well.cortexjdk.utils.kmer.CanonicalKmer;
+import uk.ac.ox.well.cortexjdk.utils.kmer.CortexByteKmer;
 import uk.ac.ox.well.cortexjdk.utils.stoppingrules.TraversalStoppingRule;
 import uk.ac.ox.well.cortexjdk.utils.traversal.CortexEdge;
 import uk.ac.ox.well.cortexjdk.utils.traversal.CortexVertex;
@@ -16,6 +17,7 @@ import java.util.Collection;
 import java.util.LinkedHashMap;
 import java.util.List;
 import java.util.Map;
+import java.util.Set;
 
 import static uk.ac.ox.well.cortexjdk.utils.traversal.TraversalEngineConfiguration.GraphCombinationOperator.AND;
 import static uk.ac.ox.well.cortexjdk.utils.traversal.TraversalEngineConfiguration.TraversalDirection.BOTH;
@@ -107,6 +109,73 @@ public class GpuTraversalEngine {
         return dfsAll(java.util.Collections.singletonList(source), sk).get(0);
     }
 
+    /** dfs(Collection sources[, Collection sinks]) (TraversalEngine.java:37-62): every source towards all the sinks in ONE device launch, the
+     *  graphs that came back merged in source order (Graphs.addGraph) by the library */
+    public DirectedWeightedPseudograph<CortexVertex, CortexEdge> dfs(Collection<String> sources) { return dfs(sources, null); }
+    public DirectedWeightedPseudograph<CortexVertex, CortexEdge> dfs(Collection<String> sources, Collection<String> sinks) {
+        int n = sources.size(), m = sinks == null ? 0 : sinks.size();
+        if (n == 0) { return null; }
+        byte[] src = new byte[n * k];
+        int i = 0;
+        for (String s : sources) { System.arraycopy(s.getBytes(), 0, src, (i++) * k, k); }
+        byte[] sk = new byte[Math.max(1, n * m) * k];
+        long[] so = new long[n + 1];
+        for (i = 0; i < n; i++) {
+            int j = 0;
+            if (sinks != null) { for (String s : sinks) { System.arraycopy(s.getBytes(), 0, sk, (i * m + (j++)) * k, k); } }
+            so[i + 1] = (long) (i + 1) * m;
+        }
+        long res = dfsBatch(handle, src, n, sk, so);
+        long merged = 0;
+        try {
+            merged = dfsMerge(res, n);
+            return graphOf(merged, 0);
+        } finally {
+            if (merged != 0) { dfsFree(merged); }
+            dfsFree(res);
+        }
+    }
+
+    // ---- neighbourhood (TraversalEngine.java:147-239) and assemble (:112-145)
+    public Set<CortexVertex> getNextVertices(CortexByteKmer sk) { return neighbours(java.util.Collections.singletonList(new String(sk.getKmer())), true).get(0); }
+    public Set<CortexVertex> getPrevVertices(CortexByteKmer sk) { return neighbours(java.util.Collections.singletonList(new String(sk.getKmer())), false).get(0); }
+
+    /** getNextVertices / getPrevVertices of many k-mers in ONE device launch; every set iterates in the reference's HashSet order */
+    public List<Set<CortexVertex>> neighbours(List<String> kmers, boolean forward) {
+        int n = kmers.size();
+        byte[] flat = new byte[n * k];
+        for (int i = 0; i < n; i++) { System.arraycopy(kmers.get(i).getBytes(), 0, flat, i * k, k); }
+        long[] off = new long[n + 1], words = new long[Math.max(1, 4 * n) * w], rec = new long[Math.max(1, 4 * n)];
+        neighboursBatch(handle, flat, n, forward, off, words, rec);
+        int total = (int) off[n];
+        List<CortexVertex> all = makeVertices(total, words, rec, new int[Math.max(1, total)], new int[Math.max(1, total)]);
+        List<Set<CortexVertex>> out = new ArrayList<>(n);
+        for (int i = 0; i < n; i++) { out.add(new java.util.LinkedHashSet<>(all.subList((int) off[i], (int) off[i + 1]))); }
+        return out;
+    }
+
+    public List<CortexVertex> assemble(String seed) {
+        int n = (int) assemble(handle, seed.getBytes(), 0, null, null);
+        long[] words = new long[Math.max(1, n) * w], rec = new long[Math.max(1, n)];
+        assemble(handle, seed.getBytes(), n, words, rec);
+        return makeVertices(n, words, rec, new int[Math.max(1, n)], new int[Math.max(1, n)]);
+    }
+
+    private DirectedWeightedPseudograph<CortexVertex, CortexEdge> graphOf(long res, long i) {
+        long[] sz = dfsSizes(res, i);
+        if (sz[0] != 0) { return null; }
+        int nv = (int) sz[1], ne = (int) sz[2];
+        long[] words = new long[Math.max(1, nv) * w], rec = new long[Math.max(1, nv)];
+        int[] copy = new int[Math.max(1, nv)], index = new int[Math.max(1, nv)];
+        int[] es = new int[Math.max(1, ne)], ed = new int[Math.max(1, ne)], ecol = new int[Math.max(1, ne)];
+        dfsGet(res, i, words, rec, copy, index, es, ed, ecol);
+        List<CortexVertex> vs = makeVertices(nv, words, rec, copy, index);
+        DirectedWeightedPseudograph<CortexVertex, CortexEdge> g = new DirectedWeightedPseudograph<>(CortexEdge.class);
+        for (CortexVertex v : vs) { g.addVertex(v); }
+        for (int e = 0; e < ne; e++) { g.addEdge(vs.get(es[e]), vs.get(ed[e]), new CortexEdge(vs.get(es[e]), vs.get(ed[e]), ecol[e], 1.0)); }
+        return g;
+    }
+
     /** dfs(source, sinks...) for many sources in ONE device launch; null entries where the reference returns null */
     public List<DirectedWeightedPseudograph<CortexVertex, CortexEdge>> dfsAll(List<String> sources, List<String[]> sinks) {
         int n = sources.size();
@@ -184,6 +253,9 @@ public class GpuTraversalEngine {
     private static native String dfsWalk(long res, long i, byte[] seed, int color);
     private static native void dfsFree(long res);
     private static native long dfsKmersTraversed(long h);
+    private static native long dfsMerge(long res, int n);
+    private static native void neighboursBatch(long h, byte[] kmers, int n, boolean forward, long[] offsets, long[] words, long[] rec);
+    private static native long assemble(long h, byte[] seed, long capacity, long[] words, long[] rec);
 
     /** toContig(toWalk(g, seed, colour)) of a dfs result computed on the library side (used by gap-closing callers) */
     public static String dfsContig(long res, long i, String seed, int color) { return dfsWalk(res, i, seed.getBytes(), color); }

@@ -292,6 +292,53 @@ jlong JNIFN(GpuTraversalEngine, dfsBatch)(JNIEnv* env, jclass c, jlong h, jbyteA
     if (st != LDBG_OK) { rethrow(env, st); return 0; }
     return (jlong)(intptr_t)r;
 }
+/* dfs(Collection<String> sources, Collection<String> sinks) (TraversalEngine.java:37-62): results 0 .. n-1 of `res` merged in that order
+ * with Graphs.addGraph -> a result handle holding ONE graph (index 0) */
+jlong JNIFN(GpuTraversalEngine, dfsMerge)(JNIEnv* env, jclass c, jlong res, jint n) {
+    int64_t* which = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * 8);
+    for (jint i = 0; i < n; i++) which[i] = i;
+    ldbg_dfs_result* out = NULL;
+    ldbg_status st = ldbg_dfs_result_merge(R(res), which, n, &out);
+    free(which);
+    if (st != LDBG_OK) { rethrow(env, st); return 0; }
+    return (jlong)(intptr_t)out;
+}
+/* getNextVertices / getPrevVertices (TraversalEngine.java:147-239) of n k-mers: offsets[n+1]; words[4 n W], rec[4 n] filled up to offsets[n] */
+void JNIFN(GpuTraversalEngine, neighboursBatch)(JNIEnv* env, jclass c, jlong h, jbyteArray kmers, jint n, jboolean forward, jlongArray offsets, jlongArray words, jlongArray rec) {
+    jbyte* km = (*env)->GetByteArrayElements(env, kmers, NULL);
+    jlong* off = (*env)->GetLongArrayElements(env, offsets, NULL);
+    jlong* w = (*env)->GetLongArrayElements(env, words, NULL);
+    jlong* r = (*env)->GetLongArrayElements(env, rec, NULL);
+    ldbg_status st = ldbg_engine_neighbours_batch(E(h), (const char*)km, n, forward ? 1 : 0, (int64_t*)off, (uint64_t*)w, (int64_t*)r, 4 * (int64_t)n);
+    (*env)->ReleaseByteArrayElements(env, kmers, km, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, offsets, off, 0);
+    (*env)->ReleaseLongArrayElements(env, words, w, 0);
+    (*env)->ReleaseLongArrayElements(env, rec, r, 0);
+    if (st != LDBG_OK) rethrow(env, st);
+}
+/* assemble(seed) (TraversalEngine.java:112-145): returns the number of vertices; with arrays of that capacity fills words (len x W) and rec */
+jlong JNIFN(GpuTraversalEngine, assemble)(JNIEnv* env, jclass c, jlong h, jbyteArray seed, jlong capacity, jlongArray words, jlongArray rec) {
+    jsize k = (*env)->GetArrayLength(env, seed);
+    char* sd = (char*)malloc((size_t)k + 1);
+    (*env)->GetByteArrayRegion(env, seed, 0, k, (jbyte*)sd);
+    sd[k] = 0;
+    int64_t len = 0;
+    ldbg_status st;
+    if (capacity <= 0 || !words) {
+        st = ldbg_engine_assemble(E(h), sd, 0, &len, NULL, NULL);
+        free(sd);
+        if (st != LDBG_OK && st != LDBG_ERR_CAPACITY) { rethrow(env, st); return -1; }
+        return len;
+    }
+    jlong* w = (*env)->GetLongArrayElements(env, words, NULL);
+    jlong* r = (*env)->GetLongArrayElements(env, rec, NULL);
+    st = ldbg_engine_assemble(E(h), sd, capacity, &len, (uint64_t*)w, (int64_t*)r);
+    free(sd);
+    (*env)->ReleaseLongArrayElements(env, words, w, 0);
+    (*env)->ReleaseLongArrayElements(env, rec, r, 0);
+    if (st != LDBG_OK) { rethrow(env, st); return -1; }
+    return len;
+}
 /* {isNull, vertices, edges} of result i */
 jlongArray JNIFN(GpuTraversalEngine, dfsSizes)(JNIEnv* env, jclass c, jlong res, jlong i) {
     int is_null = 1; int64_t nv = 0, ne = 0;

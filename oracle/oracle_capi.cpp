@@ -254,6 +254,36 @@ void* orc_engine_dfs(void* ep, const char* source, const char** sinks, int nsink
     });
     return r;
 }
+// dfs(Collection<String> sources, Collection<String> sinks) (TraversalEngine.java:37-62): the first graph that comes back as it is, every
+// further one merged into it with Graphs.addGraph
+void* orc_engine_dfs_collection(void* ep, const char** sources, int nsources, const char** sinks, int nsinks, int* status) {
+    DfsResult* r = nullptr;
+    *status = guard([&] {
+        std::vector<std::string> s(sinks, sinks + nsinks);
+        auto& e = ((Engine*)ep)->e;
+        std::unique_ptr<PGraph> dfs;
+        for (int i = 0; i < nsources; i++) {
+            auto g = e.dfs(sources[i], s);
+            if (!g) continue;
+            if (!dfs) dfs = std::move(g);
+            else dfs->add_graph(*g);
+        }
+        r = new DfsResult{std::move(dfs), e.config().graph->k};
+        return 0;
+    });
+    return r;
+}
+// getNextVertices / getPrevVertices (TraversalEngine.java:147-239) in the HashSet's iteration order; kmers_out: cap x k bytes
+int orc_engine_adjacent(void* ep, const char* kmer, int forward, char* kmers_out, int64_t* rec_out, int cap, int* n_out) {
+    return guard([&] {
+        auto& e = ((Engine*)ep)->e;
+        std::vector<Vertex> vs = forward ? e.next_vertices(kmer) : e.prev_vertices(kmer);
+        *n_out = (int)vs.size();
+        const size_t k = (size_t)e.config().graph->k;
+        for (size_t i = 0; i < vs.size() && (int)i < cap; i++) { memcpy(kmers_out + i * k, vs[i].sk.data(), k); rec_out[i] = vs[i].rec; }
+        return 0;
+    });
+}
 int orc_result_is_null(void* rp) { return ((DfsResult*)rp)->g ? 0 : 1; }
 int64_t orc_result_num_vertices(void* rp) { auto* r = (DfsResult*)rp; return r->g ? (int64_t)r->g->verts.size() : 0; }
 int64_t orc_result_num_edges(void* rp) { auto* r = (DfsResult*)rp; return r->g ? (int64_t)r->g->edges.size() : 0; }

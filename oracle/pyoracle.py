@@ -363,6 +363,46 @@ class Engine:
         _check(st.value)
         return DfsResult(self, h)
 
+    def dfs_collection(self, sources, sinks=()):
+        """dfs(Collection<String> sources, Collection<String> sinks) (TraversalEngine.java:37-62)"""
+        so = [_b(s) for s in sources]
+        sk = [_b(s) for s in sinks]
+        a1 = (C.c_char_p * max(1, len(so)))(*so)
+        a2 = (C.c_char_p * max(1, len(sk)))(*sk)
+        st = C.c_int()
+        lib().orc_engine_dfs_collection.restype = C.c_void_p
+        h = lib().orc_engine_dfs_collection(C.c_void_p(self.h), a1, len(so), a2, len(sk), C.byref(st))
+        _check(st.value)
+        return DfsResult(self, h)
+
+    def _adjacent(self, kmer, forward):
+        k = self.graph.k
+        buf = np.zeros((8, k), dtype=np.uint8)
+        rec = np.zeros(8, dtype=np.int64)
+        n = C.c_int()
+        _check(lib().orc_engine_adjacent(C.c_void_p(self.h), _b(kmer), 1 if forward else 0, buf.ctypes.data_as(C.c_char_p),
+                                         rec.ctypes.data_as(C.POINTER(C.c_int64)), 8, C.byref(n)))
+        return [(buf[i].tobytes().decode(), int(rec[i])) for i in range(n.value)]
+
+    def next_vertices(self, kmer):
+        """getNextVertices (TraversalEngine.java:195-239) -> [(kmer, record index or -1)] in HashSet iteration order"""
+        return self._adjacent(kmer, True)
+
+    def prev_vertices(self, kmer):
+        return self._adjacent(kmer, False)
+
+    def assemble(self, seed, max_length):
+        """assemble(seed) (TraversalEngine.java:112-145) over the cursor -> [(kmer, record index or -1)] in contig order"""
+        rec, _, _ = self.graph.find(seed)
+        fw, rv = [], []
+        self.seek(seed)
+        while self.has_next() and len(fw) < max_length:
+            fw.append(self.next())
+        self.seek(seed)
+        while self.has_previous() and len(rv) < max_length:
+            rv.insert(0, self.previous())
+        return rv + [(seed, rec)] + fw
+
     def close(self):
         if self.h:
             lib().orc_engine_destroy(C.c_void_p(self.h))

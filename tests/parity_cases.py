@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import corticall_amd as ca
+from corticall_amd._native import JavaNullPointerException
 from corticall_amd import (AND, BOTH, FORWARD, OR, REVERSE, ContigStopper, CortexGraph, CortexLinks,
                            TraversalEngineFactory, TraversalUtils)
 
@@ -1013,6 +1014,81 @@ def case_findtips(orc, lib, tmp, k, seed, with_links):
         a, b = tg.getRecord(j), roi.getRecord(i)
         assert a.getKmerAsString() == b.getKmerAsString() and list(a.getCoverages()) == list(b.getCoverages()) and list(a.getEdges()) == list(b.getEdges())
     tg.close(); roi.close(); oroi.close()
+
+
+# ------------------------------------------------------------------ façade members beside walk / dfs(source, sinks)
+def case_facade(orc, lib, tmp, k, seed, with_links):
+    """getNextVertices / getPrevVertices (TraversalEngine.java:147-239: vertices in HashSet iteration order), assemble (:112-145) and
+    dfs(Collection<String> sources, Collection<String> sinks) (:37-62: Graphs.addGraph merges in source order) against the oracle"""
+    rng = random.Random(7700 + 31 * seed + k)
+    base = genome_with_repeats(rng, 1500, n_rep=5, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+    kid = mutate(rng, base, snv=0.015, indel=0.003)
+    dad = mutate(rng, base, snv=0.02, indel=0.003)
+    cs = Case(orc, tmp, lib, [("kid", [kid]), ("mom", [base]), ("dad", [dad])], k, link_samples=(["kid"] if with_links else []),
+              reads={"kid": [kid[i:i + 4 * k] for i in range(0, max(1, len(kid) - 4 * k), k)] + [kid[-4 * k:]]} if with_links else None,
+              name="fac%d_%d_%d" % (k, seed, int(with_links)))
+    kmers = cs.all_kmers()
+    qs = rng.sample(kmers, min(len(kmers), 250))
+    qs = [q if rng.random() < 0.5 else orc.revcomp(q) for q in qs] + [rand_seq(rng, k) for _ in range(10)] + ["N" * k, kid[:k], kid[-k:]]
+    for trav, recruit in (([0], ()), ([1, 0], ()), ([2], (0, 1))):
+        oe = orc.Engine(cs.og, trav, links=[cs.olinks["kid"]] if with_links else [], recruitment_colors=recruit, stopper="ContigStopper")
+        f = TraversalEngineFactory(lib=lib).traversalColors(*trav).graph(cs.g).stoppingRule(ContigStopper)
+        if recruit:
+            f.recruitmentColors(*recruit)
+        if with_links:
+            f.links(cs.links["kid"])
+        e = f.make()
+        use = [q for q in qs if not recruit or cs.og.find(q)[0] >= 0]       # (recruitment colours + a k-mer without a record: NullPointerException, below)
+        for fwd in (True, False):
+            got = e.neighbours_batch(use, fwd)
+            for q, vs in zip(use, got):
+                exp = oe.next_vertices(q) if fwd else oe.prev_vertices(q)
+                have = [(v.getKmerAsString(), v.getCortexRecord().index if v.getCortexRecord() is not None else -1) for v in vs]
+                assert have == exp, (trav, recruit, fwd, q, have, exp)
+        assert [v.getKmerAsString() for v in e.getNextVertices(use[0])] == [x[0] for x in oe.next_vertices(use[0])]
+        assert e.neighbours_batch([], True) == []
+        if recruit:
+            with pytest.raises(JavaNullPointerException):
+                e.getPrevVertices(rand_seq(rng, k))
+            with pytest.raises(orc.OracleError):
+                oe.prev_vertices(rand_seq(rng, k))
+        e.close()
+    # assemble: with the cursor's link store when links are bound; maxBranchLength cuts both directions
+    for max_len in (75000, 7):
+        oe = orc.Engine(cs.og, [0], links=[cs.olinks["kid"]] if with_links else [], stopper="ContigStopper", max_length=max_len)
+        f = TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).stoppingRule(ContigStopper).maxBranchLength(max_len)
+        if with_links:
+            f.links(cs.links["kid"])
+        e = f.make()
+        for sd in rng.sample(kmers, 12) + [orc.revcomp(kmers[3]), rand_seq(rng, k)]:
+            exp = oe.assemble(sd, max_len)
+            got = [(v.getKmerAsString(), v.getCortexRecord().index if v.getCortexRecord() is not None else -1) for v in e.assemble(sd)]
+            assert got == exp, (max_len, sd, len(got), len(exp))
+        e.close()
+    # dfs over collections: sources a few hundred bases apart towards common sinks; the merged graph vertex by vertex, edge by edge
+    for stopper, direction, max_len in (("DestinationStopper", FORWARD, 300), ("ExplorationStopper", BOTH, 60), ("ContigStopper", BOTH, 75000)):
+        oe = orc.Engine(cs.og, [0], links=[cs.olinks["kid"]] if with_links else [], stopper=stopper, direction=direction, max_length=max_len)
+        f = TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).stoppingRule(stopper).traversalDirection(direction).maxBranchLength(max_len)
+        if with_links:
+            f.links(cs.links["kid"])
+        e = f.make()
+        for _ in range(4):
+            p0 = rng.randrange(0, len(kid) - 8 * k - 200)
+            sources = [kid[p0 + d:p0 + d + k] for d in (0, k // 2, 3 * k, 3 * k)] + [rand_seq(rng, k)]      # overlapping searches, a repeated source, one that returns null
+            sinks = [kid[p0 + 5 * k + 40:p0 + 6 * k + 40], kid[p0 + 7 * k + 90:p0 + 8 * k + 90]]
+            r = oe.dfs_collection(sources, sinks)
+            g = e.dfs(sources, sinks)
+            assert (g is None) == r.is_null, (stopper, sources)
+            if g is not None:
+                assert g.vertex_tuples() == r.vertices() and g.edge_tuples() == r.edges(), (stopper, p0, g.nv, r.nv)
+            r.free()
+        lone = [rand_seq(rng, k)]
+        r = oe.dfs_collection(lone, [])
+        g = e.dfs(lone, [])
+        assert (g is None) == r.is_null and (g is None or (g.vertex_tuples() == r.vertices() and g.edge_tuples() == r.edges()))
+        r.free()
+        assert e.dfs([], sinks) is None
+        e.close()
 
 
 # ------------------------------------------------------------------ Partition (the seed loop around the walks)

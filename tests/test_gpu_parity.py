@@ -117,6 +117,10 @@ def test_partition(orc, lib, tmp_path, k, seed, links): pc.case_partition(orc, l
 def test_findtips(orc, lib, tmp_path, k, seed, links): pc.case_findtips(orc, lib, tmp_path, k, seed, links)
 
 
+@pytest.mark.parametrize("k,seed,links", [(21, 1, False), (31, 2, True), (47, 3, True), (32, 4, False)])
+def test_facade(orc, lib, tmp_path, k, seed, links): pc.case_facade(orc, lib, tmp_path, k, seed, links)
+
+
 def test_sharded_find_one_rank_rccl(orc, lib, tmp_path):
     """the exchange path of corticall_amd/distributed.py over RCCL with device buffers (one rank: this box has one GPU;
     the two-rank case runs on gloo in tests/test_distributed.py)"""

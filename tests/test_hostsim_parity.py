@@ -112,6 +112,10 @@ def test_partition(orc, lib, tmp_path, k, seed, links): pc.case_partition(orc, l
 def test_findtips(orc, lib, tmp_path, k, seed, links): pc.case_findtips(orc, lib, tmp_path, k, seed, links)
 
 
+@pytest.mark.parametrize("k,seed,links", [(21, 1, False), (31, 2, True), (47, 3, True), (32, 4, False)])
+def test_facade(orc, lib, tmp_path, k, seed, links): pc.case_facade(orc, lib, tmp_path, k, seed, links)
+
+
 def test_batch_splitting_on_a_small_device(orc, lib, tmp_path, monkeypatch):
     """3 MB of "device memory": the path / table pools run dry, the host splits the batch and re-runs — results stay exact"""
     monkeypatch.setenv("LDBG_HOSTSIM_MEM_MB", "3")

@@ -18,6 +18,7 @@ NEEDED = [
     "ldbg_engine_config_default", "ldbg_engine_create", "ldbg_engine_destroy",
     "ldbg_engine_walk_batch_run", "ldbg_engine_walk_batch_fetch", "ldbg_engine_walk_vertices", "ldbg_engine_walk_roi_hits",
     "ldbg_engine_dfs_batch", "ldbg_dfs_result_sizes", "ldbg_dfs_result_get", "ldbg_dfs_result_walk", "ldbg_dfs_result_free", "ldbg_engine_dfs_kmers_traversed",
+    "ldbg_dfs_result_merge", "ldbg_engine_neighbours_batch", "ldbg_engine_assemble",
     "ldbg_engine_seek", "ldbg_engine_has_next", "ldbg_engine_has_previous", "ldbg_engine_next", "ldbg_engine_previous",
 ]
 
@@ -62,5 +63,5 @@ def test_every_native_method_has_its_definition():
     for method in ("getFile", "size", "isEmpty", "containsKey", "get", "getHeader", "getSource"):
         assert re.search(r"public [\w<>\[\], ]+ %s\(" % method, l), method
     e = open(os.path.join(JAVA, "GpuTraversalEngine.java")).read()
-    for method in ("getConfiguration", "dfs", "walk", "next", "previous", "seek", "hasNext", "hasPrevious"):
+    for method in ("getConfiguration", "dfs", "walk", "next", "previous", "seek", "hasNext", "hasPrevious", "getNextVertices", "getPrevVertices", "assemble"):
         assert re.search(r"public [\w<>\[\], ]+ %s\(" % method, e), method

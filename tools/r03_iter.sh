@@ -11,3 +11,7 @@ LDBG_DIAG_LIB=1 LDBG_WG_TIMES=1 python3 bench.py --steps 2 --warmup 1 --no-cpu-b
 echo "== shipped build" >> $O
 python3 bench.py --steps 10 --warmup 3 --cpu-seconds 6 >> $O 2>&1
 echo done >> $O
+if [ -n "$2" ]; then
+  python3 -m pytest tests/test_gpu_sharded_fullsize.py -x -q -m gpu --durations=10 > gpurun_out/r03_${T}_gates.log 2>&1 || true
+  tail -25 gpurun_out/r03_${T}_gates.log >> $O
+fi
