@@ -340,6 +340,52 @@ LDBG_HOSTDEV void node_from_entry(const EngineView& e, VisitedTable& t, const No
         n.vslot = vt_probe_from(t, key, h, e0, &n.vent);
     }
 }
+// node_from_entry<true> in two halves, so that the rows of SEVERAL vertices are in flight together (the run step reads two fringe
+// vertices and a table entry that do not depend on each other: three trips to memory one after the other, or one).
+// issue: every load the vertex needs — its row (neighbour index, edge and flag bytes), its run-index entry, the first probe round
+// of its table slot.  finish: the rest.  A probe round read before ANOTHER vertex claimed a slot may be stale: `claimed` names
+// the slots claimed since (0xFFFFFFFF = none); a round that covers one of them is read again.
+struct NodeLoad {
+    uint32_t nb[8];
+    uint32_t ef, h;
+    uint64_t ui, key;
+    VtPeek e0;
+    int32_t idx;
+    bool flip;
+};
+LDBG_HOSTDEV void node_issue_lean(const EngineView& e, const VisitedTable& t, bool parent_fj, uint32_t ent, NodeLoad& L) {
+    const GraphView& g = e.g;
+    L.idx = (int32_t)(ent & 0x7FFFFFFFu) - 1;
+    L.flip = (((ent >> 31) & 1u) != 0) != parent_fj;
+    L.key = vt_key(L.idx, L.flip);
+    L.h = vt_hash(L.key) & t.mask;
+    L.e0 = vt_peek(t, L.h);
+    L.ui = e.runs.uinfo ? LDBG_GLOBAL(const uint64_t, e.runs.uinfo)[L.idx] : 0ull;
+    const uint8_t* row = graph_row(g, L.idx);
+    struct alignas(16) U4 { uint32_t x, y, z, w; };
+    const U4 a = *(const U4*)(row + g.nbr_off), b = *(const U4*)(row + g.nbr_off + 16);
+    L.ef = *(const uint32_t*)(row + g.edges_off);
+    L.nb[0] = a.x; L.nb[1] = a.y; L.nb[2] = a.z; L.nb[3] = a.w; L.nb[4] = b.x; L.nb[5] = b.y; L.nb[6] = b.z; L.nb[7] = b.w;
+}
+LDBG_HOSTDEV bool vt_round_covers(const VisitedTable& t, uint32_t h, uint32_t slot) { return slot != 0xFFFFFFFFu && ((slot - h) & t.mask) < 4u; }
+LDBG_HOSTDEV void node_finish_lean(const EngineView& e, VisitedTable& t, const NodeLoad& L, unsigned base, bool fwd, Node& n, uint32_t claimed0 = 0xFFFFFFFFu,
+                                   uint32_t claimed1 = 0xFFFFFFFFu) {
+    const GraphView& g = e.g;
+    n.idx = L.idx;
+    n.copy = 0; n.vslot = 0; n.vent = 0; n.base = (uint8_t)base; n.e1 = 0; n.ent1 = 0;
+    n.flip = L.flip ? 1 : 0;
+    node_fill_bytes<true>(e, n, L.ef & ((1u << (8 * g.C)) - 1u), nullptr, (uint8_t)(L.ef >> (8 * g.C)));
+    n.ui = L.ui;
+    const uint32_t m = fwd ? n.next_mask : n.prev_mask;
+    const unsigned j = nbr_slot(n.fj != 0, fwd, lowbit4(m));
+    uint32_t v = L.nb[0];
+#pragma unroll
+    for (unsigned q = 1; q < 8; q++) v = j == q ? L.nb[q] : v;
+    const bool one = popc4(m) == 1;
+    n.ent1 = one ? v : 0u; n.e1 = one ? 1 : 0;
+    const bool stale = vt_round_covers(t, L.h, claimed0) || vt_round_covers(t, L.h, claimed1);
+    n.vslot = vt_probe_from(t, L.key, L.h, stale ? vt_peek(t, L.h) : L.e0, &n.vent);
+}
 LDBG_HOSTDEV void node_child_located(const EngineView& e, VisitedTable& t, const Node& p, bool fwd, unsigned base, Node& n) {
     node_from_entry(e, t, p, node_child_entry(e, p, fwd, base), base, fwd, n);
 }

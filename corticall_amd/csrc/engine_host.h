@@ -145,7 +145,8 @@ private:
     void launch_expand_paths(const uint32_t* d_strand_c, const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks, const RunIndexView& runs,
                              unsigned* d_overflow);
     void ensure_run_index();           // the run index of this engine's colour masks (runs.h), built on first use
-    void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks, uint64_t table_floor = 0);   // table_floor: entries the table pool holds at least
+    void ensure_scratch(int64_t n_strands, uint32_t ecap, int max_blocks, uint64_t table_floor = 0, bool small = false);
+    uint64_t scratch_scale_ = 1, scratch_scale_built_ = 1; bool scratch_full_ = true; int64_t pool_growths_ = 0;   // walk.cpp: pools start small with the run index   // table_floor: entries the table pool holds at least
     uint64_t table_floor_ = 0;
     void* h_stage_[2] = {nullptr, nullptr};              // page-locked staging buffers of downloads into pageable memory (walk.cpp: download)
     void download(char* dst, const void* d_src, size_t bytes);

@@ -400,9 +400,11 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
     const bool flagged = cur_mode && (st.cu.nxt.lflags & e.link_flag_mask);
     uint64_t m_cur = ~0ull, m_nxt = ~0ull;
     uint32_t child_ent = 0;
-    if (flagged) m_nxt = e.links.rec_of[st.cu.nxt.idx];
+    // the range of a flagged vertex's junction records: with a run index it came with the vertex (runs.cpp: k_run_link_info), else one more load
+    const bool in_ui = e.runs.uinfo != nullptr;
+    if (flagged) m_nxt = in_ui ? (st.cu.nxt.ui ? st.cu.nxt.ui : ~0ull) : e.links.rec_of[st.cu.nxt.idx];
     if (one_child) child_ent = st.cu.nxt.e1 ? st.cu.nxt.ent1 : node_child_entry(e, st.cu.nxt, st.fwd, lowbit4(nmask));
-    if (cur_mode && st.cu.first && (st.cu.cur.lflags & e.link_flag_mask)) m_cur = e.links.rec_of[st.cu.cur.idx];
+    if (cur_mode && st.cu.first && (st.cu.cur.lflags & e.link_flag_mask)) m_cur = in_ui ? (st.cu.cur.ui ? st.cu.cur.ui : ~0ull) : e.links.rec_of[st.cu.cur.idx];
     pre.links_done = true; pre.choice_done = false; pre.choice_ok = false; pre.ch = 0; pre.n_added = 0;
     // deal the owners' junction records out to the lanes (cur's records first, then nxt's: the order of the adds), one load for all
     const unsigned long long owners = wave_ballot(m_cur != ~0ull || m_nxt != ~0ull);

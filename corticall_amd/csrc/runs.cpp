@@ -138,6 +138,20 @@ LDBG_KERNEL void k_run_assign(EngineView e, int64_t n2, const unsigned long long
     }
 }
 
+// A link-flagged record is a chain of its own (run_breaker), and nothing asks for its position (every use tests ui_valid first and treats an
+// invalid entry as "in no stretch", which is what a single vertex is).  Its entry is free, then, to carry what the step onto such a vertex
+// needs next: the range of its junction records in the merged link table (links.h: rec_of, first | count << 32; bit 63 clear, 0 = none).
+// The entry comes with the row (engine.h: node_from_entry reads both in one trip), so the link-store phase of a step starts its
+// junction-record load without the rec_of trip in front of it.
+LDBG_KERNEL void k_run_link_info(EngineView e, int64_t N, uint64_t* uinfo) {
+    for (int64_t i = global_tid(); i < N; i += global_nthreads()) {
+        const uint8_t fl = graph_row(e.g, i)[e.g.flags_off];
+        if (!(fl & e.link_flag_mask)) continue;
+        const uint64_t m = e.links.rec_of[i];
+        uinfo[i] = m == ~0ull ? 0ull : (m & ~(1ull << 63));
+    }
+}
+
 int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
 
 }  // namespace
@@ -205,6 +219,7 @@ RunIndex::RunIndex(const EngineView& e, int device, rt::stream_t s) {
             default: RUN_ASSIGN(4); break;
         }
 #undef RUN_ASSIGN
+        if (e.link_flag_mask && e.links.rec_of) LDBG_LAUNCH(k_run_link_info, grid_for(N), 256, s, e, N, (uint64_t*)d_uinfo_);
         unsigned long long st[4] = {0, 0, 0, 0};
         rt::d2h(st, stats, 32, s);
         e1.record(s);

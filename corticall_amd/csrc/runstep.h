@@ -209,12 +209,34 @@ LDBG_DEV bool run_step(const WalkArgs& a, StrandState& st, LinkStoreDev& ls, Run
     // the far fringe and the interior's entry
     Node y, z;
     const uint32_t used0 = st.vt.used;
-    run_vertex(e, st.vt, pc.asc ? pc.E - 1u : pc.S + 1u, inv, fwd, y);
-    run_vertex(e, st.vt, pc.asc ? pc.E : pc.S, inv, fwd, z);
     uint64_t eB = 0;
     const uint64_t kB = piece_key(pc);
     const uint32_t hB = vt_hash(kB) & st.vt.mask;
-    const uint32_t slotB = vt_probe_from(st.vt, kB, hB, vt_peek(st.vt, hB), &eB);
+    uint32_t slotB;
+    if (e.lean_rows) {
+        // all three in flight together (engine.h: node_issue_lean): the two positions of the run index, then both rows with their table
+        // rounds and the piece entry's round — two trips to memory where the vertex-by-vertex code makes five
+        const uint32_t py = pc.asc ? pc.E - 1u : pc.S + 1u, pz = pc.asc ? pc.E : pc.S;
+        const uint32_t uy = LDBG_GLOBAL(const uint32_t, e.runs.uo)[py], uz = LDBG_GLOBAL(const uint32_t, e.runs.uo)[pz];
+        const unsigned by = LDBG_GLOBAL(const uint8_t, e.runs.ubase)[py], bz = LDBG_GLOBAL(const uint8_t, e.runs.ubase)[pz];
+        const VtPeek pB = vt_peek(st.vt, hB);
+        NodeLoad ly, lz;
+        node_issue_lean(e, st.vt, false, ((uy & 0x7FFFFFFFu) + 1u) | ((((uy >> 31) != 0u) != inv) ? 0x80000000u : 0u), ly);
+        node_issue_lean(e, st.vt, false, ((uz & 0x7FFFFFFFu) + 1u) | ((((uz >> 31) != 0u) != inv) ? 0x80000000u : 0u), lz);
+        auto travel_base = [&](unsigned bb) { const unsigned first = !inv ? (bb & 3u) : 3u - ((bb >> 2) & 3u), last = !inv ? ((bb >> 2) & 3u) : 3u - (bb & 3u); return fwd ? last : first; };
+        uint32_t u0 = st.vt.used;
+        node_finish_lean(e, st.vt, ly, travel_base(by), fwd, y);
+        const uint32_t cy = st.vt.used != u0 ? y.vslot : 0xFFFFFFFFu;        // a slot y has just claimed: rounds read before may not show it
+        u0 = st.vt.used;
+        node_finish_lean(e, st.vt, lz, travel_base(bz), fwd, z, cy);
+        const uint32_t cz = st.vt.used != u0 ? z.vslot : 0xFFFFFFFFu;
+        const bool staleB = vt_round_covers(st.vt, hB, cy) || vt_round_covers(st.vt, hB, cz);
+        slotB = vt_probe_from(st.vt, kB, hB, staleB ? vt_peek(st.vt, hB) : pB, &eB);
+    } else {
+        run_vertex(e, st.vt, pc.asc ? pc.E - 1u : pc.S + 1u, inv, fwd, y);
+        run_vertex(e, st.vt, pc.asc ? pc.E : pc.S, inv, fwd, z);
+        slotB = vt_probe_from(st.vt, kB, hB, vt_peek(st.vt, hB), &eB);
+    }
     rs.seen_marks += st.vt.used - used0;
     const int cntB = vt_count_e(eB), cntY = vt_count_e(y.vent);
     const int64_t allowed = (int64_t)e.max_len - (int64_t)st.gV + 1;          // iterations that can still append a vertex

@@ -963,9 +963,14 @@ uint32_t vt_initial_entries() {
     return v;
 }
 
-void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks, uint64_t table_floor) {
+void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks, uint64_t table_floor, bool small) {
     rt::stream_t s = graph->stream;
-    if (d_vpool_ && ecap_ == ecap && max_blocks_ == max_blocks && bt_strands_ >= ns && table_floor_ >= table_floor) return;
+    // small: the pools of a walk with the run index — a strand's table holds fringes and junction vertices, its path a few descriptors per
+    // stretch — start at a fraction of the worst case (reserving the worst case was 200 GB of hipMalloc: 1.8 s of a 3.7 s first batch)
+    // and are enlarged x4 by walk_batch_run when a batch does run out (ST_POOL_FULL: the batch is walked again, nothing is traded)
+    const uint64_t small_v = (uint64_t)ns * 1024ull * scratch_scale_, small_b = (uint64_t)ns * 2ull * scratch_scale_;
+    const bool reusable = d_vpool_ && ecap_ == ecap && max_blocks_ == max_blocks && bt_strands_ >= ns && table_floor_ >= table_floor;
+    if (reusable && (scratch_full_ || (small && scratch_scale_ == scratch_scale_built_))) return;
     release_scratch();
     size_t free_b = 0, total_b = 0;
     rt::mem_info(&free_b, &total_b);
@@ -973,9 +978,12 @@ void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks, uint64_t 
     // memory split: 40% of what is free for the visited-table pool, 35% for the path pool (both capped by need)
     const uint64_t vcap_max = next_pow2(2ull * (uint64_t)(cfg.max_branch_length + 12));
     uint64_t want_v = std::max<uint64_t>((uint64_t)ns * vt_series(vt_initial_entries(), vcap_max), table_floor) + LDBG_VT_INITIAL;
+    uint64_t want_blocks = (uint64_t)ns * (uint64_t)max_blocks;
+    scratch_full_ = !small || (small_v >= want_v && small_b >= want_blocks);
+    if (small) { want_v = std::min<uint64_t>(want_v, std::max<uint64_t>(small_v, table_floor) + LDBG_VT_INITIAL); want_blocks = std::min<uint64_t>(want_blocks, std::max<uint64_t>(small_b, 2)); }
+    scratch_scale_built_ = scratch_scale_;
     vpool_entries_ = std::max<uint64_t>(LDBG_VT_INITIAL * 2, std::min<uint64_t>(want_v, (uint64_t)(free_b * 0.40) / 8));
     table_floor_ = table_floor;
-    uint64_t want_blocks = (uint64_t)ns * (uint64_t)max_blocks;
     n_blocks_ = std::max<uint64_t>(2, std::min<uint64_t>(want_blocks, (uint64_t)(free_b * 0.35) / (LDBG_PATH_BLOCK * 8)));
     d_vpool_ = rt::dmalloc((size_t)vpool_entries_ * 8);
     d_ls_ = rt::dmalloc((size_t)slots * ecap * sizeof(LsElem));
@@ -1023,7 +1031,11 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
         WalkChunk c;
         int64_t t = 0;
         if (run_chunk(words, first, cnt, c, &t)) { trav += t; chunks.push_back(std::move(c)); }
-        else {
+        else if (!scratch_full_ && scratch_scale_ < (1ull << 24)) {
+            scratch_scale_ *= 4;                          // the small pools of a run-index walk were too small for this batch: enlarge, walk it again
+            pool_growths_++;
+            todo.push_back({first, cnt});
+        } else {
             if (cnt == 1) throw StatusError(LDBG_ERR_HIP, "path pool too small for a single walk: not enough device memory");
             todo.push_back({first + cnt / 2, cnt - cnt / 2});
             todo.push_back({first, cnt / 2});
@@ -1099,7 +1111,8 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
     r.max_blocks = (int)(((int64_t)cfg.max_branch_length + 2 + LDBG_PATH_BLOCK - 1) / LDBG_PATH_BLOCK);
     WALKRUN_ALIASES(r);
     HostLaps laps;
-    ensure_scratch(ns, link_store_capacity, max_blocks);
+    const bool lean_pools = !img && (view.g.k & 1) && !getenv("LDBG_NO_RUNS") && !getenv("LDBG_VT_INITIAL") && !getenv("LDBG_FULL_POOLS");
+    ensure_scratch(ns, link_store_capacity, max_blocks, 0, lean_pools);
     zero_dirty_tables(s);
     laps.lap("scratch + zero (issued)");
 

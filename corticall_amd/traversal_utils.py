@@ -308,3 +308,160 @@ def toContig(walk):
         sk = v.getKmerAsString()
         s = sk if not s else s + sk[-1]
     return s
+
+
+# ---------------------------------------------------------------------------------------------------------------- PathFinder
+class GraphPath:
+    """org.jgrapht.GraphPath as PathFinder's callers read it: getVertexList(), getEdgeList(), getWeight()"""
+
+    def __init__(self, vertices, edges, weight):
+        self._v, self._e, self._w = list(vertices), list(edges), weight
+
+    def getVertexList(self): return list(self._v)
+    def getEdgeList(self): return list(self._e)
+    def getStartVertex(self): return self._v[0]
+    def getEndVertex(self): return self._v[-1]
+    def getWeight(self): return self._w
+
+
+class PathFinder:
+    """J/utils/traversal/PathFinder.java:18-83: the (at most 10) shortest simple paths between two vertices over the edges of ONE colour
+    of a dfs / fillGaps graph.
+
+    The reference delegates to org.jgrapht.alg.shortestpath.KShortestPaths (jgrapht-core 1.0.1, ivy.xml:17 — the jar is not part of
+    /root/reference).  Restated here from that release's published algorithm: a Bellman-Ford iteration in which every vertex keeps a
+    RANKING LIST of its k best simple paths from the start (KShortestPathsIterator); pass p extends the lists of the vertices improved in
+    pass p - 1 along their outgoing edges; a candidate is dropped when it revisits one of its own vertices, or when the end vertex can no
+    longer be reached from its last vertex without touching the path (the guard test, on the UNDIRECTED connectivity of the graph minus
+    the path, as ConnectivityInspector over the MaskSubgraph does); a list is kept sorted by weight, a candidate of a weight already in
+    the list goes right behind the first element of that weight, and the list never grows beyond k; at most |V| - 1 passes.  Edge weights
+    are CortexEdge.getWeight() (AbstractBaseGraph.getEdgeWeight for a DefaultWeightedEdge).
+    What this restatement does NOT pin: within one pass JGraphT visits the improved vertices in the iteration order of a
+    java.util.HashSet<CortexVertex>; here they are visited in the order they were improved.  That can only permute paths of EQUAL weight
+    (the reference's own test, TraversalEngineTest.java:160-208, accepts either order) — "parity unpinned" for that tie order."""
+
+    K = 10
+
+    def __init__(self, graph, color):
+        self._out = {}             # vertex -> [(edge, target)] in insertion order (DefaultDirectedGraph: no multi-edges needed beyond equality)
+        self._edges = {}
+        for e in graph.edgeSet():
+            if e.getColor() != color:
+                continue
+            s_, t_ = graph.getEdgeSource(e), graph.getEdgeTarget(e)
+            self._out.setdefault(s_, [])
+            self._out.setdefault(t_, [])
+            if e in self._edges:       # Graph.addEdge(s, t, e) refuses an edge that is already there
+                continue
+            # a DefaultDirectedGraph holds no second edge from s to t either (AbstractBaseGraph.addEdge: !allowingMultipleEdges && containsEdge(s, t))
+            if any(t2 == t_ for _, t2 in self._out[s_]):
+                continue
+            self._edges[e] = (s_, t_)
+            self._out[s_].append((e, t_))
+
+    def vertexSet(self): return list(self._out)
+
+    def getPath(self, start, end, constraint=None, accept=True):
+        ps = self.getPaths(start, end, constraint, accept)
+        return ps[0] if ps else None
+
+    def getPaths(self, start, end, constraint=None, accept=True):
+        """constraint: a canonical k-mer (str); accept=True keeps the paths that pass through it, accept=False those that do not (:48-82)"""
+        if not self._out or start not in self._out or end not in self._out:
+            return []
+        paths = self._k_shortest(start, end)
+        if constraint is None:
+            return paths
+        out = []
+        for gp in paths:
+            found = any(min(v.getKmerAsString(), _revcomp(v.getKmerAsString())) == constraint for v in gp.getVertexList())
+            if found == bool(accept):
+                out.append(gp)
+        return out
+
+    # ---- KShortestPaths(g, 10).getPaths(start, end)
+    def _undirected(self):
+        adj = {v: set() for v in self._out}
+        for s_, outs in self._out.items():
+            for _, t_ in outs:
+                adj[s_].add(t_)
+                adj[t_].add(s_)
+        return adj
+
+    def _guard_disconnected(self, adj, path_vertices, reached, guard):
+        if reached == guard:
+            return False
+        masked = set(path_vertices)
+        if guard in masked:
+            return True
+        seen, stack = {reached}, [reached]
+        while stack:
+            u = stack.pop()
+            for w in adj[u]:
+                if w in seen or w in masked:
+                    continue
+                if w == guard:
+                    return False
+                seen.add(w)
+                stack.append(w)
+        return True
+
+    def _k_shortest(self, start, end):
+        k = self.K
+        adj = self._undirected()
+        # a ranking element: (weight, vertices tuple, edges tuple)
+        seen = {start: [(0.0, (start,), ())]}
+        prev = {start: list(seen[start])}
+        improved = [start]
+        max_hops = len(self._out) - 1
+        for _ in range(max_hops):
+            if not improved:
+                break
+            now = []
+            for u in improved:
+                if u == end:
+                    continue
+                for e, t_ in self._out[u]:
+                    if t_ == start:
+                        continue
+                    cands = []
+                    for w, vs, es in prev.get(u, ()):
+                        if t_ in vs or self._guard_disconnected(adj, vs, t_, end):
+                            continue
+                        cands.append((w + e.getWeight(), vs + (t_,), es + (e,)))
+                    relaxed = False
+                    if t_ not in seen:
+                        lst = cands[:k]
+                        if lst:
+                            seen[t_] = lst
+                            relaxed = True
+                    else:
+                        lst = seen[t_]
+                        y = 0
+                        for c in cands:
+                            placed = False
+                            while y < len(lst):
+                                if c[0] < lst[y][0]:
+                                    lst.insert(y, c)
+                                    placed = True
+                                elif c[0] == lst[y][0]:
+                                    lst.insert(y + 1, c)
+                                    placed = True
+                                if placed:
+                                    relaxed = True
+                                    if len(lst) > k:
+                                        del lst[k]
+                                    break
+                                y += 1
+                            if not placed and c[0] > lst[-1][0]:
+                                if len(lst) < k:
+                                    lst.append(c)
+                                    relaxed = True
+                                else:
+                                    break
+                    if relaxed and t_ not in now:
+                        now.append(t_)
+            for v in now:
+                prev[v] = list(seen[v])
+            improved = now
+        return [GraphPath(vs, es, w) for w, vs, es in seen.get(end, ())] if end != start else [GraphPath((start,), (), 0.0)]

@@ -884,6 +884,43 @@ def case_fill_gaps_random(orc, lib, tmp, seed):
     e.close()
 
 
+def test_ref_multiple_traversal_colors(orc, lib, tmp):           # TraversalEngineTest.java:160-208 (incl. PathFinder.getPaths, PathFinder.java:18-83)
+    from corticall_amd.traversal_utils import PathFinder, Pseudograph, java_string_set_order
+    haps = [("mom", ["AGTTCTGATCTAGGCTATATGCT"]), ("dad", ["AGTTCTGATCTGGGCTATATGCT"]), ("kid", ["AGTTCTG", "ATGGCTA"])]
+    cs = Case(orc, tmp, lib, haps, 5, name="v_multi")
+    f = TraversalEngineFactory(lib=lib).combinationOperator(AND).traversalDirection(BOTH).stoppingRule(ContigStopper).graph(cs.g)
+    samples = []
+    for sample in ("kid", "dad"):
+        samples.append(sample)
+        # g.getColorsForSampleNames(HashSet<String>): colours in the set's iteration order, ADDED to the factory's LinkedHashSet of colours
+        e = f.traversalColors([cs.g.getColorForSampleName(x) for x in java_string_set_order(samples)]).make()
+        contig, _ = e.walk_batch(["GTTCT"])
+        assert contig[0] == dict(haps)[sample][0]
+        oe = orc.Engine(cs.og, list(f._trav), op_and=True, stopper="ContigStopper")
+        assert oe.walk("GTTCT")[0] == contig[0]
+        e.close()
+    samples.append("mom")
+    e = f.traversalColors([cs.g.getColorForSampleName(x) for x in java_string_set_order(samples)]).stoppingRule("ExplorationStopper").make()
+    assert f._trav[0] == cs.g.getColorForSampleName("kid")          # the edges of the dfs graph carry the FIRST traversal colour: the kid's
+    d = e.dfs("AGTTC", "ATGCT")
+    pg = Pseudograph.fromDfsGraph(d)
+    v0 = next(v for v in pg.vertexSet() if v.getKmerAsString() == "AGTTC")      # TraversalUtils.findVertex
+    v1 = next(v for v in pg.vertexSet() if v.getKmerAsString() == "ATGCT")
+    gps = PathFinder(pg, cs.g.getColorForSampleName("kid")).getPaths(v0, v1)
+    assert len(gps) == 2
+    contigs = [TraversalUtils.toContig(gp.getVertexList()) for gp in gps]
+    assert sorted(contigs) == sorted([haps[0][1][0], haps[1][1][0]])
+    assert PathFinder(pg, cs.g.getColorForSampleName("mom")).getPaths(v0, v1) == []      # no edge carries that colour: an empty graph
+    # constraint (a canonical k-mer on one path only) with accept / reject
+    only_mom = orc.canonical("CTAGG")
+    pf = PathFinder(pg, cs.g.getColorForSampleName("kid"))
+    acc = [TraversalUtils.toContig(gp.getVertexList()) for gp in pf.getPaths(v0, v1, only_mom, True)]
+    rej = [TraversalUtils.toContig(gp.getVertexList()) for gp in pf.getPaths(v0, v1, only_mom, False)]
+    assert acc == [haps[0][1][0]] and rej == [haps[1][1][0]]
+    assert pf.getPath(v0, v1).getWeight() == float(len(haps[0][1][0]) - 5)
+    e.close()
+
+
 def test_ref_dfs_with_sinks(orc, lib, tmp):                       # TraversalEngineTest.java:389-410
     hap = "GTGTGCTAGGTCTATAGTTATAGGCGCGTCTCCGCAAAAATCGT"
     cs = Case(orc, tmp, lib, [("test", [hap])], 5, link_samples=["test"], name="v12")

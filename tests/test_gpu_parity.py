@@ -87,6 +87,7 @@ def test_dfs_dense(orc, lib, tmp_path, seed): pc.case_dfs_dense(orc, lib, tmp_pa
 
 
 def test_ref_dfs_with_sinks(orc, lib, tmp_path): pc.test_ref_dfs_with_sinks(orc, lib, tmp_path)
+def test_ref_multiple_traversal_colors(orc, lib, tmp_path): pc.test_ref_multiple_traversal_colors(orc, lib, tmp_path)
 
 
 def test_dfs_packed_results(orc, lib, tmp_path): pc.case_dfs_packed_results(orc, lib, tmp_path)

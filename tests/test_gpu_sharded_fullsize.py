@@ -43,10 +43,18 @@ def workload():
 def workload_c5s():
     """configs[4] scaled to one GPU's test budget: k = 63, 3 colours, child links, 50,000 seeds"""
     from tools import synth
+    import json
+    import shutil
     prefix = os.path.join(_bench_dir(), "c5s_L%d_k%d_s%d" % (L5, K5, NSEEDS))
-    if not os.path.exists(prefix + ".ctx"):
-        synth.generate(prefix, L5, K5, colours=3, with_links=True, seed=0xC0FFEE05, n_chrom=8, n_repeat_families=4000 * max(1, L5 // L),
-                       repeat_copies=4, repeat_len=(50, 300), n_seeds=NSEEDS, threads=min(16, os.cpu_count() or 1))
+    if not (os.path.exists(prefix + ".ctx") and os.path.exists(prefix + ".json")):
+        need = int(L5 * 1.05) * (16 + 15) + (1 << 28)            # the graph file: one 31-byte record per k-mer
+        free = shutil.disk_usage(_bench_dir()).free
+        assert free > need, "not enough room for the scaled configs[4] graph in %s: %d MB free, %d MB needed" % (_bench_dir(), free >> 20, need >> 20)
+        st = synth.generate(prefix, L5, K5, colours=3, with_links=True, seed=0xC0FFEE05, n_chrom=8, n_repeat_families=4000 * max(1, L5 // L),
+                            repeat_copies=4, repeat_len=(50, 300), n_seeds=NSEEDS, threads=min(16, os.cpu_count() or 1))
+        size = os.path.getsize(prefix + ".ctx")
+        assert size > st["n_records"] * 31 and (size - st["n_records"] * 31) < 4096, "the generator wrote %d bytes for %d records" % (size, st["n_records"])
+        json.dump(st, open(prefix + ".json", "w"))
     return prefix
 
 

@@ -15,3 +15,4 @@ if [ -n "$2" ]; then
   python3 -m pytest tests/test_gpu_sharded_fullsize.py -x -q -m gpu --durations=10 > gpurun_out/r03_${T}_gates.log 2>&1 || true
   tail -25 gpurun_out/r03_${T}_gates.log >> $O
 fi
+df -h /tmp /dev/shm . 2>/dev/null | tail -4 >> $O; free -g | head -2 >> $O; nproc >> $O

@@ -264,9 +264,12 @@ extern "C" int ldbg_synth_generate(const SynthParams* pp, const char* out_prefix
             for (int x = 0; x < W; x++) { const uint8_t* b = (const uint8_t*)&w[x]; buf.insert(buf.end(), b, b + 8); }
             for (int c = 0; c < C; c++) { const uint8_t* b = (const uint8_t*)&r.cov[c]; buf.insert(buf.end(), b, b + 4); }
             for (int c = 0; c < C; c++) buf.push_back(r.edges[c]);
-            if (buf.size() >= rs * 65536 || i + 1 == recs.size()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+            if (buf.size() >= rs * 65536 || i + 1 == recs.size()) {
+                if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) { fclose(f); return 5; }      // (disk full: say so instead of leaving a short file)
+                buf.clear();
+            }
         }
-        fclose(f);
+        if (fclose(f) != 0) return 5;
     }
 
     // ---- child links
