@@ -63,7 +63,7 @@ class ColorInfo(C.Structure):
 # every symbol include/ldbg.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "ldbg_last_error", "ldbg_version", "ldbg_device_count", "ldbg_kmer_encode", "ldbg_kmer_decode",
-    "ldbg_sort_ctx", "ldbg_join_ctx", "ldbg_ctx_write_records", "ldbg_graph_open", "ldbg_graph_open_memory", "ldbg_graph_open_collection", "ldbg_graph_close", "ldbg_graph_info", "ldbg_graph_device", "ldbg_graph_set_shard",
+    "ldbg_sort_ctx", "ldbg_join_ctx", "ldbg_ctx_write_records", "ldbg_graph_open", "ldbg_graph_open_memory", "ldbg_graph_open_device", "ldbg_graph_open_collection", "ldbg_graph_close", "ldbg_graph_info", "ldbg_graph_device", "ldbg_graph_set_shard",
     "ldbg_graph_sample_name", "ldbg_graph_color_info", "ldbg_graph_color_for_sample_name",
     "ldbg_graph_records", "ldbg_graph_records_dev", "ldbg_graph_find", "ldbg_graph_find_ascii", "ldbg_graph_find_dev", "ldbg_shard_owner_dev", "ldbg_shard_owner", "ldbg_shard_nbr_queries", "ldbg_shard_set_nbr",
     "ldbg_image_create", "ldbg_image_destroy", "ldbg_image_graph", "ldbg_image_row_bytes", "ldbg_image_clear", "ldbg_image_request", "ldbg_image_reset_requests", "ldbg_image_bucket",

@@ -19,7 +19,11 @@ void profile_reset_all();
 bool profile_get(const char* family, double* ms, int64_t* n);
 }  // namespace ldbg
 
-struct ldbg_graph { Graph g; ldbg_graph(const std::string& p, const void* img, int64_t n, int dev) : g(p, img, n, dev) {} };
+struct ldbg_graph {
+    Graph g;
+    ldbg_graph(const std::string& p, const void* img, int64_t n, int dev) : g(p, img, n, dev) {}
+    ldbg_graph(const std::string& p, const void* hdr, int64_t hdr_bytes, const void* d_recs, int64_t n_recs, int dev) : g(p, hdr, hdr_bytes, d_recs, n_recs, dev) {}
+};
 struct ldbg_links { Links l; ldbg_links(const std::string& p, const Graph& g) : l(p, g) {} };
 struct ldbg_engine {
     Engine e;
@@ -97,6 +101,9 @@ ldbg_status ldbg_graph_open(const char* path, int device, ldbg_graph** out) {
 }
 ldbg_status ldbg_graph_open_memory(const void* image, int64_t nbytes, int device, ldbg_graph** out) {
     return guard([&] { *out = nullptr; *out = new ldbg_graph("<memory>", image, nbytes, device); });
+}
+ldbg_status ldbg_graph_open_device(const void* header, int64_t header_bytes, const void* d_records, int64_t n_records, int device, ldbg_graph** out) {
+    return guard([&] { *out = nullptr; *out = new ldbg_graph("<device>", header, header_bytes, d_records, n_records, device); });
 }
 ldbg_status ldbg_graph_open_collection(const char* const* paths, int n_paths, int find_view, int device, ldbg_graph** out) {
     return guard([&] {
@@ -525,6 +532,10 @@ void ldbg_debug_ls(uint64_t* out) {
 }
 #endif
 // ---- measurement
+#ifdef LDBG_HOSTSIM
+// test hook of the host simulation (rt.h): lanes a simulated wavefront runs in lock step (1, 2, 4, ... 64)
+extern "C" void ldbg_hostsim_set_lanes(int n) { int v = 1; while (v * 2 <= n && v < 64) v *= 2; ::ldbg::sim::lanes_setting() = v; }
+#endif
 ldbg_status ldbg_profile_reset(void) { profile_reset_all(); return LDBG_OK; }
 ldbg_status ldbg_profile_get(const char* family, double* total_ms, int64_t* launches) {
     profile_get(family, total_ms, launches);

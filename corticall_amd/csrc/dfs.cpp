@@ -690,9 +690,9 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
     LsElem* fast = lds_store + (threadIdx.x & 63u);
     const uint32_t fast_stride = 64;
 #else
-    static LsElem lds_store[LDBG_LS_FAST];
-    LsElem* fast = lds_store;
-    const uint32_t fast_stride = 1;
+    static LsElem lds_store[LDBG_LS_FAST * 64];          // (one simulated wavefront at a time: rt.h)
+    LsElem* fast = lds_store + wave_lane();
+    const uint32_t fast_stride = (uint32_t)wave_size();
 #endif
     LinkStoreDev ls;
     ls.fast = fast; ls.fast_cap = LDBG_LS_FAST; ls.fast_stride = fast_stride;

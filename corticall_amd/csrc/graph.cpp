@@ -299,6 +299,21 @@ Graph::Graph(const std::string& p, const void* image, int64_t nbytes, int dev) :
     if (fd >= 0) ::close(fd);
 }
 
+// header bytes on the host, n_records records in DEVICE memory (sorted, as in a file)
+Graph::Graph(const std::string& p, const void* header, int64_t header_bytes, const void* d_records, int64_t n_records, int dev) : device(dev), path(p) {
+    if (rt::device_count() <= dev) throw StatusError(LDBG_ERR_HIP, "no HIP device " + std::to_string(dev) + " available (libldbg has no CPU fallback)");
+    rt::set_device(dev);
+    try {
+        CtxHeader probe = parse_ctx_header((const uint8_t*)header, (size_t)header_bytes, header_bytes, p);
+        hdr = parse_ctx_header((const uint8_t*)header, (size_t)header_bytes, (int64_t)probe.data_offset + n_records * (int64_t)probe.record_size, p);
+        if (hdr.W > 4) throw StatusError(LDBG_ERR_UNSUPPORTED, "k > 128 is not supported (k=" + std::to_string(hdr.k) + ")");
+        if (hdr.num_records != n_records) throw StatusError(LDBG_ERR_ARG, "open_device: the header and the record count disagree");
+        check_record_count(hdr.num_records, p);
+        stream = rt::stream_create();
+        upload((const uint8_t*)d_records, true);
+    } catch (...) { release_device(); throw; }
+}
+
 Graph::Graph(const CtxHeader& h, int64_t cap, int dev, const GraphView& like, bool tiny) : device(dev), path("#image") {
     rt::set_device(dev);
     hdr = h;
@@ -322,7 +337,7 @@ void Graph::release_device() {
     stream = nullptr;
 }
 
-void Graph::upload(const uint8_t* recs) {
+void Graph::upload(const uint8_t* recs, bool on_device) {
     const int64_t N = hdr.num_records;
     const int W = hdr.W, C = hdr.C;
     view.k = hdr.k; view.W = W; view.C = C; view.N = N;
@@ -349,6 +364,16 @@ void Graph::upload(const uint8_t* recs) {
     view.probe = (const uint8_t*)d_probe_;
     view.pstart = (const uint32_t*)d_pstart_;
 
+    if (on_device) {
+        // the records are in device memory already (a shard cut on the device, distributed.py): the layout kernel reads them where they are
+        const int64_t step = std::max<int64_t>(1, (1LL << 30) / hdr.record_size);
+        for (int64_t first = 0; first < N; first += step) {
+            const int64_t n = std::min(step, N - first);
+            LDBG_LAUNCH(k_layout, grid_for(n), 256, stream, recs + (size_t)first * hdr.record_size, first, n, N, W, C, (int)hdr.record_size,
+                        (uint64_t*)d_keys_, (uint32_t*)d_cov_, (uint8_t*)d_edges_, (uint8_t*)d_probe_, view.stride, view.edges_off, view.cov_off);
+        }
+        rt::stream_sync(stream);
+    }
     // stream the records: pinned double buffer -> raw device chunk -> layout kernel
     const int64_t chunk_recs = std::max<int64_t>(1, (64LL << 20) / hdr.record_size);
     const size_t chunk_bytes = (size_t)chunk_recs * hdr.record_size;
@@ -357,7 +382,7 @@ void Graph::upload(const uint8_t* recs) {
     rt::stream_t s2[2] = {rt::stream_create(), rt::stream_create()};
     try {
         int b = 0;
-        for (int64_t first = 0; first < N; first += chunk_recs, b ^= 1) {
+        for (int64_t first = 0; first < N && !on_device; first += chunk_recs, b ^= 1) {
             int64_t n = std::min(chunk_recs, N - first);
             rt::stream_sync(s2[b]);   // buffer b free again
             memcpy(pin[b], recs + first * hdr.record_size, (size_t)n * hdr.record_size);

@@ -86,6 +86,7 @@ class Graph {
 public:
     // file_or_image: if image != nullptr the graph is built from memory, else `path` is mmapped
     Graph(const std::string& path, const void* image, int64_t nbytes, int device);
+    Graph(const std::string& path, const void* header, int64_t header_bytes, const void* d_records, int64_t n_records, int device);
     // the local image of a hash-sharded table (image.h): `cap` zeroed rows laid out like those of `like`, filled as rows arrive
     Graph(const CtxHeader& h, int64_t cap, int device, const GraphView& like, bool java_tiny);
     bool is_image = false;
@@ -110,7 +111,7 @@ public:
 
 private:
     void* d_keys_ = nullptr; void* d_cov_ = nullptr; void* d_edges_ = nullptr; void* d_probe_ = nullptr; void* d_pstart_ = nullptr;
-    void upload(const uint8_t* records_host);
+    void upload(const uint8_t* records, bool on_device = false);
     void release_device();
 };
 

@@ -244,9 +244,8 @@ LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHd
 // its group and back the same way.  An owner qualifies when its store (after the adds) fits one element per lane of a group
 // and all its junction records were gathered; the others take the whole-wavefront path as before.  Semantics: those of
 // coop_add / the one-element-per-lane branch of coop_next_choice, statement by statement.
-#ifndef LDBG_HOSTSIM
 #define LDBG_GS 16u
-LDBG_DEV uint32_t grp_shfl(uint32_t v, uint32_t src_lane) { return (uint32_t)__shfl((int)v, (int)(src_lane & 63u), 64); }
+LDBG_DEV uint32_t grp_shfl(uint32_t v, uint32_t src_lane) { return wave_shfl_u32(v, (int)(src_lane & 63u)); }
 LDBG_DEV uint32_t grp_mask(unsigned long long ballot, uint32_t g) { return (uint32_t)(ballot >> (LDBG_GS * g)) & 0xFFFFu; }
 struct GrpTake { uint32_t myL; bool gv; int myq; };
 // the next (up to) four owners of `todo` (wave-uniform): which owner this lane's group works for, and — for an owner lane of this
@@ -344,13 +343,14 @@ LDBG_DEV void group_choices(const LinksView& Lk, const LsWave& v, LinkStoreDev& 
         const unsigned c = ls_cur(x);
         const unsigned c0 = grp_shfl(c, g << 4);
         const bool old = valid && x.birth == minbirth0;
-        const bool ok = t.gv && grp_mask(wave_ballot(old && c != c0), g) == 0u;  // the oldest links must agree (:92-119)
+        const uint32_t differ = grp_mask(wave_ballot(old && c != c0), g);          // (every lane takes part in every ballot: no short circuits around them)
+        const bool ok = t.gv && differ == 0u;                                    // the oldest links must agree (:92-119)
         // first of the oldest links in HashMap iteration order (bucket, key insertion order): minimum over the group
         const uint32_t hh = (uint32_t)x.hash;
         uint64_t best = old ? (((uint64_t)((hh ^ (hh >> 16)) & (java_cap - 1u)) << 32) | x.key_seq) : ~0ull;
 #pragma unroll
         for (int m = 8; m > 0; m >>= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, m, 16), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), m, 16);
+            const uint32_t lo = wave_shfl_u32((uint32_t)best, (int)(lane ^ (uint32_t)m)), hi = wave_shfl_u32((uint32_t)(best >> 32), (int)(lane ^ (uint32_t)m));     // (stays inside the group: m < 16)
             const uint64_t o = ((uint64_t)hi << 32) | lo;
             best = o < best ? o : best;
         }
@@ -385,7 +385,6 @@ LDBG_DEV void group_choices(const LinksView& Lk, const LsWave& v, LinkStoreDev& 
         }
     }
 }
-#endif
 
 // The link-store part of one cursor step (TraversalEngine.java:241-276) for every lane of the wavefront that is in cursor
 // mode: per-lane prefetch, cooperative adds, cooperative junction choices.  `pre` then carries the results into
@@ -436,7 +435,6 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
 #ifdef LDBG_WALK_DIAG
     if (tdiag) { tdiag[0] = __builtin_amdgcn_s_memrealtime(); tdiag[2] = (unsigned long long)__builtin_popcountll(need); }
 #endif
-#ifndef LDBG_HOSTSIM
     if (wave_size() == 64 && lw.fast_cap >= LDBG_GS) {
         // owners whose store, with everything this step may add, is one element per lane of a 16-lane group: four of them at a time
         const uint32_t r_cur = m_cur == ~0ull ? 0u : (uint32_t)(m_cur >> 32), r_nxt = m_nxt == ~0ull ? 0u : (uint32_t)(m_nxt >> 32);
@@ -449,7 +447,6 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
             need &= ~grouped;
         }
     }
-#endif
     while (need) {
         const int L = __builtin_ctzll(need);
         need &= need - 1;
@@ -472,12 +469,10 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
 #ifdef LDBG_WALK_DIAG
     if (tdiag) { tdiag[1] = __builtin_amdgcn_s_memrealtime(); tdiag[2] |= (unsigned long long)__builtin_popcountll(need) << 32; }
 #endif
-#ifndef LDBG_HOSTSIM
     if (wave_size() == 64 && lw.fast_cap >= LDBG_GS) {
         const unsigned long long grouped = wave_ballot(cur_mode && popc4(nmask) > 1 && ls.n >= 1u && ls.n <= LDBG_GS);
         if (grouped) { group_choices(e.links, lw, ls, grouped, pre); need &= ~grouped; }
     }
-#endif
     while (need) {                                    // junction choices (:266-272)
         const int L = __builtin_ctzll(need);
         need &= need - 1;

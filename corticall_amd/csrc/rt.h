@@ -122,6 +122,9 @@ LDBG_DEV uint64_t wave_bcast_u64(uint64_t v, int src) {
     uint32_t lo = wave_bcast_u32((uint32_t)v, src), hi = wave_bcast_u32((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
+// value of ANY lane (src differs from lane to lane: a permute through the LDS crossbar, ds_bpermute)
+LDBG_DEV uint32_t wave_shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src & 63, 64); }
+LDBG_DEV uint64_t wave_shfl_u64(uint64_t v, int src) { return ((uint64_t)wave_shfl_u32((uint32_t)(v >> 32), src) << 32) | wave_shfl_u32((uint32_t)v, src); }
 LDBG_DEV void wave_fence() { __threadfence_block(); }
 LDBG_DEV void device_fence() { __threadfence(); }
 LDBG_DEV uint64_t wave_shfl_xor_u64(uint64_t v, int m) {
@@ -181,10 +184,102 @@ struct Event {
     static float elapsed_ms(Event&, Event&) { return 0.0f; }
 };
 }  // namespace rt
+// ---- simulated wavefronts.  LDBG_HOSTSIM_LANES=1 (default): a "wave" is a single lane, every thread runs to completion in turn.
+// LDBG_HOSTSIM_LANES=N (N = 64 matches the device): a kernel launched one wavefront per workgroup (block <= 64) runs its lanes in
+// LOCK STEP — one fibre per lane; a wavefront primitive (ballot, broadcast, permute, scan) is a barrier at which every live lane deposits
+// its operand and then reads the others' — so that the wave-cooperative code (lscoop.h, strand.h: table regrowth, walk.cpp: expansion,
+// image.cpp: bucketing) is executed on the CPU as it is on the device.  Lanes that have left the kernel count as inactive.  A lane
+// that arrives at a DIFFERENT primitive than its neighbours is a divergence bug: the simulation aborts and says so.
+}  // namespace ldbg
+#include <execinfo.h>
+#include <ucontext.h>
+#include <stdio.h>
+#include <functional>
+#include <vector>
+namespace ldbg {
+namespace sim {
+struct Wave {
+    int lanes = 1, cur = 0, live = 0, arrived = 0;
+    unsigned long long gen = 0;
+    bool active = false;
+    ucontext_t sched;
+    ucontext_t ctx[64];
+    std::vector<char> stacks[64];
+    uint8_t done[64];
+    int kind[64];
+    void* site[64];
+    uint64_t x[2][64];
+    uint64_t y[2][64];
+    int64_t tid0 = 0, nthreads = 1;
+    std::function<void()>* body = nullptr;
+};
+inline Wave& wave() { static thread_local Wave w; return w; }
+inline int& lanes_setting() { static int n = [] { const char* e = getenv("LDBG_HOSTSIM_LANES"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 64 ? 64 : v); }(); return n; }
+inline int lanes_env() { return lanes_setting(); }
+inline void yield() { Wave& w = wave(); swapcontext(&w.ctx[w.cur], &w.sched); }
+// deposit (a, b), wait until every live lane has; returns the buffer to read
+inline int collective(int kind, uint64_t a, uint64_t b = 0) {
+    Wave& w = wave();
+    const int buf = (int)(w.gen & 1ull);
+    const unsigned long long my_gen = w.gen;
+    w.x[buf][w.cur] = a; w.y[buf][w.cur] = b; w.kind[w.cur] = kind; w.site[w.cur] = __builtin_return_address(0);
+    w.arrived++;
+    if (w.arrived == w.live) {
+        for (int l = 0; l < w.lanes; l++)
+            if (!w.done[l] && w.kind[l] != kind) {
+                fprintf(stderr, "[hostsim] wavefront divergence: lane %d is at primitive %d (%p), lane %d at %d (%p); the arriving lane's stack:\n", w.cur, kind, w.site[w.cur], l, w.kind[l], w.site[l]);
+                void* bt[32];
+                backtrace_symbols_fd(bt, backtrace(bt, 32), 2);
+                abort();
+            }
+        w.arrived = 0; w.gen++;
+    } else {
+        while (w.gen == my_gen) yield();
+    }
+    return buf;
+}
+inline void trampoline() {
+    Wave& w = wave();
+    (*w.body)();
+    w.done[w.cur] = 1;
+    w.live--;
+    if (w.live > 0 && w.arrived == w.live) {       // the lanes still at a barrier were waiting for this one only
+        const int kd = [&] { for (int l = 0; l < w.lanes; l++) if (!w.done[l]) return w.kind[l]; return 0; }();
+        for (int l = 0; l < w.lanes; l++)
+            if (!w.done[l] && w.kind[l] != kd) { fprintf(stderr, "[hostsim] wavefront divergence at a lane's exit\n"); abort(); }
+        w.arrived = 0; w.gen++;
+    }
+    swapcontext(&w.ctx[w.cur], &w.sched);
+}
+// one wavefront of `lanes` lanes in lock step; body() is the kernel call (it reads its thread index through sim_idx())
+void run_wave(int lanes, int64_t tid0, int64_t nthreads, std::function<void()>& body);
+}  // namespace sim
 struct SimIdx { int64_t tid, nthreads; };
 inline SimIdx& sim_idx() { static thread_local SimIdx s{0, 1}; return s; }
 inline int64_t global_tid() { return sim_idx().tid; }
 inline int64_t global_nthreads() { return sim_idx().nthreads; }
+inline void sim::run_wave(int lanes, int64_t tid0, int64_t nthreads, std::function<void()>& body) {
+    Wave& w = wave();
+    w.lanes = lanes; w.live = lanes; w.arrived = 0; w.gen = 0; w.active = true; w.body = &body; w.tid0 = tid0; w.nthreads = nthreads;
+    for (int l = 0; l < lanes; l++) {
+        if (w.stacks[l].empty()) w.stacks[l].resize((size_t)1 << 20);
+        w.done[l] = 0; w.kind[l] = 0;
+        getcontext(&w.ctx[l]);
+        w.ctx[l].uc_stack.ss_sp = w.stacks[l].data();
+        w.ctx[l].uc_stack.ss_size = w.stacks[l].size();
+        w.ctx[l].uc_link = &w.sched;
+        makecontext(&w.ctx[l], (void (*)())sim::trampoline, 0);
+    }
+    while (w.live > 0) {
+        for (int l = 0; l < lanes; l++) {
+            if (w.done[l]) continue;
+            w.cur = l;
+            sim_idx().tid = tid0 + l; sim_idx().nthreads = nthreads;
+            swapcontext(&w.sched, &w.ctx[l]);
+        }
+    }
+    w.active = false; w.lanes = 1; w.cur = 0;
+}
 inline unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 inline unsigned atomic_add_u32(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
 inline unsigned atomic_min_u32(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
@@ -192,26 +287,56 @@ inline unsigned atomic_or_u32(unsigned* p, unsigned v) { unsigned o = *p; *p |= 
 inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { unsigned long long o = *p; if (o == cmp) *p = v; return o; }
 inline unsigned long long atomic_exch_u64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
-// a simulated "wave" is a single lane
-inline int wave_size() { return 1; }
-inline int wave_lane() { return 0; }
-inline unsigned long long wave_ballot(bool p) { return p ? 1ull : 0ull; }
-inline uint32_t wave_bcast_u32(uint32_t v, int) { return v; }
-inline uint64_t wave_bcast_u64(uint64_t v, int) { return v; }
+inline int wave_size() { return sim::wave().active ? sim::wave().lanes : 1; }
+inline int wave_lane() { return sim::wave().active ? sim::wave().cur : 0; }
+inline unsigned long long wave_ballot(bool p) {
+    sim::Wave& w = sim::wave();
+    if (!w.active) return p ? 1ull : 0ull;
+    const int b = sim::collective(1, p ? 1ull : 0ull);
+    unsigned long long m = 0;
+    for (int l = 0; l < w.lanes; l++) if (!w.done[l] && w.x[b][l]) m |= 1ull << l;
+    return m;
+}
+// value of lane `src` (any lane: a permute; the device code uses v_readlane where src is uniform and ds_bpermute where it is not)
+inline uint64_t wave_shfl_u64(uint64_t v, int src) {
+    sim::Wave& w = sim::wave();
+    if (!w.active) return v;
+    const int b = sim::collective(2, v);
+    return w.x[b][src & (w.lanes - 1)];
+}
+inline uint32_t wave_shfl_u32(uint32_t v, int src) { return (uint32_t)wave_shfl_u64(v, src); }
+inline uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)wave_shfl_u64(v, src); }
+inline uint64_t wave_bcast_u64(uint64_t v, int src) { return wave_shfl_u64(v, src); }
+inline uint64_t wave_shfl_xor_u64(uint64_t v, int m) { return wave_shfl_u64(v, wave_lane() ^ m); }
 inline void wave_fence() {}
 inline void device_fence() {}
-inline uint64_t wave_min_u64(uint64_t v) { return v; }
-inline uint64_t wave_max_u64(uint64_t v) { return v; }
-inline int wave_count_below(unsigned long long) { return 0; }
-inline uint32_t wave_incl_scan_u32(uint32_t v) { return v; }
+inline uint64_t wave_min_u64(uint64_t v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o < v ? o : v; } return v; }
+inline uint64_t wave_max_u64(uint64_t v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o > v ? o : v; } return v; }
+inline int wave_count_below(unsigned long long ballot) { return __builtin_popcountll(ballot & ((1ull << wave_lane()) - 1ull)); }
+inline uint32_t wave_incl_scan_u32(uint32_t v) {
+    sim::Wave& w = sim::wave();
+    if (!w.active) return v;
+    const int b = sim::collective(3, v);
+    uint32_t s = 0;
+    for (int l = 0; l <= w.cur; l++) if (!w.done[l]) s += (uint32_t)w.x[b][l];
+    return s;
+}
 }  // namespace ldbg
 
-// sequential "launch": every simulated thread runs to completion in turn.  Kernels must therefore
-// not wait on other threads (none of ours do: walks are independent units).
+// "launch": LDBG_HOSTSIM_LANES=1, or a kernel of wider workgroups (none of those uses a wavefront primitive): every simulated thread
+// runs to completion in turn.  Otherwise: wavefront after wavefront, the lanes of each in lock step.
 #define LDBG_LAUNCH(kernel, grid, block, stream, ...)                      \
     do {                                                                   \
         int64_t nt__ = (int64_t)(grid) * (int64_t)(block);                 \
         if (nt__ > 4096) nt__ = 4096;                                      \
+        const int lanes__ = ::ldbg::sim::lanes_env() > 1 && (int64_t)(block) <= 64 ? (int)std::min<int64_t>((int64_t)(block), (int64_t)::ldbg::sim::lanes_env()) : 1; \
+        if (lanes__ > 1) {                                                 \
+            nt__ = (nt__ / lanes__) * lanes__; if (nt__ < lanes__) nt__ = lanes__; \
+            std::function<void()> body__ = [&]() { kernel(__VA_ARGS__); }; \
+            for (int64_t t__ = 0; t__ < nt__; t__ += lanes__) ::ldbg::sim::run_wave(lanes__, t__, nt__, body__); \
+            ::ldbg::sim_idx().tid = 0; ::ldbg::sim_idx().nthreads = 1;     \
+            break;                                                         \
+        }                                                                  \
         ::ldbg::sim_idx().nthreads = nt__;                                 \
         for (int64_t t__ = 0; t__ < nt__; t__++) {                         \
             ::ldbg::sim_idx().tid = t__;                                   \

@@ -130,9 +130,9 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     LsElem* fast = lds_store + threadIdx.x;
     const uint32_t fast_stride = BS;
 #else
-    static LsElem lds_store[LDBG_LS_FAST];
-    LsElem* fast = lds_store;
-    const uint32_t fast_stride = 1;
+    static LsElem lds_store[LDBG_LS_FAST * 64];          // (one simulated wavefront at a time: rt.h)
+    LsElem* fast = lds_store + wave_lane();
+    const uint32_t fast_stride = (uint32_t)wave_size();
 #endif
     LinkStoreDev ls;
     ls.fast = fast; ls.fast_cap = LDBG_LS_FAST; ls.fast_stride = fast_stride;
@@ -565,54 +565,73 @@ LDBG_KERNEL void k_contigs_rle(ContigRleArgs a) {
                 const uint32_t at = base_v + incl - cnt;
                 const bool head = cnt > 0u && pd_is_head(e);
                 if (cnt == 1u && !head && at >= 1u) o[place(at)] = "ACGT"[path_base(e)];
-                unsigned long long hb = wave_ballot(head);
+                // RUN heads: a run is a copy of `len` bytes of ubase with a per-byte map (which 2-bit field, complemented or not), forwards or
+                // backwards, eight bytes per lane and access, four accesses in flight.  A run is a few hundred bytes (580 on average at C3):
+                // given the whole wavefront, three quarters of the lanes have nothing to copy and ONE run is in flight per wavefront — the
+                // kernel ran at a fifth of the HBM rate, bound by the latency of run after run.  So the wavefront copies FOUR runs at a time,
+                // a group of 16 lanes each (same instruction stream, per-group operands by lane permute).
+                const bool is_run = head && LDBG_PD_KIND(e) == LDBG_PD_RUN;
+                unsigned long long hb = wave_ballot(is_run);
+                const uint32_t GS = WS == 64u ? 16u : WS, g = lane / GS, sub = lane % GS;
+                const uint8_t* ub = LDBG_GLOBAL(const uint8_t, a.runs.ubase);
+                while (hb) {
+                    uint32_t myL = 0;
+                    bool gv = false;
+                    for (uint32_t q = 0; q < WS / GS; q++) {
+                        if (!hb) break;
+                        const int L = __builtin_ctzll(hb);
+                        hb &= hb - 1;
+                        if (g == q) { myL = (uint32_t)L; gv = true; }
+                    }
+                    const uint64_t he = wave_shfl_u64(e, (int)myL);
+                    const uint32_t hat = wave_shfl_u32(at, (int)myL), len_of = wave_shfl_u32(cnt, (int)myL);
+                    const uint32_t len = gv ? len_of : 0u;
+                    const uint64_t payload = gv ? rle_stored(a, s, j0 + myL + 1u) : 0ull;
+                    const bool asc = (he >> 36) & 1ull, inv = (he >> 37) & 1ull;
+                    const uint32_t first = (uint32_t)payload;
+                    const unsigned shift = (fwd != inv) ? 2u : 0u, comp = inv ? 3u : 0u;
+                    auto ascii = [&](unsigned bb) -> unsigned { return (0x54474341u >> (8u * (((bb >> shift) & 3u) ^ comp))) & 0xFFu; };
+                    // low ends of the two byte ranges; same = both ascend with t or both descend
+                    const uint8_t* in_lo = asc ? ub + first : ub + first - (len ? len - 1u : 0u);
+                    char* out_lo = LDBG_GLOBAL(char, o) + (fwd ? place(hat) : place(hat + (len ? len - 1u : 0u)));
+                    const bool same = asc == fwd;
+                    const uint32_t nd = len / 8u;
+                    uint32_t max_nd = wave_bcast_u32(nd, 0);
+                    for (uint32_t q = 1; q < WS / GS; q++) { const uint32_t o2 = wave_bcast_u32(nd, (int)(q * GS)); max_nd = o2 > max_nd ? o2 : max_nd; }
+                    for (uint32_t base = 0; base < max_nd; base += 4u * GS) {      // (the trip count is the same for every lane)
+                        uint64_t w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t ci = base + (uint32_t)q * GS + sub;
+                            w[q] = 0;
+                            if (ci < nd) __builtin_memcpy(&w[q], in_lo + (same ? 8u * ci : len - 8u - 8u * ci), 8);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t ci = base + (uint32_t)q * GS + sub;
+                            uint64_t v = 0;
+#pragma unroll
+                            for (int bI = 0; bI < 8; bI++) v |= (uint64_t)ascii((unsigned)(w[q] >> (8 * bI)) & 0xFFu) << (8 * bI);
+                            if (!same) v = __builtin_bswap64(v);
+                            if (ci < nd) __builtin_memcpy(out_lo + 8u * ci, &v, 8);
+                        }
+                    }
+                    for (uint32_t t = 8u * nd + sub; t < len; t += GS) {           // the last one to seven bytes of every run
+                        const unsigned bb = in_lo[same ? t : len - 1u - t];
+                        out_lo[t] = (char)ascii(bb);
+                    }
+                }
+                // REPEAT (always the last entry of its strand): the bases of the last recorded revolution, again and again
+                hb = wave_ballot(head && !is_run);
                 while (hb) {
                     const int L = __builtin_ctzll(hb);
                     hb &= hb - 1;
-                    const uint64_t he = wave_bcast_u64(e, L);
                     const uint32_t hat = wave_bcast_u32(at, L), len = wave_bcast_u32(cnt, L);
                     const uint64_t payload = rle_stored(a, s, j0 + (uint32_t)L + 1);
-                    if (LDBG_PD_KIND(he) == LDBG_PD_RUN) {
-                        const bool asc = (he >> 36) & 1ull, inv = (he >> 37) & 1ull;
-                        const uint32_t first = (uint32_t)payload;
-                        // a run is a copy of `len` bytes of ubase with a per-byte map (which 2-bit field, complemented or not), forwards or
-                        // backwards: eight bytes per lane and access, four such accesses in flight per lane before the first store
-                        const uint8_t* ub = LDBG_GLOBAL(const uint8_t, a.runs.ubase);
-                        const unsigned shift = (fwd != inv) ? 2u : 0u, comp = inv ? 3u : 0u;
-                        auto ascii = [&](unsigned bb) -> unsigned { return (0x54474341u >> (8u * (((bb >> shift) & 3u) ^ comp))) & 0xFFu; };
-                        // low ends of the two byte ranges; same = both ascend with t or both descend
-                        const uint8_t* in_lo = asc ? ub + first : ub + first - (len - 1u);
-                        char* out_lo = LDBG_GLOBAL(char, o) + (fwd ? place(hat) : place(hat + len - 1u));
-                        const bool same = asc == fwd;
-                        const uint32_t nd = len / 8u;
-                        for (uint32_t base = 0; base < nd; base += 4u * WS) {      // (the trip count is the same for every lane)
-                            uint64_t w[4];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const uint32_t ci = base + (uint32_t)q * WS + lane;
-                                w[q] = 0;
-                                if (ci < nd) __builtin_memcpy(&w[q], in_lo + (same ? 8u * ci : len - 8u - 8u * ci), 8);
-                            }
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const uint32_t ci = base + (uint32_t)q * WS + lane;
-                                uint64_t v = 0;
-#pragma unroll
-                                for (int bI = 0; bI < 8; bI++) v |= (uint64_t)ascii((unsigned)(w[q] >> (8 * bI)) & 0xFFu) << (8 * bI);
-                                if (!same) v = __builtin_bswap64(v);
-                                if (ci < nd) __builtin_memcpy(out_lo + 8u * ci, &v, 8);
-                            }
-                        }
-                        for (uint32_t t = 8u * nd + lane; t < len; t += WS) {      // the last one to seven bytes
-                            const unsigned bb = in_lo[same ? t : len - 1u - t];
-                            out_lo[t] = (char)ascii(bb);
-                        }
-                    } else {                                   // REPEAT: the bases of the last recorded revolution, again and again
-                        wave_fence();
-                        const uint32_t first = (uint32_t)payload, period = (uint32_t)(payload >> 32);
-                        for (uint32_t t = lane; t < len; t += WS)
-                            o[place(hat + t)] = LDBG_GLOBAL(const char, o)[place(first + period + t % period)];
-                    }
+                    wave_fence();
+                    const uint32_t first = (uint32_t)payload, period = (uint32_t)(payload >> 32);
+                    for (uint32_t t = lane; t < len; t += WS)
+                        o[place(hat + t)] = LDBG_GLOBAL(const char, o)[place(first + period + t % period)];
                 }
                 base_v += wave_bcast_u32(incl, (int)WS - 1);
             }

@@ -89,7 +89,7 @@ def pack_kmers(ascii_kmers, k, return_valid=False):
 class ShardedCortexGraph:
     """A .ctx table hash-partitioned over the ranks of a process group."""
 
-    def __init__(self, path, device=0, lib=None, group=None, chunk_records=1 << 22):
+    def __init__(self, path, device=0, lib=None, group=None, chunk_records=1 << 22):      # (chunk: 4 M records = 130 MB at k <= 64, 3 colours)
         import torch
         import torch.distributed as dist
         self._torch, self._dist, self._group = torch, dist, group
@@ -103,37 +103,54 @@ class ShardedCortexGraph:
         self.k, self.W, self.C = h["k"], h["W"], h["C"]
         rec = 8 * self.W + 5 * self.C
         n_all = (raw.size - h["data_offset"]) // rec
-        # every rank scans ONE slice of the file (1/world of the records) and sends each record to its owner: one all-to-all.
-        # A slice is sorted and bucketing keeps the order, so a shard receives `world` sorted runs, which it merges.
+        # Every rank scans ONE slice of the file (1/world of the records) and sends each record to its owner — on the DEVICE: a chunk of the
+        # slice is uploaded, ldbg_shard_owner_dev names the owners, a stable sort by owner buckets the records (a slice is sorted and the sort
+        # keeps the order), one all-to-all per chunk carries them over (a chunk is ~130 MB: a single collective of more than 2^31 bytes does
+        # not arrive whole).  The file is sorted and the slices ascend with the rank, so what a shard receives — source rank after source
+        # rank, chunk after chunk — IS its sorted table: nothing to merge, no copy back to the host; the library lays the records out where
+        # they are (ldbg_graph_open_device).
         first, cnt = partition(n_all, self.rank, self.world)
         records = raw[h["data_offset"] + first * rec:h["data_offset"] + (first + cnt) * rec].reshape(cnt, rec)
-        buckets = [[] for _ in range(self.world)]
-        for lo in range(0, cnt, chunk_records):
-            blk = np.ascontiguousarray(records[lo:lo + chunk_records])
-            keys = np.ascontiguousarray(blk[:, :8 * self.W]).view("<u8").reshape(-1, self.W)
-            owner = np.empty(len(blk), dtype=np.int32)
-            self._lib.check(self._d.ldbg_shard_owner(self.k, keys.ctypes.data_as(C.c_void_p), C.c_int64(len(blk)), self.world,
-                                                     int(device), owner.ctypes.data_as(C.c_void_p)))
-            for r in range(self.world):
-                buckets[r].append(blk[owner == r])
-        send = [np.concatenate(b) if b else np.zeros((0, rec), dtype=np.uint8) for b in buckets]
-        send_counts = torch.tensor([len(x) for x in send], dtype=torch.int64)
-        recv_counts = torch.empty_like(send_counts)
-        dev_counts = send_counts.to(self.device)
-        dev_recv = torch.empty_like(dev_counts)
-        dist.all_to_all_single(dev_recv, dev_counts, group=group)
-        recv_counts = dev_recv.cpu()
-        flat = torch.from_numpy(np.concatenate(send).reshape(-1) if cnt else np.zeros(0, dtype=np.uint8)).to(self.device)
-        got = torch.empty(int(recv_counts.sum().item()) * rec, dtype=torch.uint8, device=self.device)
-        dist.all_to_all_single(got, flat, output_split_sizes=[int(c) * rec for c in recv_counts.tolist()],
-                               input_split_sizes=[int(c) * rec for c in send_counts.tolist()], group=group)
-        shard = got.cpu().numpy().reshape(-1, rec)
-        if len(shard) > 1:                                   # merge the sorted runs (k-mer words, most significant first)
-            keys = np.ascontiguousarray(shard[:, :8 * self.W]).view("<u8").reshape(-1, self.W)
-            order = np.lexsort(tuple(keys[:, w] for w in range(self.W - 1, -1, -1)))
-            shard = shard[order]
-        image = np.concatenate([np.asarray(raw[:h["data_offset"]]), np.ascontiguousarray(shard).reshape(-1)])
-        self.shard = CortexGraph(self.path + "#shard%d" % self.rank, device=device, lib=self._lib, image=image)
+        W8 = 8 * self.W
+        nch = torch.tensor([-(-cnt // chunk_records)], dtype=torch.int64, device=self.device)
+        dist.all_reduce(nch, op=dist.ReduceOp.MAX, group=group)
+        pieces = [[] for _ in range(self.world)]
+        for c in range(int(nch.item())):
+            lo, hi = min(cnt, c * chunk_records), min(cnt, (c + 1) * chunk_records)
+            m = hi - lo
+            if m:
+                blk = torch.from_numpy(np.array(records[lo:hi])).to(self.device)                    # [m, rec] u8
+                kb = torch.empty((m, W8), dtype=torch.uint8, device=self.device)                    # (an explicit copy: rows of exactly W8 bytes, whatever m is)
+                kb.copy_(blk[:, :W8])
+                keys = kb.view(torch.int64)                                                         # [m, W]: the file's key words are the packed words
+                canon = torch.empty_like(keys)
+                owner = torch.empty(m, dtype=torch.int32, device=self.device)
+                self._lib.check(self._d.ldbg_shard_owner_dev(self.k, self._ptr(keys), C.c_int64(m), self.world, self._ptr(canon), self._ptr(owner), None))
+                owner = owner.to(torch.int64)
+                send = blk[torch.argsort(owner, stable=True)].contiguous()
+                counts = torch.bincount(owner, minlength=self.world)
+                del blk, keys, canon, kb
+            else:
+                send = torch.zeros((0, rec), dtype=torch.uint8, device=self.device)
+                counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+            rcounts = torch.empty_like(counts)
+            dist.all_to_all_single(rcounts, counts, group=group)
+            sc, rc = counts.tolist(), rcounts.tolist()
+            got = torch.empty((int(sum(rc)), rec), dtype=torch.uint8, device=self.device)
+            dist.all_to_all_single(got.view(-1), send.view(-1), output_split_sizes=[int(x) * rec for x in rc], input_split_sizes=[int(x) * rec for x in sc], group=group)
+            at = 0
+            for src in range(self.world):
+                if rc[src]:
+                    pieces[src].append(got[at:at + rc[src]])
+                at += rc[src]
+        parts = [p_ for src in range(self.world) for p_ in pieces[src]]
+        shard = torch.cat(parts) if parts else torch.zeros((0, rec), dtype=torch.uint8, device=self.device)
+        del pieces, parts
+        if shard.is_cuda:
+            torch.cuda.current_stream(self.device).synchronize()
+        self.shard = CortexGraph(self.path + "#shard%d" % self.rank, device=device, lib=self._lib,
+                                 device_records=(bytes(raw[:h["data_offset"]]), shard.data_ptr(), int(shard.shape[0])))
+        del shard
         self._lib.check(self._d.ldbg_graph_set_shard(self.shard._h, 1))
         n = torch.tensor([self.shard.getNumRecords()], dtype=torch.int64, device=self.device)
         dist.all_reduce(n, group=group)

@@ -85,13 +85,18 @@ class CortexRecord:
 class CortexGraph:
     """J/utils/io/graph/cortex/CortexGraph.java — here: a .ctx file resident in MI355X HBM."""
 
-    def __init__(self, path, device=0, lib=None, image=None):
-        """image: bytes-like .ctx image to load instead of the file at `path` (ldbg_graph_open_memory)"""
+    def __init__(self, path, device=0, lib=None, image=None, device_records=None):
+        """image: bytes-like .ctx image to load instead of the file at `path` (ldbg_graph_open_memory)
+        device_records: (header bytes, device pointer, number of records) — the records are in device memory already (ldbg_graph_open_device)"""
         self._lib = lib or _native.default_lib()
         self._d = self._lib.dll
         self.path = str(path)
         h = C.c_void_p()
-        if image is None:
+        if device_records is not None:
+            hdr, ptr, n = device_records
+            hb = np.frombuffer(hdr, dtype=np.uint8)
+            self._lib.check(self._d.ldbg_graph_open_device(hb.ctypes.data_as(C.c_void_p), C.c_int64(hb.size), C.c_void_p(ptr), C.c_int64(n), int(device), C.byref(h)))
+        elif image is None:
             self._lib.check(self._d.ldbg_graph_open(self.path.encode(), int(device), C.byref(h)))
         else:
             buf = np.frombuffer(image, dtype=np.uint8)

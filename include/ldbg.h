@@ -75,6 +75,9 @@ ldbg_status ldbg_ctx_write_records(const char* in_path, const int64_t* indices, 
 ldbg_status ldbg_graph_open(const char* path, int device, ldbg_graph** out);
 /* same, from an in-memory image of a .ctx file (header + records) */
 ldbg_status ldbg_graph_open_memory(const void* image, int64_t nbytes, int device, ldbg_graph** out);
+/* same, the header bytes on the host and the records (sorted, the file's record layout) already in DEVICE memory: a shard of a
+ * hash-partitioned table cut on the device (corticall_amd/distributed.py) is laid out without a round trip through the host */
+ldbg_status ldbg_graph_open_device(const void* header, int64_t header_bytes, const void* d_records, int64_t n_records, int device, ldbg_graph** out);
 /* new CortexCollection(graphs...)   J/utils/io/graph/cortex/CortexCollection.java:34-58: several sorted graphs of one k-mer size as ONE
  * graph, every member's colours side by side, merged on the device without writing a file.  find_view = 0: the records its
  * iterator yields (:218-293, the union of the members' k-mers); find_view = 1: the graph its findRecord answers from (:160-188, one

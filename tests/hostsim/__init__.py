@@ -10,10 +10,11 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SO = os.path.join(ROOT, "tests", "hostsim", "_build", "libldbg_hostsim.so")
+SO16 = os.path.join(ROOT, "tests", "hostsim", "_build16", "libldbg_hostsim.so")
 
 
-def build():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "corticall_amd", "csrc"), "hostsim", "-j8"],
+def build(target="hostsim"):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "corticall_amd", "csrc"), target, "-j8"],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
@@ -23,3 +24,15 @@ def load(rebuild=True):
     if rebuild:
         build()
     return NativeLib(SO)
+
+
+def load_wavefront(lanes=64, rebuild=True):
+    """the simulation with `lanes` lanes per wavefront in LOCK STEP (csrc/rt.h: one fibre per lane, wavefront primitives are barriers) and the
+    device's 16 link-store elements per lane: the wave-cooperative code — lscoop.h (whole-wavefront and 16-lane group operations), table
+    regrowth, path expansion, request bucketing — runs on the CPU as it does on the device"""
+    from corticall_amd import NativeLib
+    if rebuild:
+        build("hostsim16")
+    lib = NativeLib(SO16)
+    lib.dll.ldbg_hostsim_set_lanes(int(lanes))
+    return lib
