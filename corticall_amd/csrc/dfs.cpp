@@ -181,6 +181,10 @@ LDBG_DEV uint32_t append_failure(const DfsArgs& a, const StrandState& st) {
 template <int W>
 LDBG_DEV bool log_vertex(const DfsArgs& a, DfsLane<W>& L, const Node& v, const Kmer<W>& nk) {
     StrandState& st = L.st;
+#ifdef LDBG_HOSTSIM
+    if (getenv("LDBG_DFS_TRACE_IDX") && v.idx == atoll(getenv("LDBG_DFS_TRACE_IDX")))
+        fprintf(stderr, "KL log_vertex idx %d flip %d copy %d depth %u iters %u gV %u logpos %u ui_valid %d pos %u cut %u\n", v.idx, (int)v.flip, v.copy, L.depth, st.iters, st.gV, st.pw.n, (int)ui_valid(v.ui), ui_pos(v.ui), L.cut);
+#endif
     if (!path_append(a.w, st.s, st.pw, pack_vertex(v))) return false;
     if (v.idx < 0) {
         if (!path_append(a.w, st.s, st.pw, DFS_KMER)) return false;
@@ -222,7 +226,13 @@ LDBG_DEV bool merged_vertices(const DfsArgs& a, DfsLane<W>& L, uint32_t start, u
         uint32_t h = (uint32_t)(sig_mix(key) >> 20) & (cap - 1u);
         while (true) {
             const uint64_t cur = path_read(a.w, st.s, end + h);
-            if (cur == 0ull) { path_write(a.w, st.s, end + h, key); count++; return; }
+            if (cur == 0ull) {
+                path_write(a.w, st.s, end + h, key); count++;
+#ifdef LDBG_HOSTSIM
+                if (getenv("LDBG_DFS_TRACE_KEYS")) fprintf(stderr, "K %u %lld %d %d\n", L.depth, (long long)path_idx(key), (int)path_flip(key), path_copy(key));
+#endif
+                return;
+            }
             if (cur == key) return;
             h = (h + 1u) & (cap - 1u);
         }
@@ -232,6 +242,9 @@ LDBG_DEV bool merged_vertices(const DfsArgs& a, DfsLane<W>& L, uint32_t start, u
         const uint64_t en = path_read(a.w, st.s, pos);
         if (!(en & DFS_MARK)) {
             if (path_idx(en) < 0) { st.status = ST_MERGE_UNSUPPORTED; return false; }
+#ifdef LDBG_HOSTSIM
+            if (getenv("LDBG_DFS_TRACE_IDX") && path_idx(en) == atoll(getenv("LDBG_DFS_TRACE_IDX"))) fprintf(stderr, "KV single pos %u flip %d copy %d depth %u\n", pos, (int)path_flip(en), path_copy(en), L.depth);
+#endif
             insert(en & ident);
             continue;
         }
@@ -243,6 +256,9 @@ LDBG_DEV bool merged_vertices(const DfsArgs& a, DfsLane<W>& L, uint32_t start, u
         const int copy = st.fwd ? (int)acopy : -(int)acopy;
         for (uint32_t t = 0; t < len; t++) {                              // as k_expand_paths (walk.cpp) materialises them
             const uint32_t u = LDBG_GLOBAL(const uint32_t, a.w.e.runs.uo)[asc ? first + t : first - t];
+#ifdef LDBG_HOSTSIM
+            if (getenv("LDBG_DFS_TRACE_IDX") && (int64_t)(u & 0x7FFFFFFFu) == atoll(getenv("LDBG_DFS_TRACE_IDX"))) fprintf(stderr, "KV run pos %u t %u of len %u first %u asc %d inv %d copy %d depth %u\n", pos, t, len, first, (int)asc, (int)inv, copy, L.depth);
+#endif
             insert(path_pack((int64_t)(u & 0x7FFFFFFFu), ((u >> 31) != 0u) != inv, 0u, copy) & ident);
         }
     }
@@ -252,7 +268,7 @@ LDBG_DEV bool merged_vertices(const DfsArgs& a, DfsLane<W>& L, uint32_t start, u
 
 // dfs(cv, goForward, size, depth, visited, sinks) entered: TraversalEngine.java:356-371
 template <int W>
-LDBG_DEV void open_branch(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, const Node& av, const Kmer<W>& avk, uint32_t size) {
+LDBG_DEV void open_branch(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, const Node& av, const Kmer<W>& avk, uint32_t size, int64_t slot) {
     StrandState& st = L.st;
     const EngineView& e = a.w.e;
     if ((int)L.depth >= a.max_depth) { st.status = ST_DEPTH_OVERFLOW; return; }
@@ -268,6 +284,29 @@ LDBG_DEV void open_branch(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, con
     st.cv = av;
     L.nullk = avk;
     L.cut = av.idx >= 0 && ui_valid(av.ui) ? ui_pos(av.ui) : LDBG_RUN_NONE;     // (Node.ui is 0 where the engine has no run index)
+    if (L.cut != LDBG_RUN_NONE && L.depth > 0u) {
+        // This branch's first vertex cuts the piece it lies in.  If a branch further up THIS chain has crossed that piece — its interior is
+        // marked under the piece's key (runstep.h) — the cut would leave vertices the ancestor visited as interior ones behind per-vertex
+        // entries that know nothing of that visit (copy indices and the "visited before" test of :424 would come out wrong: a search
+        // that circles back INTO a stretch it crossed; found by the seed sweep, tests/test_soak_hostsim.py seed 231).  The two
+        // representations cannot be reconciled here: the search is handed back and run again without the index (ST_RETRY_PLAIN).
+        const uint32_t pos = L.cut;
+        uint32_t S = pos - ui_dstart(av.ui), E = pos + ui_dend(av.ui);
+        for (uint32_t d = 0; d < L.depth; d++) piece_cut(S, E, pos, LDBG_GLOBAL(const uint32_t, &a.frames[(size_t)slot * a.max_depth + d].cut)[0]);
+        if (E - S + 1u >= LDBG_RUN_MIN) {
+            // (in either orientation: the cut is a position, it shortens the piece for the vertices of both strands of the chain)
+            for (uint64_t plus = 0; plus < 2ull && st.status == ST_OK; plus++) {
+                const uint64_t key = (1ull << 33) | ((uint64_t)S << 1) | plus;      // runstep.h: piece_key
+                uint32_t h = vt_hash(key) & st.vt.mask;
+                for (uint32_t probes = 0; probes <= st.vt.mask; probes++, h = (h + 1u) & st.vt.mask) {
+                    const uint64_t ev = LDBG_GLOBAL(const uint64_t, st.vt.tab)[h];
+                    if (ev == 0ull) break;
+                    if ((ev & LDBG_VT_KEY_MASK) == key) { if (vt_count_e(ev) > 0) st.status = ST_RETRY_PLAIN; break; }
+                }
+            }
+            if (st.status != ST_OK) return;
+        }
+    }
     if (!path_append(a.w, st.s, st.pw, DFS_OPEN) || !log_vertex<W>(a, L, av, avk)) { st.status = append_failure(a, st); return; }
     st.quirk |= av.flip && !av.fj;
     if (e.cursor_on) {                                   // seek(cv.getKmerAsString()) :363-365
@@ -558,9 +597,12 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
                 uint32_t merged = 0;
                 if (!merged_vertices<W>(a, L, F.kids_start, merged)) return true;
                 size = F.size + (F.gV ? F.gV : 1u) + merged;
+#ifdef LDBG_HOSTSIM
+                if (getenv("LDBG_DFS_TRACE")) fprintf(stderr, "P sibling depth %u F.size %u F.gV %u merged %u kids_start %u log_end %u\n", L.depth, F.size, F.gV, merged, F.kids_start, st.pw.n);
+#endif
             }
             L.depth++;
-            open_branch<W>(a, L, ls, av, avk, size);
+            open_branch<W>(a, L, ls, av, avk, size, slot);
             if (st.cv.npe && st.status == ST_OK) st.status = ST_NULLPTR;
             return st.status != ST_OK;
         }
@@ -653,7 +695,7 @@ LDBG_DEV bool dfs_step(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_
 }
 
 template <int W>
-LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t s) {
+LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64_t s, int64_t slot) {
     StrandState& st = L.st;
     const EngineView& e = a.w.e;
     st.s = s;
@@ -677,7 +719,7 @@ LDBG_DEV bool dfs_begin(const DfsArgs& a, DfsLane<W>& L, LinkStoreDev& ls, int64
         node_locate(st.vt, v);
     } else node_null(e, v);
     if (v.npe) { st.status = ST_NULLPTR; return false; }
-    open_branch<W>(a, L, ls, v, sk, 0);
+    open_branch<W>(a, L, ls, v, sk, 0, slot);
     return st.status == ST_OK;
 }
 
@@ -729,14 +771,15 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
             const int64_t fi = (int64_t)atomic_add_u64(a.w.next_strand, 1ull);
             if (fi >= a.w.n_strands) exhausted = true;
             else {
-                const int64_t s = (int64_t)(((unsigned __int128)fi * (unsigned __int128)a.w.fetch_stride) % (unsigned __int128)a.w.n_strands);
+                const int64_t s = a.w.retry ? (int64_t)a.w.retry[fi]          // (the second launch: only the searches the run steps handed back)
+                                            : (int64_t)(((unsigned __int128)fi * (unsigned __int128)a.w.fetch_stride) % (unsigned __int128)a.w.n_strands);
                 const bool fwd = (s & 1) != 0;
                 if ((fwd && !a.w.run_fwd) || (!fwd && !a.w.run_rev)) {
                     a.w.strand_n[s] = 0; a.w.status[s] = ST_BRANCH_NULL; a.w.iters[s] = 0; a.w.quirk[s] = 0;
                 } else if (IMG) {
                     L.st.s = s; L.st.fwd = fwd; active = true; begun = false;
                 } else {
-                    active = dfs_begin<W>(a, L, ls, s);
+                    active = dfs_begin<W>(a, L, ls, s, slot);
                     if (!active) strand_finish(a.w, L.st);
                 }
             }
@@ -758,7 +801,7 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
                 if (!ready) suspended = true;
                 else {
                     begun = true;
-                    active = dfs_begin<W>(a, L, ls, st.s);
+                    active = dfs_begin<W>(a, L, ls, st.s, slot);
                     if (!active) strand_finish(a.w, L.st);
                 }
             }
@@ -1407,22 +1450,26 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
             }
         }
     };
+    const RunIndexView log_runs = a.w.e.runs;       // the logs of the first launch hold RUN descriptors over this index, whatever runs afterwards
     if (!sharded) {
         launch(s);
         if (a.w.e.runs.uinfo) {
-            // a search the run steps handed back (ST_RETRY_PLAIN: cases they leave to the k-mer-by-k-mer code) sends the chunk round again without the index
+            // the searches the run steps handed back (ST_RETRY_PLAIN: cases they leave to the k-mer-by-k-mer code) go round again without the
+            // index — those searches only: the others keep their logs; the pool cursors carry on (fresh tables and blocks behind the used ones)
             std::vector<uint32_t> st0((size_t)ns);
             rt::d2h(st0.data(), d_status, (size_t)ns * 4, s);
-            unsigned long long c0[4] = {0, 0, 0, 0};
-            rt::d2h(c0, d_ctr, 32, s);
             rt::stream_sync(s);
-            bool again = getenv("LDBG_DFS_FORCE_RETRY") != nullptr;      // (test hook: take the second launch whatever the first one said)
-            for (int64_t i = 0; i < ns; i++) again |= st0[(size_t)i] == ST_RETRY_PLAIN;
-            if (again) {
-                vpool_dirty_ = c0[2];
-                zero_dirty_tables(s);
-                rt::dmemset(d_ctr, 0, 64, s);
+            const bool force = getenv("LDBG_DFS_FORCE_RETRY") != nullptr;      // (test hook: every search takes the second launch)
+            std::vector<uint32_t> again;
+            for (int64_t i = 0; i < ns; i++) if (force || st0[(size_t)i] == ST_RETRY_PLAIN) again.push_back((uint32_t)i);
+            if (!again.empty()) {
+                uint32_t* d_retry = (uint32_t*)tmp.get(again.size() * 4);
+                rt::h2d(d_retry, again.data(), again.size() * 4, s);
+                rt::dmemset(d_ctr, 0, 8, s);                           // the strand queue starts over
                 a.w.e.runs = RunIndexView{nullptr, nullptr, nullptr};
+                a.w.retry = d_retry;
+                a.w.n_strands = (int64_t)again.size();
+                dfs_retried_ += (int64_t)again.size();
                 launch(s);
             }
         }
@@ -1516,7 +1563,7 @@ bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vecto
         uint64_t* d_dense = (uint64_t*)tmp.get((size_t)total * 8);
         rt::h2d(d_off, strand_off.data(), (size_t)(ns + 1) * 8, s);
         unsigned* d_ovf = (unsigned*)tmp.get(4);
-        launch_expand_paths(d_strand_n, d_off, ns, d_dense, max_blocks, a.w.e.runs, d_ovf);
+        launch_expand_paths(d_strand_n, d_off, ns, d_dense, max_blocks, log_runs, d_ovf);
         rt::d2h(log, d_dense, (size_t)total * 8, s);
         rt::stream_sync(s);
     }

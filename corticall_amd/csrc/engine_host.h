@@ -113,6 +113,7 @@ public:
     int dfs_max_depth = 64;
     int dfs_log_blocks = 64;          // path blocks (1024 entries) one strand's dfs log may use
     int64_t dfs_traversed() const { return dfs_traversed_; }
+    int64_t dfs_retried_ = 0;         // searches that took the second launch without the run index
     int64_t retried_strands() const { return retried_strands_; }
 
     int64_t batch_n = 0, batch_bytes = 0, batch_traversed = 0;

@@ -244,18 +244,18 @@ LDBG_DEV bool coop_next_choice(const LinksView& Lk, const LsWave& v, int L, LsHd
 // its group and back the same way.  An owner qualifies when its store (after the adds) fits one element per lane of a group
 // and all its junction records were gathered; the others take the whole-wavefront path as before.  Semantics: those of
 // coop_add / the one-element-per-lane branch of coop_next_choice, statement by statement.
-#define LDBG_GS 16u
+#define LDBG_GS 16u          // the wider of the two group sizes (8 and 16 lanes: eight or four owners at a time)
 LDBG_DEV uint32_t grp_shfl(uint32_t v, uint32_t src_lane) { return wave_shfl_u32(v, (int)(src_lane & 63u)); }
-LDBG_DEV uint32_t grp_mask(unsigned long long ballot, uint32_t g) { return (uint32_t)(ballot >> (LDBG_GS * g)) & 0xFFFFu; }
+template <uint32_t GS> LDBG_DEV uint32_t grp_mask(unsigned long long ballot, uint32_t g) { return (uint32_t)(ballot >> (GS * g)) & ((1u << GS) - 1u); }
 struct GrpTake { uint32_t myL; bool gv; int myq; };
 // the next (up to) four owners of `todo` (wave-uniform): which owner this lane's group works for, and — for an owner lane of this
 // batch — the group that works for it (myq, else -1)
-LDBG_DEV GrpTake grp_take(unsigned long long& todo) {
-    const uint32_t lane = (uint32_t)wave_lane(), g = lane >> 4;
+template <uint32_t GS> LDBG_DEV GrpTake grp_take(unsigned long long& todo) {
+    const uint32_t lane = (uint32_t)wave_lane(), g = lane / GS;
     GrpTake t;
     t.myL = 0; t.gv = false; t.myq = -1;
 #pragma unroll
-    for (uint32_t q = 0; q < 4; q++) {
+    for (uint32_t q = 0; q < 64u / GS; q++) {
         if (!todo) break;
         const int L = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -265,11 +265,11 @@ LDBG_DEV GrpTake grp_take(unsigned long long& todo) {
     return t;
 }
 
-LDBG_DEV void group_adds(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls, unsigned long long todo, uint64_t m_cur, uint64_t m_nxt,
+template <uint32_t GS> LDBG_DEV void group_adds(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls, unsigned long long todo, uint64_t m_cur, uint64_t m_nxt,
                          uint32_t start_cur, uint32_t start_nxt, uint32_t flags, const JuncRec& gathered, StepPre& pre) {
-    const uint32_t lane = (uint32_t)wave_lane(), g = lane >> 4, sub = lane & 15u;
+    const uint32_t lane = (uint32_t)wave_lane(), g = lane / GS, sub = lane % GS;
     while (todo) {
-        const GrpTake t = grp_take(todo);
+        const GrpTake t = grp_take<GS>(todo);
         uint32_t n = grp_shfl(ls.n, t.myL), java_cap = grp_shfl(ls.java_cap, t.myL), nkeys = grp_shfl(ls.nkeys, t.myL), next_seq = grp_shfl(ls.next_seq, t.myL);
         uint32_t n_new = grp_shfl(ls.n_new, t.myL);
         const uint32_t age = grp_shfl(ls.age, t.myL), cap = grp_shfl(ls.cap, t.myL);
@@ -277,7 +277,8 @@ LDBG_DEV void group_adds(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls,
         const uint32_t sc = grp_shfl(start_cur, t.myL), sn = grp_shfl(start_nxt, t.myL), fl = grp_shfl(flags, t.myL);
         const uint32_t R = t.gv ? cnt_cur + cnt_nxt : 0u;
         uint32_t maxR = wave_bcast_u32(R, 0);
-        { const uint32_t r1 = wave_bcast_u32(R, 16), r2 = wave_bcast_u32(R, 32), r3 = wave_bcast_u32(R, 48); maxR = maxR > r1 ? maxR : r1; maxR = maxR > r2 ? maxR : r2; maxR = maxR > r3 ? maxR : r3; }
+#pragma unroll
+        for (uint32_t q = 1; q < 64u / GS; q++) { const uint32_t rq = wave_bcast_u32(R, (int)(q * GS)); maxR = maxR > rq ? maxR : rq; }
         LsElem y;
         y.str_off = 0; y.birth = 0; y.hash = 0; y.key_seq = 0; y.len = 0; y.pos = 0; y.comp = 0; y.nxn = 0; y.nx = 0;
         if (t.gv && sub < n) y = lsw_get(v, (int)t.myL, sub);
@@ -298,9 +299,9 @@ LDBG_DEV void group_adds(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls,
             x.len = (uint16_t)jr.len; x.pos = 0; x.comp = lgf ? 0 : 1; x.key_seq = 0;
             ls_first_nx(jr, x);
             const bool match = use && sub < n && ls_same_string(Lk, y, x);
-            const uint32_t gm = grp_mask(wave_ballot(match), g);
+            const uint32_t gm = grp_mask<GS>(wave_ballot(match), g);
             const uint32_t top = gm ? 31u - (uint32_t)__builtin_clz(gm) : 0u;        // the newest element filed under the same junction string
-            const uint32_t ks = grp_shfl(y.key_seq, (g << 4) + top);
+            const uint32_t ks = grp_shfl(y.key_seq, (g * GS) + top);
             if (use) {
                 if (gm) x.key_seq = ks;
                 else {
@@ -318,7 +319,7 @@ LDBG_DEV void group_adds(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls,
         }
         wave_fence();
         // the headers go back to their owners
-        const uint32_t back = t.myq >= 0 ? (uint32_t)t.myq << 4 : lane;
+        const uint32_t back = t.myq >= 0 ? (uint32_t)t.myq * GS : lane;
         const uint32_t rn = grp_shfl(n, back), rcap = grp_shfl(java_cap, back), rkeys = grp_shfl(nkeys, back), rseq = grp_shfl(next_seq, back), rnew = grp_shfl(n_new, back);
         const uint32_t rovf = grp_shfl(ovf ? 1u : 0u, back);
         if (t.myq >= 0) {
@@ -329,54 +330,56 @@ LDBG_DEV void group_adds(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls,
 }
 
 // getNextJunctionChoice for (up to) four owners at once; every owner in `todo` has 1 <= n <= 16 elements
-LDBG_DEV void group_choices(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls, unsigned long long todo, StepPre& pre) {
-    const uint32_t lane = (uint32_t)wave_lane(), g = lane >> 4, sub = lane & 15u;
+template <uint32_t GS> LDBG_DEV void group_choices(const LinksView& Lk, const LsWave& v, LinkStoreDev& ls, unsigned long long todo, StepPre& pre) {
+    const uint32_t lane = (uint32_t)wave_lane(), g = lane / GS, sub = lane % GS;
     while (todo) {
-        const GrpTake t = grp_take(todo);
+        const GrpTake t = grp_take<GS>(todo);
         const uint32_t n = grp_shfl(ls.n, t.myL), java_cap = grp_shfl(ls.java_cap, t.myL), age = grp_shfl(ls.age, t.myL);
         uint32_t nkeys = grp_shfl(ls.nkeys, t.myL);
         const bool valid = t.gv && sub < n;
         LsElem x;
         x.str_off = 0; x.birth = 0; x.hash = 0; x.key_seq = 0; x.len = 0; x.pos = 0; x.comp = 0; x.nxn = 0; x.nx = 0;
         if (valid) x = lsw_get(v, (int)t.myL, sub);
-        const uint32_t minbirth0 = grp_shfl(x.birth, g << 4);                    // births never decrease along the array: element 0 is among the oldest
+        const uint32_t minbirth0 = grp_shfl(x.birth, g * GS);                    // births never decrease along the array: element 0 is among the oldest
         const unsigned c = ls_cur(x);
-        const unsigned c0 = grp_shfl(c, g << 4);
+        const unsigned c0 = grp_shfl(c, g * GS);
         const bool old = valid && x.birth == minbirth0;
-        const uint32_t differ = grp_mask(wave_ballot(old && c != c0), g);          // (every lane takes part in every ballot: no short circuits around them)
+        const uint32_t differ = grp_mask<GS>(wave_ballot(old && c != c0), g);          // (every lane takes part in every ballot: no short circuits around them)
         const bool ok = t.gv && differ == 0u;                                    // the oldest links must agree (:92-119)
         // first of the oldest links in HashMap iteration order (bucket, key insertion order): minimum over the group
         const uint32_t hh = (uint32_t)x.hash;
         uint64_t best = old ? (((uint64_t)((hh ^ (hh >> 16)) & (java_cap - 1u)) << 32) | x.key_seq) : ~0ull;
 #pragma unroll
-        for (int m = 8; m > 0; m >>= 1) {
-            const uint32_t lo = wave_shfl_u32((uint32_t)best, (int)(lane ^ (uint32_t)m)), hi = wave_shfl_u32((uint32_t)(best >> 32), (int)(lane ^ (uint32_t)m));     // (stays inside the group: m < 16)
+        for (int m = (int)GS / 2; m > 0; m >>= 1) {
+            const uint32_t lo = wave_shfl_u32((uint32_t)best, (int)(lane ^ (uint32_t)m)), hi = wave_shfl_u32((uint32_t)(best >> 32), (int)(lane ^ (uint32_t)m));     // (stays inside the group: m < GS)
             const uint64_t o = ((uint64_t)hi << 32) | lo;
             best = o < best ? o : best;
         }
         const uint32_t seq1 = (uint32_t)best;
-        const uint32_t kbm = grp_mask(wave_ballot(valid && x.key_seq == seq1), g);       // the last element filed under that key supplies the choice (:129-133)
-        const unsigned ch1 = grp_shfl(c, (g << 4) + (kbm ? 31u - (uint32_t)__builtin_clz(kbm) : 0u));
+        const uint32_t kbm = grp_mask<GS>(wave_ballot(valid && x.key_seq == seq1), g);       // the last element filed under that key supplies the choice (:129-133)
+        const unsigned ch1 = grp_shfl(c, (g * GS) + (kbm ? 31u - (uint32_t)__builtin_clz(kbm) : 0u));
         const bool keep = valid && lsw_keeps(x, ch1);
         // keys whose last element expires leave the HashMap (:84-88)
         const unsigned long long deadb = wave_ballot(ok && valid && !keep);
-        const uint32_t dead_g = grp_mask(deadb, g);
-        uint32_t any = (uint32_t)((deadb | (deadb >> 16) | (deadb >> 32) | (deadb >> 48)) & 0xFFFFull);
+        const uint32_t dead_g = grp_mask<GS>(deadb, g);
+        uint32_t any = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 64u / GS; q++) any |= grp_mask<GS>(deadb, q);
         while (any) {
             const uint32_t sd = (uint32_t)__builtin_ctz(any);
             any &= any - 1u;
-            const uint32_t ks = grp_shfl(x.key_seq, (g << 4) + sd);
+            const uint32_t ks = grp_shfl(x.key_seq, (g * GS) + sd);
             const bool hit = valid && x.key_seq == ks && sub != sd && (sub < sd || keep);
-            const uint32_t hm = grp_mask(wave_ballot(hit), g);
+            const uint32_t hm = grp_mask<GS>(wave_ballot(hit), g);
             if (((dead_g >> sd) & 1u) && hm == 0u) nkeys--;
         }
         LsElem xa = x;
         if (ok && keep) ls_advance(Lk, xa);
-        const uint32_t kb = grp_mask(wave_ballot(ok && keep), g);
+        const uint32_t kb = grp_mask<GS>(wave_ballot(ok && keep), g);
         if (ok && keep) lsw_set(v, (int)t.myL, (uint32_t)__builtin_popcount(kb & ((1u << sub) - 1u)), xa);
-        const uint32_t nn = grp_mask(wave_ballot(ok && keep && x.birth == age), g);
+        const uint32_t nn = grp_mask<GS>(wave_ballot(ok && keep && x.birth == age), g);
         wave_fence();
-        const uint32_t back = t.myq >= 0 ? (uint32_t)t.myq << 4 : lane;
+        const uint32_t back = t.myq >= 0 ? (uint32_t)t.myq * GS : lane;
         const uint32_t rok = grp_shfl(ok ? 1u : 0u, back), rch = grp_shfl(ch1, back), rkeys = grp_shfl(nkeys, back);
         const uint32_t rn = grp_shfl((uint32_t)__builtin_popcount(kb), back), rnew = grp_shfl((uint32_t)__builtin_popcount(nn), back);
         if (t.myq >= 0) {
@@ -440,10 +443,20 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
         const uint32_t r_cur = m_cur == ~0ull ? 0u : (uint32_t)(m_cur >> 32), r_nxt = m_nxt == ~0ull ? 0u : (uint32_t)(m_nxt >> 32);
         const bool mine = (m_cur != ~0ull || m_nxt != ~0ull) && !ls.overflow && ls.n + r_cur + r_nxt <= LDBG_GS &&
                           (m_cur == ~0ull || start_cur != LDBG_NOT_GATHERED) && (m_nxt == ~0ull || start_nxt != LDBG_NOT_GATHERED);
+        // (a store of at most 8 elements — 94 % of the adds at C3 — takes an 8-lane group: eight owners at a time)
+        const unsigned long long grouped8 = wave_ballot(mine && ls.n + r_cur + r_nxt <= 8u);
         const unsigned long long grouped = wave_ballot(mine);
+#ifdef LDBG_WALK_DIAG
+        if (tdiag) {      // [3] owners of adds that take the 16-lane group path | those whose store would fit an 8-lane group << 16 | sum of their store sizes << 32
+            const unsigned long long g8 = wave_ballot(mine && ls.n + r_cur + r_nxt <= 8u);
+            const uint32_t nsum = wave_incl_scan_u32((m_cur != ~0ull || m_nxt != ~0ull) ? ls.n + r_cur + r_nxt : 0u);
+            tdiag[3] = (unsigned long long)__builtin_popcountll(grouped) | ((unsigned long long)__builtin_popcountll(g8) << 16) | ((unsigned long long)wave_bcast_u32(nsum, 63) << 32);
+        }
+#endif
         if (grouped) {
             const uint32_t flags = (st.cu.cur.flip ? 1u : 0u) | (st.cu.nxt.flip ? 2u : 0u) | (st.fwd ? 4u : 0u);
-            group_adds(e.links, lw, ls, grouped, m_cur, m_nxt, start_cur, start_nxt, flags, gathered, pre);
+            if (grouped8) group_adds<8>(e.links, lw, ls, grouped8, m_cur, m_nxt, start_cur, start_nxt, flags, gathered, pre);
+            if (grouped & ~grouped8) group_adds<16>(e.links, lw, ls, grouped & ~grouped8, m_cur, m_nxt, start_cur, start_nxt, flags, gathered, pre);
             need &= ~grouped;
         }
     }
@@ -471,7 +484,10 @@ LDBG_DEV void coop_step_prepare(const EngineView& e, StrandState& st, LinkStoreD
 #endif
     if (wave_size() == 64 && lw.fast_cap >= LDBG_GS) {
         const unsigned long long grouped = wave_ballot(cur_mode && popc4(nmask) > 1 && ls.n >= 1u && ls.n <= LDBG_GS);
-        if (grouped) { group_choices(e.links, lw, ls, grouped, pre); need &= ~grouped; }
+        const unsigned long long grouped8 = wave_ballot(cur_mode && popc4(nmask) > 1 && ls.n >= 1u && ls.n <= 8u);
+        if (grouped8) group_choices<8>(e.links, lw, ls, grouped8, pre);
+        if (grouped & ~grouped8) group_choices<16>(e.links, lw, ls, grouped & ~grouped8, pre);
+        need &= ~grouped;
     }
     while (need) {                                    // junction choices (:266-272)
         const int L = __builtin_ctzll(need);

@@ -112,7 +112,7 @@ LDBG_DEV unsigned long long atomic_min_u64(unsigned long long* p, unsigned long 
 LDBG_DEV unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long v) { return atomicCAS(p, cmp, v); }
 LDBG_DEV unsigned long long atomic_exch_u64(unsigned long long* p, unsigned long long v) { return atomicExch(p, v); }
 // wavefront primitives (64 lanes on gfx950); kernels that use them are launched with 64-thread blocks
-LDBG_DEV int wave_size() { return (int)blockDim.x; }   // wave kernels run one (possibly partial) wavefront per workgroup
+LDBG_DEV int wave_size() { return blockDim.x < 64u ? (int)blockDim.x : 64; }   // a (possibly partial) wavefront; workgroups of several wavefronts index them by global_tid() / wave_size()
 LDBG_DEV int wave_lane() { return (int)(threadIdx.x & 63u); }
 LDBG_DEV unsigned long long wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
 // broadcast from a lane every lane agrees on (src is wave-uniform at every call site: it comes from a ballot): v_readlane,

@@ -220,7 +220,8 @@ LDBG_DEV bool strand_begin(const WalkArgs& a, StrandState& st, LinkStoreDev& ls,
 // slots it carries.
 LDBG_DEV void wave_grow_tables(const WalkArgs& a, StrandState& st, bool active) {
     const uint32_t cap = st.vt.mask + 1;
-    const bool need = active && st.status == ST_OK && (st.vt.used + 8) * (uint32_t)(a.grow_at > 2 ? a.grow_at : 2) > cap && cap < a.vcap_max;
+    // (room for what ONE iteration can claim: a run step's three entries, a lean run's four, a general step's children)
+    const bool need = active && st.status == ST_OK && (st.vt.used + 16) * (uint32_t)(a.grow_at > 2 ? a.grow_at : 2) > cap && cap < a.vcap_max;
     unsigned long long ballot = wave_ballot(need);
     const int lane = wave_lane();
     while (ballot) {

@@ -15,6 +15,13 @@
 
 namespace ldbg {
 
+// Launch geometry of the one-wavefront-per-strand (or per-seed) stream kernels, measured for k_contigs_rle at C3 (profiles/r03_rle_geometry.log):
+// one-wavefront workgroups, one per seed (no grid-stride loop) 0.75 ms; 16,384 of them 0.83 ms; four-wavefront workgroups 0.79-0.87 ms, and
+// 1.04 ms on a grid the chip holds at once (2,048 x 256).  The kernel is a chain of dependent trips per seed (PMC, profiles/r03a_pmc.log:
+// 4,076 wavefronts in flight on average, 208 us each), so what helps is MORE short-lived wavefronts, not fewer long ones.
+#define LDBG_STREAM_BLOCK 64
+#define LDBG_STREAM_GRID 65536
+
 // the walk kernel's strand_finish: strand_n counts VERTICES (runs are stored as descriptors), strand_c the stored entries
 LDBG_DEV void walk_finish(const WalkArgs& a, StrandState& st) {
     strand_finish(a, st);
@@ -227,7 +234,8 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
 #endif
         // ---- run step: a whole unbranched stretch at once (runstep.h)
         bool stepped = false;
-        if (runs_on && running) {
+        auto run_phase = [&](bool on) {
+            if (!(runs_on && on)) return;
             const bool ma = run_mode_a(a, st, rs);
             const bool mb = !ma && run_mode_b(a, st, rs);
             if (ma || mb) {
@@ -237,12 +245,18 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
                 kc_run++; kc_runv += st.iters - it0;
                 if (ended) { walk_finish(a, st); active = false; }
             }
-        }
+        };
+        run_phase(running);
 #ifdef LDBG_WALK_DIAG
         unsigned long long tc2 = 0;
         if (a.wave_cat) tc2 = __builtin_amdgcn_s_memrealtime();
 #endif
-        const bool lean = running && active && !stepped && lean_ok(a, st) && !(runs_on && run_entry_a(a.e, st, rs));
+        // The phases of an iteration fall through (resident table): a strand that has just crossed a stretch goes on with its lean steps,
+        // and one that has moved and now stands before a junction or a link-flagged vertex takes its general step, all in THIS iteration.
+        // Per unitig a strand then spends three iterations (choice; adds; run + lean + the next choice) where it spent five, and an
+        // iteration costs the wavefront the same whichever of its lanes use which phase.  (Over an image a strand that has moved must have
+        // its rows checked first: one phase per iteration there.)
+        const bool lean = running && active && (!IMG || !stepped) && lean_ok(a, st) && !(runs_on && run_entry_a(a.e, st, rs));
         if (lean) {
             // a short run of lean steps without going round the outer loop (its ballots, refill and regrowth checks): every lean
             // step claims at most one table slot, and the regrowth check above leaves room for eight
@@ -261,16 +275,20 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             wc[0] += 1; wc[1] += tc1 - tc0; wc[2] += tc2 - tc1; wc[3] += tc3 - tc2;
         }
 #endif
-        const unsigned long long general_lanes = wave_ballot(running && active && !lean && !stepped);
+        bool general = running && active;
+        if (general && (lean || stepped)) {          // it has moved: does it need a general step now, or another run / lean step (next iteration)?
+            if constexpr (IMG) general = false;
+            else general = !(runs_on && (run_mode_a(a, st, rs) || run_mode_b(a, st, rs))) && !(lean_ok(a, st) && !(runs_on && run_entry_a(a.e, st, rs)));
+        }
+        const unsigned long long general_lanes = wave_ballot(general);
         if (general_lanes == 0ull) continue;          // the whole wavefront took a lean or a run step (or waits for rows)
         wave_general++;
 #ifdef LDBG_WALK_DIAG
-        unsigned long long tc4 = 0, tprep[3] = {0, 0, 0};
+        unsigned long long tc4 = 0, tprep[4] = {0, 0, 0, 0};
         if (a.wave_cat) tc4 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long t_general = a.st_gen ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
         // ---- link-store work of this step, carried out by the whole wavefront for one lane at a time (lscoop.h)
-        const bool general = running && active && !lean && !stepped;
         const bool cur_mode = general && st.status == ST_OK && a.e.cursor_on && st.cu.has;
         StepPre pre;
         const uint32_t used1 = st.vt.used;
@@ -299,6 +317,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
             const unsigned long long tc6 = __builtin_amdgcn_s_memrealtime();
             wc[4] += 1; wc[5] += tc6 - tc4; wc[6] += tprep[0] - tc4; wc[7] += tprep[1] - tprep[0]; wc[8] += tc5 - tprep[1]; wc[9] += tc6 - tc5;
             wc[10] += (unsigned long long)__builtin_popcountll(general_lanes); wc[11] += tprep[2] & 0xFFFFFFFFull; wc[12] += tprep[2] >> 32;
+            wc[13] += tprep[3] & 0xFFFFull; wc[14] += (tprep[3] >> 16) & 0xFFFFull; wc[15] += tprep[3] >> 32;
         }
 #endif
     }
@@ -553,13 +572,18 @@ LDBG_KERNEL void k_contigs_rle(ContigRleArgs a) {
             // place of vertex v >= 1 of this strand in the contig: the reverse strand runs backwards from the seed
             auto place = [&](uint32_t v) -> int64_t { return fwd ? nrev + k - 1 + (int64_t)v : nrev - (int64_t)v; };
             uint32_t base_v = 0;
+            uint64_t carry = 0;                                    // the stored entry before this group's first
             for (uint32_t j0 = 0; j0 < nc; j0 += WS) {
+                // The kernel is a chain of dependent trips to memory per group of 64 stored entries (few bytes in flight per wavefront:
+                // Little's law held it at a fifth of the HBM rate), so every trip that can go, goes: the block's address is read once per
+                // group (64 entries never straddle a block), the entry before each lane's comes from its neighbour lane, and a descriptor's
+                // payload word is the entry of the lane after its head — three dependent loads per run round became one.
                 const uint32_t j = j0 + lane;
-                uint64_t e = 0, prev = 0;
-                if (j < nc) {
-                    e = rle_stored(a, s, j);
-                    if (j & (LDBG_PATH_BLOCK - 1)) prev = rle_stored(a, s, j - 1);
-                }
+                const uint64_t* blk = a.pool + (uint64_t)a.block_table[s * a.max_blocks + j0 / LDBG_PATH_BLOCK] * LDBG_PATH_BLOCK;
+                const uint64_t e = j < nc ? LDBG_GLOBAL(const uint64_t, blk)[j & (LDBG_PATH_BLOCK - 1)] : 0ull;
+                const uint64_t up = wave_shfl_u64(e, (int)lane - 1);
+                const uint64_t prev = (j & (LDBG_PATH_BLOCK - 1)) == 0u ? 0ull : (lane == 0u ? carry : up);
+                carry = wave_shfl_u64(e, (int)WS - 1);
                 const uint32_t cnt = j < nc ? pd_expanded(prev, e) : 0u;
                 const uint32_t incl = wave_incl_scan_u32(cnt);
                 const uint32_t at = base_v + incl - cnt;
@@ -586,11 +610,25 @@ LDBG_KERNEL void k_contigs_rle(ContigRleArgs a) {
                     const uint64_t he = wave_shfl_u64(e, (int)myL);
                     const uint32_t hat = wave_shfl_u32(at, (int)myL), len_of = wave_shfl_u32(cnt, (int)myL);
                     const uint32_t len = gv ? len_of : 0u;
-                    const uint64_t payload = gv ? rle_stored(a, s, j0 + myL + 1u) : 0ull;
+                    const uint64_t next_e = wave_shfl_u64(e, (int)myL + 1);         // the payload word follows its head
+                    const uint64_t payload = !gv ? 0ull : (myL + 1u < WS ? next_e : rle_stored(a, s, j0 + myL + 1u));
                     const bool asc = (he >> 36) & 1ull, inv = (he >> 37) & 1ull;
                     const uint32_t first = (uint32_t)payload;
                     const unsigned shift = (fwd != inv) ? 2u : 0u, comp = inv ? 3u : 0u;
                     auto ascii = [&](unsigned bb) -> unsigned { return (0x54474341u >> (8u * (((bb >> shift) & 3u) ^ comp))) & 0xFFu; };
+                    // four bytes of ubase -> four letters: the 2-bit fields of all four at once, then ONE byte permute out of the word "ACGT"
+                    // (v_perm_b32: a selector byte 0..3 picks that byte of the second source) — the letters were a third of the kernel's
+                    // instructions when they were looked up byte by byte
+                    auto ascii4 = [&](uint32_t bb4) -> uint32_t {
+                        const uint32_t f = ((bb4 >> shift) & 0x03030303u) ^ (comp * 0x01010101u);
+#ifndef LDBG_HOSTSIM
+                        return __builtin_amdgcn_perm(0u, 0x54474341u, f);
+#else
+                        uint32_t v = 0;
+                        for (int bI = 0; bI < 4; bI++) v |= ((0x54474341u >> (8u * ((f >> (8 * bI)) & 3u))) & 0xFFu) << (8 * bI);
+                        return v;
+#endif
+                    };
                     // low ends of the two byte ranges; same = both ascend with t or both descend
                     const uint8_t* in_lo = asc ? ub + first : ub + first - (len ? len - 1u : 0u);
                     char* out_lo = LDBG_GLOBAL(char, o) + (fwd ? place(hat) : place(hat + (len ? len - 1u : 0u)));
@@ -609,9 +647,7 @@ LDBG_KERNEL void k_contigs_rle(ContigRleArgs a) {
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             const uint32_t ci = base + (uint32_t)q * GS + sub;
-                            uint64_t v = 0;
-#pragma unroll
-                            for (int bI = 0; bI < 8; bI++) v |= (uint64_t)ascii((unsigned)(w[q] >> (8 * bI)) & 0xFFu) << (8 * bI);
+                            uint64_t v = (uint64_t)ascii4((uint32_t)w[q]) | ((uint64_t)ascii4((uint32_t)(w[q] >> 32)) << 32);
                             if (!same) v = __builtin_bswap64(v);
                             if (ci < nd) __builtin_memcpy(out_lo + 8u * ci, &v, 8);
                         }
@@ -627,11 +663,31 @@ LDBG_KERNEL void k_contigs_rle(ContigRleArgs a) {
                     const int L = __builtin_ctzll(hb);
                     hb &= hb - 1;
                     const uint32_t hat = wave_bcast_u32(at, L), len = wave_bcast_u32(cnt, L);
-                    const uint64_t payload = rle_stored(a, s, j0 + (uint32_t)L + 1);
+                    const uint64_t payload = (uint32_t)L + 1u < WS ? wave_bcast_u64(e, L + 1) : rle_stored(a, s, j0 + (uint32_t)L + 1);
                     wave_fence();
+                    // `len` further bases: the last recorded revolution (vertices first + period .. first + 2 period - 1 of this strand, already
+                    // spelled) again and again.  A walk that circles a repeat until maxLength has ~75,000 of them: copied a byte per lane and
+                    // trip (a load, then a store the next load had to wait for) one such strand took longer than the rest of the launch
+                    // together.  Eight bases per lane and access: eight independent byte loads, one store.
                     const uint32_t first = (uint32_t)payload, period = (uint32_t)(payload >> 32);
-                    for (uint32_t t = lane; t < len; t += WS)
-                        o[place(hat + t)] = LDBG_GLOBAL(const char, o)[place(first + period + t % period)];
+                    const uint32_t nch = (len + 7u) / 8u;
+                    for (uint32_t c = lane; c < nch; c += WS) {
+                        const uint32_t t0 = 8u * c, m = len - t0 < 8u ? len - t0 : 8u;
+                        uint32_t r = t0 % period;
+                        uint64_t v = 0;
+#pragma unroll
+                        for (uint32_t b = 0; b < 8u; b++) {
+                            if (b < m) {
+                                const uint64_t ch = (uint8_t)LDBG_GLOBAL(const char, o)[place(first + period + r)];
+                                v |= ch << (8u * (fwd ? b : m - 1u - b));
+                            }
+                            r++;
+                            if (r == period) r = 0;
+                        }
+                        char* lo = LDBG_GLOBAL(char, o) + (fwd ? place(hat + t0) : place(hat + t0 + m - 1u));
+                        if (m == 8u) __builtin_memcpy(lo, &v, 8);
+                        else for (uint32_t b = 0; b < m; b++) lo[b] = (char)(v >> (8u * b));
+                    }
                 }
                 base_v += wave_bcast_u32(incl, (int)WS - 1);
             }
@@ -858,7 +914,7 @@ void Engine::ensure_dense(WalkChunk& c) {
     xa.pool = (const uint64_t*)d_pool_; xa.block_table = (const uint32_t*)d_block_table_; xa.max_blocks = c.max_blocks;
     xa.strand_c = (const uint32_t*)c.d_strand_c; xa.strand_off = (const int64_t*)c.d_strand_off; xa.n_strands = ns;
     xa.runs = c.runs; xa.dense = (uint64_t*)c.d_path; xa.overflow = d_ovf;
-    LDBG_LAUNCH(k_expand_paths, grid_for(ns * 64, 64, 256 * 64), 64, s, xa);
+    LDBG_LAUNCH(k_expand_paths, grid_for(ns * 64, LDBG_STREAM_BLOCK, LDBG_STREAM_GRID), LDBG_STREAM_BLOCK, s, xa);
     unsigned ovf = 0;
     rt::d2h(&ovf, d_ovf, 4, s);
     rt::stream_sync(s);
@@ -890,7 +946,7 @@ LDBG_KERNEL void k_path_lengths(const uint64_t* pool, const uint32_t* block_tabl
     }
 }
 void Engine::launch_path_lengths(const uint32_t* d_strand_c, int64_t n_strands, int max_blocks, uint32_t* d_len) {
-    LDBG_LAUNCH(k_path_lengths, grid_for(n_strands * 64, 64, 256 * 64), 64, graph->stream, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
+    LDBG_LAUNCH(k_path_lengths, grid_for(n_strands * 64, LDBG_STREAM_BLOCK, LDBG_STREAM_GRID), LDBG_STREAM_BLOCK, graph->stream, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
                 d_strand_c, n_strands, d_len);
 }
 void Engine::launch_expand_paths(const uint32_t* d_strand_c, const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks, const RunIndexView& runs,
@@ -899,7 +955,7 @@ void Engine::launch_expand_paths(const uint32_t* d_strand_c, const int64_t* d_st
     xa.pool = (const uint64_t*)d_pool_; xa.block_table = (const uint32_t*)d_block_table_; xa.max_blocks = max_blocks;
     xa.strand_c = d_strand_c; xa.strand_off = d_strand_off; xa.n_strands = n_strands;
     xa.runs = runs; xa.dense = d_dense; xa.overflow = d_overflow;
-    LDBG_LAUNCH(k_expand_paths, grid_for(n_strands * 64, 64, 256 * 64), 64, graph->stream, xa);
+    LDBG_LAUNCH(k_expand_paths, grid_for(n_strands * 64, LDBG_STREAM_BLOCK, LDBG_STREAM_GRID), LDBG_STREAM_BLOCK, graph->stream, xa);
 }
 
 void Engine::launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks) {
@@ -1333,6 +1389,8 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
                 const double g = w[4] ? (double)w[4] : 1.0;
                 fprintf(stderr, "[ldbg] %s: general part per iteration: prefetch %.2f us, adds %.2f us, choices %.2f us, step %.2f us; lanes %.1f, add owners %.2f, choice owners %.2f\n", who,
                         w[6] / 100.0 / g, w[7] / 100.0 / g, w[8] / 100.0 / g, w[9] / 100.0 / g, w[10] / g, w[11] / g, w[12] / g);
+                fprintf(stderr, "[ldbg] %s: add owners in 16-lane groups %.2f per iteration, of which a store of <= 8 elements %.2f; elements per add owner (store + records) %.1f\n", who,
+                        w[13] / g, w[14] / g, w[11] ? (double)w[15] / (double)w[11] : 0.0);
             };
             line("average wavefront", sum, (double)grid);
             line("slowest wavefront", &wc[16 * (size_t)slowest], 1.0);
@@ -1432,12 +1490,17 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
         ra.pool = (const uint64_t*)d_pool_; ra.block_table = (const uint32_t*)d_block_table_; ra.max_blocks = max_blocks;
         ra.strand_c = (const uint32_t*)out.d_strand_c; ra.strand_n = d_strand_n; ra.walk_len = d_walk_len; ra.contig_off = d_contig_off;
         ra.out = (char*)out.d_contigs;
-        const int rg = grid_for(n * 64, 64, 256 * 64);
+        int rb = LDBG_STREAM_BLOCK, rcap = LDBG_STREAM_GRID;
+#ifndef LDBG_HOSTSIM
+        if (const char* ev = getenv("LDBG_RLE_BLOCK")) rb = atoi(ev) >= 256 ? 256 : (atoi(ev) >= 128 ? 128 : 64);      // tuning knobs
+        if (const char* ev = getenv("LDBG_RLE_GRID")) rcap = std::max(1, atoi(ev));
+#endif
+        const int rg = grid_for(n * 64, rb, rcap);
         switch (W) {
-            case 1: LDBG_LAUNCH(k_contigs_rle<1>, rg, 64, s, ra); break;
-            case 2: LDBG_LAUNCH(k_contigs_rle<2>, rg, 64, s, ra); break;
-            case 3: LDBG_LAUNCH(k_contigs_rle<3>, rg, 64, s, ra); break;
-            default: LDBG_LAUNCH(k_contigs_rle<4>, rg, 64, s, ra); break;
+            case 1: LDBG_LAUNCH(k_contigs_rle<1>, rg, rb, s, ra); break;
+            case 2: LDBG_LAUNCH(k_contigs_rle<2>, rg, rb, s, ra); break;
+            case 3: LDBG_LAUNCH(k_contigs_rle<3>, rg, rb, s, ra); break;
+            default: LDBG_LAUNCH(k_contigs_rle<4>, rg, rb, s, ra); break;
         }
     } else {
         ensure_dense(out);

@@ -540,14 +540,17 @@ std::unique_ptr<PGraph> TraversalEngine::dfs_branch(Vertex cv, bool fwd, int gra
                 }
                 int gv2 = (int)g->verts.size();
                 TraversalState tc{&cv, fwd, graph_size + gv2, depth, gv2, (int)avs.size(), (int)rvs.size(), true, gv2 > ec_.max_length, &sinks};
-                if (children || stopper.has_succeeded(tc)) return g;
+                if (children || stopper.has_succeeded(tc)) { if (getenv("ORC_TRACE")) fprintf(stderr, "O end depth %d success 1 iters %llu\n", depth, (unsigned long long)dfs_iterations); return g; }
             }
         } else if (stopper.traversal_succeeded()) {
+            if (getenv("ORC_TRACE")) fprintf(stderr, "O end depth %d success 1 iters %llu\n", depth, (unsigned long long)dfs_iterations);
             return g;
         } else {
+            if (getenv("ORC_TRACE")) fprintf(stderr, "O end depth %d success 0 iters %llu\n", depth, (unsigned long long)dfs_iterations);
             return nullptr;
         }
     } while (avs.size() == 1);
+    if (getenv("ORC_TRACE")) fprintf(stderr, "O end depth %d success 0 iters %llu\n", depth, (unsigned long long)dfs_iterations);
     return nullptr;
 }
 

@@ -10,6 +10,8 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SO = os.path.join(ROOT, "tests", "hostsim", "_build", "libldbg_hostsim.so")
+if os.environ.get("LDBG_HOSTSIM_SO"):          # e.g. the AddressSanitizer build (make hostsim-asan), run once per round
+    SO = os.path.abspath(os.environ["LDBG_HOSTSIM_SO"])
 SO16 = os.path.join(ROOT, "tests", "hostsim", "_build16", "libldbg_hostsim.so")
 
 
@@ -21,7 +23,7 @@ def build(target="hostsim"):
 def load(rebuild=True):
     """rebuild=False: workers spawned by a test that has already built the library (two makes at once would race)"""
     from corticall_amd import NativeLib
-    if rebuild:
+    if rebuild and not os.environ.get("LDBG_HOSTSIM_SO"):
         build()
     return NativeLib(SO)
 

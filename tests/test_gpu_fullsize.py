@@ -68,18 +68,16 @@ def test_full_size_walks(orc, workload):
         idx, _, _ = g.find_batch(win, with_payload=False)
         assert (idx < 0).sum() <= 2
     # (4) bit-exact against the oracle on random seeds (tuned search: same results as the faithful mode, checked in
-    #     tests/test_oracle_golden.py, but fast enough for long walks)
-    og = orc.Graph(workload + ".ctx", tuned=True)
-    ol = orc.Links(workload + ".ctp.gz")
-    oe = orc.Engine(og, [0], links=[ol], stopper="ContigStopper")
-    t0, checked = time.time(), 0
-    for i in sample:
-        if time.time() - t0 > (60 if checked >= 20 else 400):      # (a time budget, but never fewer than 20 walks)
-            break
+    #     tests/test_oracle_golden.py, but fast enough for long walks), on several host threads: as many as 30 s allow, never fewer than 40
+    from tests.fullsize_util import oracle_sample
+
+    def make():
+        return orc.Engine(orc.Graph(workload + ".ctx", tuned=True), [0], links=[orc.Links(workload + ".ctp.gz")], stopper="ContigStopper")
+
+    def check(oe, i):
         exp, nv = oe.walk(seeds[i].tobytes().decode())
-        assert raw[offs[i]:offs[i + 1]].decode() == exp and wl[i] == nv
-        checked += 1
-    assert checked >= 20
+        assert raw[offs[i]:offs[i + 1]].decode() == exp and wl[i] == nv, i
+    assert oracle_sample(make, [int(i) for i in sample], check, 30, 40) >= 40
     g.close()
 
 
@@ -146,7 +144,7 @@ def test_full_size_lookups_and_walks_c2(orc, workload_c2):
     og = orc.Graph(workload_c2 + ".ctx", use_cache=True, tuned=False)
     t0, checked = time.time(), 0
     for i in rng.choice(n, 4000, replace=False):
-        if time.time() - t0 > (40 if checked >= 500 else 400):
+        if time.time() - t0 > (25 if checked >= 500 else 400):
             break
         exp, ecov, eed = og.find(q[i].tobytes().decode())
         assert exp == int(idx[i]), (q[i].tobytes(), exp, int(idx[i]))
@@ -166,16 +164,15 @@ def test_full_size_lookups_and_walks_c2(orc, workload_c2):
         assert seeds[i].tobytes() in raw[offs[i]:offs[i + 1]]
     arena2, offs2, _ = e.walk_batch_arrays(seeds)
     assert hashlib.sha256(arena2.tobytes()).hexdigest() == hashlib.sha256(raw).hexdigest() and (offs2 == offs).all()
-    ogt = orc.Graph(workload_c2 + ".ctx", tuned=True)
-    oe = orc.Engine(ogt, [0], stopper="ContigStopper")
-    t0, checked = time.time(), 0
-    for i in rng.choice(len(seeds), 600, replace=False):
-        if time.time() - t0 > (40 if checked >= 20 else 400):      # (a time budget, but never fewer than 20 walks)
-            break
+    from tests.fullsize_util import oracle_sample
+
+    def make():
+        return orc.Engine(orc.Graph(workload_c2 + ".ctx", tuned=True), [0], stopper="ContigStopper")
+
+    def check(oe, i):
         exp, nv = oe.walk(seeds[i].tobytes().decode())
-        assert raw[offs[i]:offs[i + 1]].decode() == exp and wl[i] == nv
-        checked += 1
-    assert checked >= 20
+        assert raw[offs[i]:offs[i + 1]].decode() == exp and wl[i] == nv, i
+    assert oracle_sample(make, [int(i) for i in rng.choice(len(seeds), 2000, replace=False)], check, 20, 40) >= 40
     assert e.kmers_traversed > 0
     g.close()
 
@@ -236,19 +233,20 @@ def test_full_size_dfs_c4(orc, workload):
         vt = gi.vertex_tuples()
         assert vt[0][0] == seeds[i].tobytes().decode() and any(v[0] == sink[i].tobytes().decode() for v in vt)
         assert gi.vertex_tuples() == b2.graph(int(i)).vertex_tuples() and gi.edge_tuples() == b2.graph(int(i)).edge_tuples()
-    og = orc.Graph(workload + ".ctx", tuned=True)
-    ol = orc.Links(workload + ".ctp.gz")
-    oe = orc.Engine(og, [0], links=[ol], stopper="DestinationStopper", direction=orc.FORWARD)
-    t0, checked = time.time(), 0
-    for i in sample:
-        if time.time() - t0 > (60 if checked >= 20 else 400):
-            break
+    from tests.fullsize_util import oracle_sample
+    mine = {int(i): b1.graph(int(i)) for i in sample[:1500]}        # (graph handles are made on this thread; the checks only read them)
+    tuples = {i: (None if gi is None else (gi.vertex_tuples(), gi.edge_tuples())) for i, gi in mine.items()}
+
+    def make():
+        return orc.Engine(orc.Graph(workload + ".ctx", tuned=True), [0], links=[orc.Links(workload + ".ctp.gz")], stopper="DestinationStopper", direction=orc.FORWARD)
+
+    def check(oe, i):
         r = oe.dfs(seeds[i].tobytes().decode(), [sink[i].tobytes().decode()])
-        gi = b1.graph(int(i))
-        assert (gi is None) == r.is_null
-        if gi is not None:
-            assert gi.vertex_tuples() == r.vertices() and gi.edge_tuples() == r.edges()
-        r.free()
-        checked += 1
-    assert checked >= 20
+        try:
+            assert (tuples[i] is None) == r.is_null, i
+            if tuples[i] is not None:
+                assert tuples[i][0] == r.vertices() and tuples[i][1] == r.edges(), i
+        finally:
+            r.free()
+    assert oracle_sample(make, list(tuples), check, 30, 40) >= 40
     g.close()

@@ -51,7 +51,7 @@ def test_dense_cycles(orc, lib, tmp_path, seed): pc.case_dense_cycles(orc, lib, 
 def test_run_steps(orc, lib, tmp_path, seed): pc.case_run_steps(orc, lib, tmp_path, seed)
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 109])      # (109: siblings that cut one stretch in different places, found by tools/soak_gpu.py)
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 109, 231])      # (109: siblings that cut one stretch in different places, tools/soak_gpu.py; 231: a branch that opens INSIDE a stretch an ancestor crossed, tests/test_soak_hostsim.py)
 def test_dfs_run_steps(orc, lib, tmp_path, seed): pc.case_dfs_run_steps(orc, lib, tmp_path, seed)
 
 

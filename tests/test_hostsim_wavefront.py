@@ -35,7 +35,8 @@ def test_dense_cycles(orc, lib, tmp_path, seed): pc.case_dense_cycles(orc, lib, 
 def test_run_steps(orc, lib, tmp_path, seed): pc.case_run_steps(orc, lib, tmp_path, seed)
 
 
-def test_big_link_stores(orc, lib, tmp_path): pc.case_big_link_stores(orc, lib, tmp_path)
+@slow
+def test_big_link_stores(orc, lib, tmp_path): pc.case_big_link_stores(orc, lib, tmp_path)      # (6.5 minutes in lock step: hundreds of live links per walk)
 @slow
 def test_long_walks(orc, lib, tmp_path): pc.case_long_walks(orc, lib, tmp_path)
 def test_ref_cycles_without_and_with_links(orc, lib, tmp_path): pc.test_ref_cycles_without_and_with_links(orc, lib, tmp_path)

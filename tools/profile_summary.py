@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out_dir = os.path.join(ROOT, "profiles")
-WALK_KERNELS = ("k_walk", "k_expand_paths", "k_contigs", "k_zero16", "k_walk_lengths", "k_dfs", "k_path_lengths")
+WALK_KERNELS = ("k_walk", "k_expand_paths", "k_contigs", "k_zero16", "k_walk_lengths", "k_dfs", "k_path_lengths", "k_find")
 
 
 def rows(pattern):
@@ -44,7 +44,7 @@ with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w") as f:
 
 # ---- counters
 pmc = {}
-for sub in ("fetch", "write", "sq1", "sq2"):
+for sub in ("fetch", "write", "sq1", "sq2", "sq3"):
     for r in rows("prof_%s_%s/**/*counter_collection.csv" % (tag, sub)):
         k = short(r.get("Kernel_Name", "?"))
         if not any(k.startswith(w) for w in WALK_KERNELS):

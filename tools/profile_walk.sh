@@ -18,4 +18,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 echo sq1 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_sq2 -o s2 -- $B > $R/gpurun_out/prof_${TAG}_sq2.log 2>&1
 echo sq2 done
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_sq3 -o s3 -- $B > $R/gpurun_out/prof_${TAG}_sq3.log 2>&1
+echo sq3 done
 python3 $R/tools/profile_summary.py $TAG

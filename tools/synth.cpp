@@ -51,7 +51,7 @@ typedef std::vector<uint8_t> Seq;   // base codes 0..3
 
 uint8_t rand_base(Rng& r, double gc) { bool g = r.uniform() < gc; bool hi = r.next() & 1; return g ? (hi ? 1 : 2) : (hi ? 0 : 3); }
 
-struct Occ { u128 key; uint8_t colour; uint8_t edge; };
+struct __attribute__((packed)) Occ { u128 key; uint8_t colour; uint8_t edge; };      // 18 bytes: a 1 Gb genome in 3 colours is 3 x 10^9 of them, twice over while they are bucketed
 struct Rec { u128 key; uint32_t cov[3]; uint8_t edges[3]; };
 
 inline u128 kmask(int k) { return k == 64 ? ~(u128)0 : (((u128)1 << (2 * k)) - 1); }
