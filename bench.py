@@ -5,9 +5,10 @@ metric   : k-mers traversed / s (whole job), contigs / s alongside
 workload : configs[2] — synthetic P. falciparum-scale (23,332,839 bp) 3-colour k=47 LdBG with child links,
            link-guided contig walks (ContigStopper, BOTH, OR: the `Partition` configuration,
            Partition.java:85-94) from 50,000 seed k-mers (de novo mutation k-mers padded with random
-           child k-mers).  One "step" = one walk_batch over all seeds of the rank; the graph and the
-           links are resident in HBM before the timed region, the seeds (2.35 MB of ASCII) enter through
-           the C ABI's host pointer inside it.
+           child k-mers).  One "step" = one walk_batch over all seeds of the rank; the graph, the links
+           and the seeds (2.35 MB of ASCII, an (n, k) uint8 device array) are resident in HBM before the
+           timed region and the results stay there; `host_seeds` is the same step with the seeds handed
+           over as a host buffer, `with_contigs_fetched` with every contig brought back as well.
 N > 1    : one process per GPU (torchrun); every rank holds a replica of the graph (it fits: ~2 GB) and
            walks its own 50,000 seeds — independent units, no data-path collective, weak scaling.
 Prints ONE JSON line on rank 0.
@@ -630,22 +631,26 @@ def main():
         return bench_c4(args, ca, g, links, eng, seeds, st, prefix, rank, world, dist, sync, t_load)
 
     # the FIRST batch of an engine builds its run index (the records in unitig order): a caller that runs one batch per engine pays it
+    # the step's input resident in HBM before the timed region (the contract's `value`): the seeds as an (n, k) uint8 device array, used
+    # where they are by ldbg_engine_walk_batch_run_device.  The same steps with the seeds handed over as a host buffer are timed below
+    # (`host_seeds`), and with every contig brought back as well (`with_contigs_fetched`).
+    d_seeds = torch.from_numpy(np.ascontiguousarray(seeds)).to("cuda:%d" % local_rank)
     sync()
     first_batch_ms = None
     if args.warmup >= 1:
         t_first = time.time()
-        eng.walk_batch_arrays(seeds, fetch=False)
+        eng.walk_batch_arrays(d_seeds, fetch=False)
         sync()
         first_batch_ms = (time.time() - t_first) * 1e3
     run_index_ms, _ = ca.profile_get("run_index")
     for _ in range(max(0, args.warmup - 1)):
-        eng.walk_batch_arrays(seeds, fetch=False)
+        eng.walk_batch_arrays(d_seeds, fetch=False)
     ca.profile_reset()
     sync()
     t0 = time.time()
     traversed = 0
     for _ in range(args.steps):
-        eng.walk_batch_arrays(seeds, fetch=False)      # results stay in HBM (contigs + vertex lists)
+        eng.walk_batch_arrays(d_seeds, fetch=False)      # results stay in HBM (contigs, offsets, vertex lists)
         traversed += eng.kmers_traversed
     sync()
     dt = time.time() - t0
@@ -654,6 +659,13 @@ def main():
     kinds = {nm: ca.profile_get("walk_" + nm)[0] / max(1, walk_launches) for nm in
              ("steps_run", "run_vertices", "steps_lean", "steps_general", "link_adds", "choices", "wave_iterations", "wave_general",
               "busiest_general", "busiest_iterations", "wavefronts")}
+    # the same steps with the seeds handed over in host memory (n x k ASCII bytes of an ordinary numpy array)
+    sync()
+    t1 = time.time()
+    for _ in range(args.steps):
+        eng.walk_batch_arrays(seeds, fetch=False)
+    sync()
+    dt_host_seeds = time.time() - t1
     # the same steps with every contig downloaded to the caller (what the reference's walk() hands over): reported beside `value`
     eng.walk_batch_arrays(seeds, fetch=True, pinned=True)        # (the page-locked arena is allocated once, like every other buffer of the engine)
     sync()
@@ -720,6 +732,7 @@ def main():
                 "seeds_per_gpu": len(seeds), "kmers_traversed_per_step": traversed // args.steps,
                 "multi_gpu": "replicated graph, seeds partitioned, no data-path collective" if world > 1 else "single GPU",
                 "load_seconds": round(t_load, 2), "run_index_build_ms": run_index_ms, "first_batch_ms": first_batch_ms,
+                "inputs": "graph, links and seeds resident in HBM before the timed region (ldbg_engine_walk_batch_run_device); results stay in HBM",
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_walk<%d>" % W, "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -751,10 +764,13 @@ def main():
                                      "frac": contig_bytes / (HBM_PEAK_GBS * 1e9) / (max_dt / args.steps) if max_dt > 0 else None,
                                      "note": "a step must at least read one base byte and write one contig byte per k-mer"},
             },
+            "host_seeds": {"value": tot_trav / max_dt * dt / dt_host_seeds if dt_host_seeds > 0 else None, "ms_per_step": dt_host_seeds / args.steps * 1e3,
+                           "note": "rank 0's steps again with the seeds handed over as a host buffer (pageable numpy array, %d bytes per step over "
+                                   "PCIe) instead of resident in HBM; results stay in HBM as for `value`" % seeds.nbytes},
             "with_contigs_fetched": {"value": tot_trav / max_dt * dt / dt_fetch if dt_fetch > 0 else None, "ms_per_step": dt_fetch / args.steps * 1e3,
                                      "bytes_per_step": fetched_bytes // max(1, args.steps),
-                                     "note": "rank 0's steps again with all contigs downloaded into the engine's page-locked arena (ldbg_host_alloc): what a host "
-                                             "that reads the strings sees",
+                                     "note": "rank 0's steps again, host seeds in and all contigs downloaded into the engine's page-locked arena (ldbg_host_alloc): "
+                                             "what a host that hands over strings and reads strings sees",
                                      "pageable_ms_per_step": dt_fetch_pageable * 1e3,
                                      "pageable_note": "the same into a fresh pageable array (staged through the library's page-locked buffers)"},
         }

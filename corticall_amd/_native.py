@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(_HERE, "_build", "libldbg.so")
 if os.environ.get("LDBG_DIAG_LIB") == "1":
     # the same sources built with the walk kernel's timers compiled in (make -C corticall_amd/csrc diag): profiling sessions only (tools/)
     LIB_PATH = os.path.join(_HERE, "_build_diag", "libldbg.so")
+elif os.environ.get("LDBG_DIAG_LIB") == "variant":
+    # a tuning variant (make -C corticall_amd/csrc variant VARIANT_FLAGS=...): experiments of tools/ only
+    LIB_PATH = os.path.join(_HERE, "_build_variant", "libldbg.so")
 
 LDBG_OK = 0
 STATUS_NAMES = {
@@ -71,7 +74,7 @@ EXPORTS = [
     "ldbg_engine_sharded_walk_begin", "ldbg_engine_sharded_walk_round", "ldbg_engine_sharded_walk_finish", "ldbg_engine_sharded_dfs_batch",
     "ldbg_links_open", "ldbg_links_close", "ldbg_links_index", "ldbg_links_source", "ldbg_links_info", "ldbg_links_sample_name", "ldbg_links_get",
     "ldbg_engine_config_default", "ldbg_engine_create", "ldbg_engine_destroy",
-    "ldbg_engine_walk_batch", "ldbg_engine_walk_batch_run", "ldbg_engine_walk_batch_fetch", "ldbg_host_alloc", "ldbg_host_free", "ldbg_engine_walk_vertices", "ldbg_engine_walk_roi_hits",
+    "ldbg_engine_walk_batch", "ldbg_engine_walk_batch_run", "ldbg_engine_walk_batch_run_device", "ldbg_engine_walk_batch_fetch", "ldbg_host_alloc", "ldbg_host_free", "ldbg_engine_walk_vertices", "ldbg_engine_walk_roi_hits",
     "ldbg_engine_dfs_batch", "ldbg_dfs_result_sizes", "ldbg_dfs_result_get", "ldbg_dfs_result_walk", "ldbg_dfs_result_merge", "ldbg_dfs_result_free", "ldbg_engine_neighbours_batch", "ldbg_engine_assemble",
     "ldbg_engine_dfs_kmers_traversed",
     "ldbg_engine_seek", "ldbg_engine_has_next", "ldbg_engine_has_previous", "ldbg_engine_next", "ldbg_engine_previous",
@@ -93,6 +96,11 @@ class NativeLib:
         for name in EXPORTS:
             getattr(d, name)   # raises AttributeError if a declared symbol is not exported
         d.ldbg_engine_config_default.restype = None
+        try:                    # the host simulation of the test suite (tests/hostsim) exports this; libldbg.so does not
+            d.ldbg_hostsim_set_lanes
+            self.is_hostsim = True
+        except AttributeError:
+            self.is_hostsim = False
 
     def check(self, status):
         if status == LDBG_OK:

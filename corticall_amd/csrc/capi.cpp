@@ -377,17 +377,24 @@ ldbg_status ldbg_engine_create(const ldbg_engine_config* cfg, ldbg_engine** out)
 }
 ldbg_status ldbg_engine_destroy(ldbg_engine* e) { return guard([&] { delete e; }); }
 
-ldbg_status ldbg_engine_walk_batch_run(ldbg_engine* e, const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
+static ldbg_status walk_batch_run_any(ldbg_engine* e, const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed, bool on_device) {
     return guard([&] {
         // a full per-walk link store is retried with a larger one (exactness is never traded away)
         for (int attempt = 0;; attempt++) {
-            try { e->e.walk_batch_run(seeds, n, total_bytes, traversed); return; }
+            try { e->e.walk_batch_run(seeds, n, total_bytes, traversed, on_device); return; }
             catch (const StatusError& se) {
                 if (se.status == LDBG_ERR_CAPACITY && std::string(se.what()) == "LINKSTORE_FULL" && attempt < 8) { e->e.link_store_capacity *= 4; continue; }
                 throw;
             }
         }
     });
+}
+ldbg_status ldbg_engine_walk_batch_run(ldbg_engine* e, const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
+    return walk_batch_run_any(e, seeds, n, total_bytes, traversed, false);
+}
+ldbg_status ldbg_engine_walk_batch_run_device(ldbg_engine* e, const void* d_seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
+    if (n > 0 && !d_seeds) return guard([&] { throw StatusError(LDBG_ERR_ARG, "ldbg_engine_walk_batch_run_device: null seeds"); });
+    return walk_batch_run_any(e, (const char*)d_seeds, n, total_bytes, traversed, true);
 }
 ldbg_status ldbg_host_alloc(int64_t bytes, void** out) {
     return guard([&] { *out = nullptr; if (bytes < 0) throw StatusError(LDBG_ERR_ARG, "ldbg_host_alloc: negative size"); *out = rt::hmalloc_pinned((size_t)bytes); });

@@ -733,6 +733,8 @@ LDBG_WAVE_KERNEL void k_dfs(DfsArgs a) {
     const uint32_t fast_stride = 64;
 #else
     static LsElem lds_store[LDBG_LS_FAST * 64];          // (one simulated wavefront at a time: rt.h)
+    if ((rt::poison() || getenv("LDBG_HOSTSIM_ZERO_LDS")) && wave_lane() == 0) memset((void*)lds_store, rt::poison() ? 0xAB : 0, sizeof lds_store);      // (lane 0 is the first fibre to run)
+    if (wave_lane() == 0) lds_shadow_begin(lds_store, sizeof lds_store);
     LsElem* fast = lds_store + wave_lane();
     const uint32_t fast_stride = (uint32_t)wave_size();
 #endif

@@ -409,7 +409,34 @@ struct LsElem {
 };
 static_assert(sizeof(LsElem) == 24, "LsElem is moved as six words");
 // element copies through pointers of a known address space (six word moves; the compiler pairs them up)
+#ifdef LDBG_HOSTSIM
+// LDBG_HOSTSIM_LDS_CHECK=1: the simulated LDS remembers which elements the running wavefront has written; reading one it has not is
+// reading what an earlier workgroup left there (LDS is never cleared on the device either) — abort with a backtrace
+struct LdsShadow { const char* base = nullptr; size_t bytes = 0; std::vector<uint8_t> written; bool on = false; };
+inline LdsShadow& lds_shadow() { static LdsShadow s; return s; }
+inline void lds_shadow_begin(const void* base, size_t bytes) {
+    LdsShadow& s = lds_shadow();
+    static const bool want = getenv("LDBG_HOSTSIM_LDS_CHECK") != nullptr;
+    s.on = want;
+    if (!want) return;
+    s.base = (const char*)base; s.bytes = bytes; s.written.assign(bytes / 24 + 1, 0);
+}
+inline void lds_shadow_touch(const void* q, bool write) {
+    LdsShadow& s = lds_shadow();
+    if (!s.on || (const char*)q < s.base || (const char*)q >= s.base + s.bytes) return;
+    const size_t i = (size_t)((const char*)q - s.base) / 24;
+    if (write) { s.written[i] = 1; return; }
+    if (!s.written[i]) {
+        fprintf(stderr, "[hostsim] link-store element %zu of the simulated LDS is read before this wavefront wrote it\n", i);
+        void* bt[48]; const int nb = backtrace(bt, 48); backtrace_symbols_fd(bt, nb, 2);
+        abort();
+    }
+}
+#endif
 template <typename P> LDBG_HOSTDEV LsElem ls_elem_in(P q) {
+#ifdef LDBG_HOSTSIM
+    lds_shadow_touch((const void*)q, false);
+#endif
     uint32_t w[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) w[i] = q[i];
@@ -418,6 +445,9 @@ template <typename P> LDBG_HOSTDEV LsElem ls_elem_in(P q) {
     return x;
 }
 template <typename P> LDBG_HOSTDEV void ls_elem_out(P q, const LsElem& x) {
+#ifdef LDBG_HOSTSIM
+    lds_shadow_touch((const void*)q, true);
+#endif
     uint32_t w[6];
     __builtin_memcpy(w, &x, 24);
 #pragma unroll

@@ -13,14 +13,20 @@ struct WalkChunk {
     int64_t first = 0, n = 0;              // seeds [first, first+n)
     void* d_path = nullptr;                // dense u64 path entries of all strands of the chunk
     size_t path_cap = 0, contigs_cap = 0;  // bytes behind d_path / d_contigs (buffers are reused from batch to batch)
-    std::vector<int64_t> strand_off;       // [2n+1] offsets into d_path (strand 2i = reverse, 2i+1 = forward)
-    std::vector<uint32_t> status;          // [2n]
     void* d_contigs = nullptr;             // dense ASCII contigs
-    std::vector<int64_t> contig_off;       // [n+1]
-    std::vector<int64_t> walk_len;         // [n]
     void* d_seed_words = nullptr;          // [n][W]
     void* d_term = nullptr;                // [2n][W] k-mer of a trailing null-record vertex
-    std::vector<uint8_t> seed_ok;          // toWalk seed test: record present and coverage > 0
+    // offsets and lengths are computed on the device and stay there (a batch whose contigs are consumed in HBM never needs them on the
+    // host); Engine::ensure_host brings them over the first time fetch / walk_vertices ask
+    void* d_contig_off = nullptr;          // [n+1] int64
+    void* d_walk_len = nullptr;            // [n] int64
+    int64_t total_bytes = 0;               // contig_off[n]
+    int64_t total_entries = 0;             // strand_off[2n]
+    bool host_ready = false;
+    std::vector<int64_t> strand_off;       // [2n+1] offsets into d_path (strand 2i = reverse, 2i+1 = forward)        } host mirrors,
+    std::vector<int64_t> contig_off;       // [n+1]                                                                  } valid once
+    std::vector<int64_t> walk_len;         // [n]                                                                    } host_ready
+    std::vector<uint32_t> status;          // [2n]: filled only where a strand ended in an error (walk_finish)
     // the walks as the kernel stored them (vertex entries and run / repeat descriptors in the engine's path pool): d_path is expanded
     // from them by Engine::ensure_dense the first time vertex lists are asked for — contigs do not need it
     void* d_strand_c = nullptr;            // [2n] stored entries per strand
@@ -95,10 +101,12 @@ public:
     ldbg_engine_config cfg{};
     EngineView view{};
 
-    void walk_batch_run(const char* seeds, int64_t n, int64_t* total_contig_bytes, int64_t* kmers_traversed);
+    // seeds: n x k ASCII bytes — in host memory, or (seeds_on_device) already in this device's memory
+    void walk_batch_run(const char* seeds, int64_t n, int64_t* total_contig_bytes, int64_t* kmers_traversed, bool seeds_on_device = false);
     void walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len);
     void walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index);
     void clear_batch();
+    void quiesce() noexcept;                                     // waits for the streams this engine has work on (before blocks go back to rt::tfree)
     void walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, uint8_t* has_null);
     // walk_batch_run over the local image of a hash-sharded table, one bulk-synchronous round at a time (image.h): begin with the
     // seeds' image slots (device array, -1 = no record), then rounds until no rank has a strand left, then finish
@@ -136,7 +144,13 @@ private:
     std::unique_ptr<class RunIndex> runs_;     // records in unitig order for this engine's colour masks (runs.h), built by the first walk batch
     int64_t retried_strands_ = 0;
     std::vector<uint8_t> sink_valid_;
-    std::vector<uint8_t> seed_valid_;          // per seed of the current walk batch: is the string a k-mer over ACGT (Q4)              // strands the run steps handed back to the k-mer-by-k-mer code (diagnostics)
+    std::vector<uint8_t> seed_valid_;          // per source of the current dfs batch: is the string a k-mer over ACGT (Q4)
+    // seeds of the current walk batch on the device: packed words and the Q4 validity byte (walk.cpp: k_seed_words)
+    void* d_batch_words_ = nullptr; void* d_batch_valid_ = nullptr; void* d_batch_ascii_ = nullptr;
+    void seeds_to_device(const char* seeds, int64_t n, bool seeds_on_device);
+    void drop_batch_seeds();
+    unsigned long long* h_small_ = nullptr;    // page-locked landing block for the counters a batch hands to the host (64 words)
+    void ensure_host(WalkChunk& c);
     void build_roi_bits();
     bool dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
                    int64_t first, int64_t n, DfsBatch& out, const ShardedRun* sharded);
@@ -160,10 +174,10 @@ private:
     void result_free(void* p, size_t cap);
     void drop_spares();
     void zero_dirty_tables(rt::stream_t s);      // the part of the table pool the last launch handed out
-    bool run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);
+    bool run_chunk(int64_t first, int64_t n, WalkChunk& out, int64_t* traversed);
     void ensure_dense(WalkChunk& c);
     void materialize_pending();
-    void walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkRun& r, ShardImage* img, const int32_t* d_seed_slot);
+    void walk_prepare(int64_t first, int64_t n, WalkRun& r, ShardImage* img, const int32_t* d_seed_slot);
     void walk_launch(WalkRun& r);
     bool walk_finish(WalkRun& r, int64_t* traversed);
     WalkRun* sharded_run_ = nullptr;           // the batch in progress over a sharded table's image (sharded_walk_begin .. _finish)

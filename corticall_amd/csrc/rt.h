@@ -13,7 +13,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
 
 #include "../../include/ldbg.h"
 #include "ctx_host.h"   // StatusError
@@ -53,8 +58,78 @@ inline int cu_count(int d) {            // compute units of the device (256 on a
     check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d), "hipDeviceGetAttribute");
     return n > 0 ? n : 256;
 }
-inline void* dmalloc(size_t n) { void* p = nullptr; check(hipMalloc(&p, n ? n : 1), "hipMalloc"); return p; }
-inline void dfree(void* p) { if (p) (void)hipFree(p); }
+// Device blocks that come and go with every batch (a dozen per walk batch: status words, counters, offsets ...) are kept in free lists by
+// size class instead of going back to the runtime: hipMalloc / hipFree cost tens of microseconds each and hipFree waits for the whole device.
+// tmalloc / tfree are that path; a block may be handed to tfree only AFTER the host has waited for the stream that last used it (hipFree
+// would have waited by itself; a cached block is handed out again at once).  dmalloc / dfree stay the plain runtime calls, and a block from
+// tmalloc may be given to either.  Blocks above 64 MB and anything beyond 1 GB held are not kept; a failing hipMalloc empties the lists first.
+struct BlockCache {
+    std::mutex m;
+    std::unordered_map<void*, std::pair<int, size_t>> live;            // blocks handed out by tmalloc: device, class size
+    std::map<std::pair<int, size_t>, std::vector<void*>> free_;
+    size_t held = 0;
+    static size_t size_class(size_t n) {                                // 2^k or 1.5 x 2^k, at least 4 KB
+        size_t c = 4096;
+        while (c < n) { if (c + c / 2 >= n) return c + c / 2; c *= 2; }
+        return c;
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> g(m);
+        for (auto& kv : free_) for (void* p : kv.second) (void)hipFree(p);
+        free_.clear(); held = 0;
+    }
+};
+inline BlockCache& block_cache() { static BlockCache c; return c; }
+inline void* dmalloc(size_t n) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, n ? n : 1);
+    if (e != hipSuccess) { (void)hipGetLastError(); block_cache().release_all(); e = hipMalloc(&p, n ? n : 1); }
+    check(e, "hipMalloc");
+    return p;
+}
+inline void dfree(void* p) {
+    if (!p) return;
+    { BlockCache& c = block_cache(); std::lock_guard<std::mutex> g(c.m); c.live.erase(p); }
+    (void)hipFree(p);
+}
+inline void* tmalloc(size_t n) {
+    BlockCache& c = block_cache();
+    const size_t cls = BlockCache::size_class(n);
+    if (cls > ((size_t)64 << 20)) return dmalloc(n);
+    int dev = 0;
+    check(hipGetDevice(&dev), "hipGetDevice");
+    {
+        std::lock_guard<std::mutex> g(c.m);
+        auto it = c.free_.find({dev, cls});
+        if (it != c.free_.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            c.held -= cls;
+            c.live[p] = {dev, cls};
+            return p;
+        }
+    }
+    void* p = dmalloc(cls);
+    std::lock_guard<std::mutex> g(c.m);
+    c.live[p] = {dev, cls};
+    return p;
+}
+inline void tfree(void* p) {
+    if (!p) return;
+    BlockCache& c = block_cache();
+    {
+        std::lock_guard<std::mutex> g(c.m);
+        auto it = c.live.find(p);
+        if (it != c.live.end() && c.held + it->second.second <= ((size_t)1 << 30)) {
+            c.free_[it->second].push_back(p);
+            c.held += it->second.second;
+            c.live.erase(it);
+            return;
+        }
+        if (it != c.live.end()) c.live.erase(it);
+    }
+    (void)hipFree(p);
+}
 inline void* hmalloc_pinned(size_t n) { void* p = nullptr; check(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault), "hipHostMalloc"); return p; }
 inline void hfree_pinned(void* p) { if (p) (void)hipHostFree(p); }
 // is p page-locked host memory the runtime knows (ldbg_host_alloc, hipHostMalloc, hipHostRegister)?  Copies to it run at the bus rate.
@@ -160,8 +235,18 @@ namespace rt {
 inline int device_count() { return 1; }
 inline void set_device(int) {}
 inline int cu_count(int) { return 256; }
-inline void* dmalloc(size_t n) { return calloc(n ? n : 1, 1); }
+// LDBG_HOSTSIM_POISON=1: "device" memory comes back filled with 0xAB instead of zeros and the simulated LDS is filled likewise when a
+// wavefront starts — hipMalloc and LDS hand out whatever the last user left, and code that relies on zeros there must fail HERE
+inline bool poison() { static const bool on = getenv("LDBG_HOSTSIM_POISON") != nullptr; return on; }
+inline void* dmalloc(size_t n) {
+    if (!poison()) return calloc(n ? n : 1, 1);
+    void* p = malloc(n ? n : 1);
+    if (p) memset(p, 0xAB, n ? n : 1);
+    return p;
+}
 inline void dfree(void* p) { free(p); }
+inline void* tmalloc(size_t n) { return dmalloc(n); }
+inline void tfree(void* p) { free(p); }
 inline void* hmalloc_pinned(size_t n) { return malloc(n ? n : 1); }
 inline void hfree_pinned(void* p) { free(p); }
 inline bool host_is_pinned(const void*) { return getenv("LDBG_HOSTSIM_PAGEABLE") == nullptr; }     // (the test hook sends copies through the staging path)
@@ -308,7 +393,10 @@ inline uint32_t wave_shfl_u32(uint32_t v, int src) { return (uint32_t)wave_shfl_
 inline uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)wave_shfl_u64(v, src); }
 inline uint64_t wave_bcast_u64(uint64_t v, int src) { return wave_shfl_u64(v, src); }
 inline uint64_t wave_shfl_xor_u64(uint64_t v, int m) { return wave_shfl_u64(v, wave_lane() ^ m); }
-inline void wave_fence() {}
+// a lane's write followed by another lane's read of the same place is ordered on the device by the lock step itself (the fence makes the
+// write visible); the fibres of the simulation run one after the other between two primitives, so the fence is a barrier here: every
+// lane has done its writes before any lane goes on to read
+inline void wave_fence() { if (sim::wave().active) (void)sim::collective(3, 0ull); }
 inline void device_fence() {}
 inline uint64_t wave_min_u64(uint64_t v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o < v ? o : v; } return v; }
 inline uint64_t wave_max_u64(uint64_t v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) { uint64_t o = wave_shfl_xor_u64(v, m); v = o > v ? o : v; } return v; }

@@ -138,6 +138,8 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
     const uint32_t fast_stride = BS;
 #else
     static LsElem lds_store[LDBG_LS_FAST * 64];          // (one simulated wavefront at a time: rt.h)
+    if ((rt::poison() || getenv("LDBG_HOSTSIM_ZERO_LDS")) && wave_lane() == 0) memset((void*)lds_store, rt::poison() ? 0xAB : 0, sizeof lds_store);      // (lane 0 is the first fibre to run)
+    if (wave_lane() == 0) lds_shadow_begin(lds_store, sizeof lds_store);
     LsElem* fast = lds_store + wave_lane();
     const uint32_t fast_stride = (uint32_t)wave_size();
 #endif
@@ -358,22 +360,67 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
 }
 
 // ---- result assembly -------------------------------------------------------------------------
+// the seeds of a batch: n x k ASCII bytes -> packed words + the Q4 validity byte (a string with a byte outside ACGTacgt is no k-mer: its
+// words are zero and findRecord misses, kmer.h: ascii_batch_to_words is the host form of the same rule)
+LDBG_KERNEL void k_seed_words(const unsigned char* ascii, int64_t n, int k, int W, uint64_t* words, uint8_t* valid) {
+    const int nw = (k + 31) / 32, lead = W - nw;         // words that carry bases; leading all-zero words
+    for (int64_t q = global_tid(); q < n; q += global_nthreads()) {
+        const unsigned char* c = ascii + q * k;
+        uint64_t w[4] = {0ull, 0ull, 0ull, 0ull};
+        bool bad = false;
+        int i = 0;
+        for (int wi = lead; wi < W; wi++) {
+            const int cnt = wi == lead ? k - 32 * (nw - 1) : 32;
+            uint64_t acc = 0;
+            for (int j = 0; j < cnt; j++) {
+                unsigned v = 0;
+                switch (c[i++] | 0x20u) {
+                    case 'a': v = 0; break;
+                    case 'c': v = 1; break;
+                    case 'g': v = 2; break;
+                    case 't': v = 3; break;
+                    default: bad = true; break;
+                }
+                acc = (acc << 2) | (uint64_t)v;
+            }
+            w[wi] = acc;
+        }
+        for (int wi = 0; wi < W; wi++) words[q * W + wi] = bad ? 0ull : w[wi];
+        valid[q] = bad ? 0 : 1;
+    }
+}
+// strands the run steps handed back (ST_RETRY_PLAIN): their numbers, for the second launch (any order: strands are independent)
+LDBG_KERNEL void k_retry_list(const uint32_t* status, int64_t ns, uint32_t* list, unsigned long long* count) {
+    for (int64_t s = global_tid(); s < ns; s += global_nthreads())
+        if (status[s] == ST_RETRY_PLAIN) list[atomic_add_u64(count, 1ull)] = (uint32_t)s;
+}
 struct AsmArgs {
     EngineView e;
     int64_t n;
-    int op_and;
+    int op_and, k;
     const uint64_t* seeds;
     const uint64_t* pool; const uint32_t* block_table; int max_blocks;
-    const uint32_t* strand_n; const uint32_t* status;
+    const uint32_t* strand_n; const uint32_t* status; const uint32_t* iters; const uint8_t* quirk;
     int64_t* walk_len;                       // [n]
     uint8_t* seed_ok;                        // [n]
+    uint32_t* contig_len;                    // [n] bytes of the contig (0: no walk)
+    unsigned long long* flags;               // [0] strands that ran out of pool, [1] strands that ended in an error, [2] strands with a quirk-Q6 vertex, [3] loop iterations
 };
-// toWalk's seed test (TraversalUtils.java:392-397) + OR/AND combination (TraversalEngine.java:85-99)
+LDBG_DEV unsigned long long wave_sum_u64(unsigned long long v) { for (int m = wave_size() >> 1; m > 0; m >>= 1) v += wave_shfl_xor_u64(v, m); return v; }
+// toWalk's seed test (TraversalUtils.java:392-397) + OR/AND combination (TraversalEngine.java:85-99); what the host wants to know about
+// the batch as a whole (did a strand run out of pool, end in an error, pass a quirk vertex; k-mers traversed) is counted here, so that the
+// per-strand arrays stay on the device
 LDBG_KERNEL void k_walk_lengths(AsmArgs a) {
-    for (int64_t i = global_tid(); i < a.n; i += global_nthreads()) {
+    const int64_t WS = wave_size(), lane = wave_lane();
+    const int64_t wave = global_tid() / WS, nwaves = (global_nthreads() + WS - 1) / WS;
+    unsigned long long n_full = 0, n_err = 0, n_quirk = 0, n_iters = 0;
+    for (int64_t base = wave * WS; base < a.n; base += nwaves * WS) {
+        const int64_t i = base + lane;
+        if (i >= a.n) continue;
+        const uint32_t sr = a.status[2 * i], sf = a.status[2 * i + 1];
         uint32_t nr = a.strand_n[2 * i], nf = a.strand_n[2 * i + 1];
-        bool null_r = a.status[2 * i] == ST_BRANCH_NULL, null_f = a.status[2 * i + 1] == ST_BRANCH_NULL;
-        bool err = (a.status[2 * i] != ST_OK && !null_r) || (a.status[2 * i + 1] != ST_OK && !null_f);
+        bool null_r = sr == ST_BRANCH_NULL, null_f = sf == ST_BRANCH_NULL;
+        bool err = (sr != ST_OK && !null_r) || (sf != ST_OK && !null_f);
         bool is_null = a.op_and ? (null_r || null_f) : (null_r && null_f);
         int64_t len = 0;
         uint8_t ok = 0;
@@ -388,8 +435,57 @@ LDBG_KERNEL void k_walk_lengths(AsmArgs a) {
         }
         a.walk_len[i] = len;
         a.seed_ok[i] = ok;
+        a.contig_len[i] = len > 0 ? (uint32_t)(len + a.k - 1) : 0u;
+        n_full += (sr == ST_POOL_FULL) + (sf == ST_POOL_FULL);
+        n_err += (sr != ST_OK && !null_r && sr != ST_POOL_FULL) + (sf != ST_OK && !null_f && sf != ST_POOL_FULL);
+        n_quirk += (a.quirk[2 * i] != 0) + (a.quirk[2 * i + 1] != 0);
+        n_iters += (unsigned long long)a.iters[2 * i] + a.iters[2 * i + 1];
+    }
+    n_full = wave_sum_u64(n_full); n_err = wave_sum_u64(n_err); n_quirk = wave_sum_u64(n_quirk); n_iters = wave_sum_u64(n_iters);
+    if (lane == 0) {
+        if (n_full) atomic_add_u64(a.flags + 0, n_full);
+        if (n_err) atomic_add_u64(a.flags + 1, n_err);
+        if (n_quirk) atomic_add_u64(a.flags + 2, n_quirk);
+        if (n_iters) atomic_add_u64(a.flags + 3, n_iters);
     }
 }
+// exclusive prefix sums of n 32-bit counts as n + 1 64-bit offsets (strand_n -> strand_off, contig_len -> contig_off): partial sums of
+// OFF_SCAN_OWNERS stretches, their prefix by one wavefront, the offsets
+#define OFF_SCAN_OWNERS 4096
+LDBG_KERNEL void k_off_sums(int64_t n, int64_t chunk, const uint32_t* cnt, unsigned long long* sums) {
+    for (int64_t t = global_tid(); t < OFF_SCAN_OWNERS; t += global_nthreads()) {
+        const int64_t lo = std::min<int64_t>(t * chunk, n), hi = std::min<int64_t>(lo + chunk, n);
+        unsigned long long s = 0;
+        for (int64_t i = lo; i < hi; i++) s += cnt[i];
+        sums[t] = s;
+    }
+}
+LDBG_KERNEL void k_off_top(unsigned long long* sums, int64_t* total) {
+    if (global_tid() / wave_size() != 0) return;
+    const int WS = wave_size(), lane = wave_lane(), per = OFF_SCAN_OWNERS / WS;
+    unsigned long long mine = 0;
+    for (int j = 0; j < per; j++) mine += sums[lane * per + j];
+    unsigned long long base = 0, all = 0;
+    for (int l = 0; l < WS; l++) { const unsigned long long t = wave_bcast_u64(mine, l); if (l < lane) base += t; all += t; }
+    for (int j = 0; j < per; j++) { const unsigned long long v = sums[lane * per + j]; sums[lane * per + j] = base; base += v; }
+    if (lane == 0) *total = (int64_t)all;
+}
+LDBG_KERNEL void k_off_apply(int64_t n, int64_t chunk, const uint32_t* cnt, const unsigned long long* sums, const int64_t* total, int64_t* off) {
+    for (int64_t t = global_tid(); t < OFF_SCAN_OWNERS; t += global_nthreads()) {
+        const int64_t lo = std::min<int64_t>(t * chunk, n), hi = std::min<int64_t>(lo + chunk, n);
+        unsigned long long run = sums[t];
+        for (int64_t i = lo; i < hi; i++) { off[i] = (int64_t)run; run += cnt[i]; }
+        if (t == 0) off[n] = *total;
+    }
+}
+// d_tmp: OFF_SCAN_OWNERS words; d_total: one int64 on the device
+static void launch_offsets(const uint32_t* d_cnt, int64_t n, int64_t* d_off, unsigned long long* d_tmp, int64_t* d_total, rt::stream_t s) {
+    const int64_t chunk = (n + OFF_SCAN_OWNERS - 1) / OFF_SCAN_OWNERS;
+    LDBG_LAUNCH(k_off_sums, OFF_SCAN_OWNERS / 256, 256, s, n, chunk, d_cnt, d_tmp);
+    LDBG_LAUNCH(k_off_top, 1, 64, s, d_tmp, d_total);
+    LDBG_LAUNCH(k_off_apply, OFF_SCAN_OWNERS / 256, 256, s, n, chunk, d_cnt, (const unsigned long long*)d_tmp, (const int64_t*)d_total, d_off);
+}
+
 
 LDBG_KERNEL void k_compact_paths(const uint64_t* pool, const uint32_t* block_table, int max_blocks, const int64_t* strand_off,
                                  int64_t n_strands, uint64_t* dense) {
@@ -824,7 +920,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
 }
 
-Engine::~Engine() { sharded_abort(); clear_batch(); drop_spares(); rt::hfree_pinned(h_log_); rt::hfree_pinned(h_stage_[0]); rt::hfree_pinned(h_stage_[1]); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
+Engine::~Engine() { sharded_abort(); clear_batch(); drop_batch_seeds(); drop_spares(); rt::hfree_pinned(h_small_); rt::hfree_pinned(h_log_); rt::hfree_pinned(h_stage_[0]); rt::hfree_pinned(h_stage_[1]); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
 
 // ROI hits of the walks of the last batch: offsets[n+1] into hits (ROI record numbers, order within a walk arbitrary),
 // has_null[i] = the dfs graph of seed i holds a vertex without a record
@@ -857,12 +953,10 @@ void Engine::walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, u
         RoiHitArgs a;
         ensure_dense(c);
         a.roi_of = (const uint32_t*)d_roi_of_; a.n = c.n; a.dense = (const uint64_t*)c.d_path;
-        int64_t* d_soff = (int64_t*)rt::dmalloc((size_t)(2 * c.n + 1) * 8);
-        int64_t* d_wl = (int64_t*)rt::dmalloc((size_t)std::max<int64_t>(1, c.n) * 8);
+        const int64_t* d_soff = (const int64_t*)c.d_strand_off;
+        const int64_t* d_wl = (const int64_t*)c.d_walk_len;
         unsigned long long* d_cnt = (unsigned long long*)rt::dmalloc((size_t)std::max<int64_t>(1, c.n) * 8);
         uint8_t* d_null = (uint8_t*)rt::dmalloc((size_t)std::max<int64_t>(1, c.n));
-        rt::h2d(d_soff, c.strand_off.data(), (size_t)(2 * c.n + 1) * 8, s);
-        rt::h2d(d_wl, c.walk_len.data(), (size_t)c.n * 8, s);
         rt::dmemset(d_cnt, 0, (size_t)std::max<int64_t>(1, c.n) * 8, s);
         rt::dmemset(d_null, 0, (size_t)std::max<int64_t>(1, c.n), s);
         a.strand_off = d_soff; a.walk_len = d_wl; a.count = d_cnt; a.out_off = nullptr; a.out = nullptr; a.has_null = d_null; a.fill = 0;
@@ -887,7 +981,7 @@ void Engine::walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, u
             rt::dfree(d_off); rt::dfree(d_out);
         }
         total += chunk_total;
-        rt::dfree(d_soff); rt::dfree(d_wl); rt::dfree(d_cnt); rt::dfree(d_null);
+        rt::dfree(d_cnt); rt::dfree(d_null);
     }
     if (total > capacity) throw StatusError(LDBG_ERR_CAPACITY, "hit buffer too small: need " + std::to_string(total));
 }
@@ -907,7 +1001,7 @@ void Engine::ensure_dense(WalkChunk& c) {
     rt::set_device(graph->device);
     rt::stream_t s = graph->stream;
     const int64_t ns = 2 * c.n;
-    c.d_path = result_alloc((size_t)std::max<int64_t>(1, c.strand_off[ns]) * 8, &c.path_cap);
+    c.d_path = result_alloc((size_t)std::max<int64_t>(1, c.total_entries) * 8, &c.path_cap);
     unsigned* d_ovf = (unsigned*)rt::dmalloc(4);
     rt::dmemset(d_ovf, 0, 4, s);
     ExpandArgs xa;
@@ -1016,10 +1110,19 @@ void Engine::drop_spares() {
     spares_.clear();
 }
 
+// Blocks go back to the block cache (rt::tfree) only once nothing on the device can still touch them: wait for the streams this engine
+// has work on (hipFree used to do that by itself).  Idle streams: microseconds.
+void Engine::quiesce() noexcept {
+    try {
+        rt::stream_sync(graph->stream);
+        if (sharded_run_ && sharded_stream_ && sharded_stream_ != graph->stream) rt::stream_sync(sharded_stream_);
+    } catch (...) {}
+}
 void Engine::clear_batch() {
+    if (!chunks.empty()) quiesce();
     for (auto& c : chunks) {
-        result_free(c.d_path, c.path_cap); result_free(c.d_contigs, c.contigs_cap); rt::dfree(c.d_seed_words); rt::dfree(c.d_term);
-        rt::dfree(c.d_strand_c); rt::dfree(c.d_strand_off);
+        result_free(c.d_path, c.path_cap); result_free(c.d_contigs, c.contigs_cap); rt::tfree(c.d_seed_words); rt::tfree(c.d_term);
+        rt::tfree(c.d_strand_c); rt::tfree(c.d_strand_off); rt::tfree(c.d_contig_off); rt::tfree(c.d_walk_len);
     }
     chunks.clear();
     batch_n = batch_bytes = batch_traversed = 0;
@@ -1082,7 +1185,29 @@ struct HostLaps {
     }
 };
 
-void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed) {
+// the seeds of a batch go to the device as they are (n x k ASCII bytes; nothing to copy when the caller's seeds are there already) and
+// become packed words there: on the host that conversion was 0.5 ms of a 7 ms step at C3
+void Engine::seeds_to_device(const char* seeds, int64_t n, bool seeds_on_device) {
+    rt::stream_t s = graph->stream;
+    const int k = graph->hdr.k, W = graph->hdr.W;
+    drop_batch_seeds();
+    d_batch_words_ = rt::tmalloc((size_t)std::max<int64_t>(1, n) * W * 8);
+    d_batch_valid_ = rt::tmalloc((size_t)std::max<int64_t>(1, n));
+    if (n <= 0) return;
+    if (!seeds_on_device) {           // (the copy of page-locked seeds is asynchronous: the batch's first wait covers it, the block goes back with the batch's seeds)
+        d_batch_ascii_ = rt::tmalloc((size_t)n * k);
+        rt::h2d(d_batch_ascii_, seeds, (size_t)n * k, s);
+    }
+    LDBG_LAUNCH(k_seed_words, grid_for(n, 256, 1024), 256, s, (const unsigned char*)(seeds_on_device ? (const void*)seeds : d_batch_ascii_), n, k, W,
+                (uint64_t*)d_batch_words_, (uint8_t*)d_batch_valid_);
+}
+void Engine::drop_batch_seeds() {
+    if (d_batch_words_ || d_batch_valid_ || d_batch_ascii_) quiesce();
+    rt::tfree(d_batch_words_); rt::tfree(d_batch_valid_); rt::tfree(d_batch_ascii_);
+    d_batch_words_ = d_batch_valid_ = d_batch_ascii_ = nullptr;
+}
+
+void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, int64_t* traversed, bool seeds_on_device) {
     if (cfg.stopping_rule != LDBG_STOP_CONTIG || cfg.connect_all_neighbors)
         throw StatusError(LDBG_ERR_UNSUPPORTED, "walk_batch runs ContigStopper without connectAllNeighbors; use dfs_batch for other rules");
     if (cfg.n_secondary > 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "secondary colours are not supported by walk_batch");
@@ -1090,11 +1215,8 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
     HostLaps laps;
     clear_batch();
     laps.lap("clear_batch");
-    const int k = graph->hdr.k, W = graph->hdr.W;
-    std::vector<uint64_t> words((size_t)n * W);
-    seed_valid_.resize((size_t)std::max<int64_t>(1, n));
-    ascii_batch_to_words(seeds, n, k, W, words.data(), seed_valid_.data());
-    laps.lap("seed words");
+    seeds_to_device(seeds, n, seeds_on_device);
+    laps.lap("seed words (device)");
     batch_n = n;
     int64_t trav = 0;
     // the whole batch in one launch; if the path pool runs dry the batch is split and re-run (exactness first)
@@ -1105,7 +1227,7 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
         if (cnt <= 0) continue;
         WalkChunk c;
         int64_t t = 0;
-        if (run_chunk(words, first, cnt, c, &t)) { trav += t; chunks.push_back(std::move(c)); }
+        if (run_chunk(first, cnt, c, &t)) { trav += t; chunks.push_back(std::move(c)); }
         else if (!scratch_full_ && scratch_scale_ < (1ull << 24)) {
             scratch_scale_ *= 4;                          // the small pools of a run-index walk were too small for this batch: enlarge, walk it again
             pool_growths_++;
@@ -1119,7 +1241,7 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
     std::sort(chunks.begin(), chunks.end(), [](const WalkChunk& a, const WalkChunk& b) { return a.first < b.first; });
     batch_traversed = trav;
     batch_bytes = 0;
-    for (auto& c : chunks) batch_bytes += c.contig_off.back();
+    for (auto& c : chunks) batch_bytes += c.total_bytes;
     if (total_bytes) *total_bytes = batch_bytes;
     if (traversed) *traversed = trav;
 }
@@ -1134,13 +1256,15 @@ struct WalkRun {
     uint32_t vcap_max = 0;
     bool want_times = false;
     double walk_ms = 0;
+    rt::Event ev0, ev1;                    // around the (last) launch of the walk kernel; read after the batch's first wait (walk_finish)
+    bool timed = false;
     uint32_t *d_strand_n = nullptr, *d_strand_c = nullptr, *d_retry = nullptr, *d_status = nullptr, *d_iters = nullptr;
     uint8_t *d_quirk = nullptr, *d_seed_valid = nullptr;
     unsigned long long* d_ctr = nullptr;
     void* d_save = nullptr;
     WalkChunk out;
     void free_tmp() {
-        rt::dfree(d_strand_n); rt::dfree(d_strand_c); rt::dfree(d_retry); rt::dfree(d_seed_valid); rt::dfree(d_status); rt::dfree(d_iters); rt::dfree(d_ctr); rt::dfree(d_quirk);
+        rt::tfree(d_strand_n); rt::tfree(d_strand_c); rt::tfree(d_retry); rt::tfree(d_seed_valid); rt::tfree(d_status); rt::tfree(d_iters); rt::tfree(d_ctr); rt::tfree(d_quirk);
         rt::dfree(d_save);
         d_strand_n = d_strand_c = d_retry = d_status = d_iters = nullptr; d_quirk = d_seed_valid = nullptr; d_ctr = nullptr; d_save = nullptr;
     }
@@ -1178,7 +1302,7 @@ LDBG_KERNEL void k_round_stats(const unsigned long long* ctr, int64_t ns, const 
 }
 
 // img: the walk runs on the local image of a sharded table (image.h): strands suspend where a row is missing, seeds come as image slots
-void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first_, int64_t n_, WalkRun& r, ShardImage* img, const int32_t* d_seed_slot) {
+void Engine::walk_prepare(int64_t first_, int64_t n_, WalkRun& r, ShardImage* img, const int32_t* d_seed_slot) {
     r.W = graph->hdr.W; r.k = graph->hdr.k; r.first = first_; r.n = n_; r.ns = 2 * n_;
     r.out.first = first_; r.out.n = n_;
     // a strand's visited table never needs more than this (longest possible branch at load <= 1/2)
@@ -1191,17 +1315,17 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
     zero_dirty_tables(s);
     laps.lap("scratch + zero (issued)");
 
-    out.d_seed_words = rt::dmalloc((size_t)n * W * 8);
-    rt::h2d(out.d_seed_words, &seed_words[first * W], (size_t)n * W * 8, s);
-    d_seed_valid = (uint8_t*)rt::dmalloc((size_t)n);
-    rt::h2d(d_seed_valid, &seed_valid_[first], (size_t)n, s);
-    out.d_term = rt::dmalloc((size_t)ns * W * 8);
-    d_strand_n = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    d_strand_c = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    d_status = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    d_iters = (uint32_t*)rt::dmalloc((size_t)ns * 4);
-    d_quirk = (uint8_t*)rt::dmalloc((size_t)ns);
-    d_ctr = (unsigned long long*)rt::dmalloc(256);      // [0..7] queue / pool cursors, [8..] the step-kind counters (strand.h: WalkArgs::kinds)
+    out.d_seed_words = rt::tmalloc((size_t)n * W * 8);           // the chunk keeps its seeds (k_contigs, walk_vertices); the batch's go with the next batch
+    rt::d2d(out.d_seed_words, (const uint64_t*)d_batch_words_ + first * W, (size_t)n * W * 8, s);
+    d_seed_valid = (uint8_t*)rt::tmalloc((size_t)n);
+    rt::d2d(d_seed_valid, (const uint8_t*)d_batch_valid_ + first, (size_t)n, s);
+    out.d_term = rt::tmalloc((size_t)ns * W * 8);
+    d_strand_n = (uint32_t*)rt::tmalloc((size_t)ns * 4);
+    d_strand_c = (uint32_t*)rt::tmalloc((size_t)ns * 4);
+    d_status = (uint32_t*)rt::tmalloc((size_t)ns * 4);
+    d_iters = (uint32_t*)rt::tmalloc((size_t)ns * 4);
+    d_quirk = (uint8_t*)rt::tmalloc((size_t)ns);
+    d_ctr = (unsigned long long*)rt::tmalloc(256);      // [0..7] queue / pool cursors, [8..] the step-kind counters (strand.h: WalkArgs::kinds)
     rt::dmemset(d_ctr, 0, 256, s);
     rt::dmemset(out.d_term, 0, (size_t)ns * W * 8, s);
 
@@ -1299,11 +1423,10 @@ void Engine::walk_prepare(const std::vector<uint64_t>& seed_words, int64_t first
 // one launch of the walk kernel: the whole batch for a resident table, one bulk-synchronous round on an image
 void Engine::walk_launch(WalkRun& r) {
     rt::stream_t s = graph->stream;
-    rt::Event e0, e1;
-    e0.record(s);
+    r.ev0.record(s);
     launch_k_walk(r, r.a, s);
-    e1.record(s);
-    r.walk_ms += rt::Event::elapsed_ms(e0, e1);
+    r.ev1.record(s);
+    r.timed = true;
 }
 
 // returns false when the path pool was exhausted (nothing is kept; the caller splits the chunk)
@@ -1313,47 +1436,53 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
     const int grid = r.grid, block = r.block; (void)block;
     HostLaps laps;
 
+    // Everything the host must know before it can go on is counted on the device and lands in ONE page-locked block (h_small_):
+    // [0..31] the kernel's counters (d_ctr), [32] strand_off[2n], [33] contig_off[n].  The per-strand arrays stay in HBM.
+    if (!h_small_) h_small_ = (unsigned long long*)rt::hmalloc_pinned(64 * 8);
+    unsigned long long* const ctr = h_small_;
     // strands the run steps handed back (ST_RETRY_PLAIN) are walked again k-mer by k-mer, without the run index
-    out.status.resize(ns);
-    rt::d2h(out.status.data(), d_status, (size_t)ns * 4, s);
-    rt::stream_sync(s);
     if (runs_ && !a.img_on) {
-        std::vector<uint32_t> again;
-        for (int64_t i = 0; i < ns; i++) if (out.status[i] == ST_RETRY_PLAIN) again.push_back((uint32_t)i);
-        if (!again.empty()) {
-            d_retry = (uint32_t*)rt::dmalloc(again.size() * 4);
-            rt::h2d(d_retry, again.data(), again.size() * 4, s);
+        d_retry = (uint32_t*)rt::tmalloc((size_t)ns * 4);
+        LDBG_LAUNCH(k_retry_list, grid_for(ns, 256, 1024), 256, s, (const uint32_t*)d_status, ns, d_retry, d_ctr + 28);
+        rt::d2h(ctr, d_ctr, 256, s);
+        rt::stream_sync(s);
+        if (r.timed) { r.walk_ms += rt::Event::elapsed_ms(r.ev0, r.ev1); r.timed = false; }
+        const int64_t n_again = (int64_t)ctr[28];
+        if (n_again > 0) {
             rt::dmemset(d_ctr, 0, 8, s);                       // the strand queue starts over; the pool cursors carry on
             WalkArgs b = a;
             b.e.runs = RunIndexView{nullptr, nullptr, nullptr};
             b.retry = d_retry;
-            b.n_strands = (int64_t)again.size();
-            retried_strands_ += (int64_t)again.size();
+            b.n_strands = n_again;
+            retried_strands_ += n_again;
             launch_k_walk(r, b, s);
         }
     }
 
-    // lengths + seed test
-    int64_t* d_walk_len = (int64_t*)rt::dmalloc((size_t)n * 8);
-    uint8_t* d_seed_ok = (uint8_t*)rt::dmalloc((size_t)n);
+    // lengths + seed test + what the batch as a whole has to report; offsets of the strands' vertex lists and of the contigs
+    int64_t* d_walk_len = (int64_t*)rt::tmalloc((size_t)n * 8);
+    uint8_t* d_seed_ok = (uint8_t*)rt::tmalloc((size_t)n);
+    uint32_t* d_contig_len = (uint32_t*)rt::tmalloc((size_t)n * 4);
+    int64_t* d_strand_off = (int64_t*)rt::tmalloc((size_t)(ns + 1) * 8);
+    int64_t* d_contig_off = (int64_t*)rt::tmalloc((size_t)(n + 1) * 8);
+    unsigned long long* d_scan = (unsigned long long*)rt::tmalloc((size_t)(2 * OFF_SCAN_OWNERS + 2) * 8);
+    auto free_results = [&] {
+        rt::tfree(d_walk_len); rt::tfree(d_seed_ok); rt::tfree(d_contig_len); rt::tfree(d_strand_off); rt::tfree(d_contig_off); rt::tfree(d_scan);
+        d_walk_len = nullptr; d_seed_ok = nullptr; d_contig_len = nullptr; d_strand_off = nullptr; d_contig_off = nullptr; d_scan = nullptr;
+    };
     AsmArgs aa;
-    aa.e = view; aa.n = n; aa.op_and = cfg.combination_operator == LDBG_OP_AND;
+    aa.e = view; aa.n = n; aa.op_and = cfg.combination_operator == LDBG_OP_AND; aa.k = k;
     aa.seeds = a.seeds; aa.pool = a.pool; aa.block_table = a.block_table; aa.max_blocks = max_blocks;
-    aa.strand_n = d_strand_n; aa.status = d_status;
-    aa.walk_len = d_walk_len; aa.seed_ok = d_seed_ok;
+    aa.strand_n = d_strand_n; aa.status = d_status; aa.iters = d_iters; aa.quirk = d_quirk;
+    aa.walk_len = d_walk_len; aa.seed_ok = d_seed_ok; aa.contig_len = d_contig_len; aa.flags = d_ctr + 24;
     LDBG_LAUNCH(k_walk_lengths, grid_for(n, 256, 2048), 256, s, aa);
-
-    std::vector<uint32_t> strand_n(ns), iters(ns);
-    out.walk_len.resize(n);
-    out.seed_ok.resize(n);
-    rt::d2h(strand_n.data(), d_strand_n, (size_t)ns * 4, s);
-    rt::d2h(out.status.data(), d_status, (size_t)ns * 4, s);
-    rt::d2h(iters.data(), d_iters, (size_t)ns * 4, s);
-    rt::d2h(out.walk_len.data(), d_walk_len, (size_t)n * 8, s);
-    rt::d2h(out.seed_ok.data(), d_seed_ok, (size_t)n, s);
-    unsigned long long ctr[20] = {0};
-    rt::d2h(ctr, d_ctr, 160, s);
+    int64_t* d_totals = (int64_t*)(d_scan + 2 * OFF_SCAN_OWNERS);
+    launch_offsets(d_strand_n, ns, d_strand_off, d_scan, d_totals, s);
+    launch_offsets(d_contig_len, n, d_contig_off, d_scan + OFF_SCAN_OWNERS, d_totals + 1, s);
+    rt::d2h(ctr, d_ctr, 256, s);
+    rt::d2h(ctr + 32, d_totals, 16, s);
     rt::stream_sync(s);
+    if (r.timed) { r.walk_ms += rt::Event::elapsed_ms(r.ev0, r.ev1); r.timed = false; }
     {
         static const char* const kind_names[8] = {"walk_steps_run", "walk_run_vertices", "walk_steps_lean", "walk_steps_general", "walk_link_adds", "walk_choices",
                                                   "walk_wave_iterations", "walk_wave_general"};
@@ -1361,6 +1490,14 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
         profile_add("walk_busiest_general", (double)(ctr[16] >> 32));
         profile_add("walk_busiest_iterations", (double)(ctr[16] & 0xFFFFFFFFull));
         profile_add("walk_wavefronts", (double)grid);
+    }
+    const bool pool_full = ctr[24] != 0, any_error = ctr[25] != 0, any_quirk = ctr[26] != 0;
+    std::vector<uint32_t> iters;
+    if (want_times || any_error) {                 // (diagnostics, and the error report below: these want the per-strand arrays)
+        out.status.resize(ns);
+        rt::d2h(out.status.data(), d_status, (size_t)ns * 4, s);
+        if (want_times) { iters.resize(ns); rt::d2h(iters.data(), d_iters, (size_t)ns * 4, s); }
+        rt::stream_sync(s);
     }
     if (want_times) {
         std::vector<unsigned long long> t((size_t)grid * 2);
@@ -1448,36 +1585,38 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
     profile_add("walk", r.walk_ms);
     laps.lap("launch .. results on host");
 
-    bool pool_full = false;
-    for (int64_t i = 0; i < ns; i++) pool_full |= out.status[i] == ST_POOL_FULL;
     if (pool_full) {
-        free_tmp(); rt::dfree(d_walk_len); rt::dfree(d_seed_ok);
-        rt::dfree(out.d_seed_words); rt::dfree(out.d_term);
+        free_tmp(); free_results();
+        rt::tfree(out.d_seed_words); rt::tfree(out.d_term);
         out.d_seed_words = out.d_term = nullptr;
         return false;
     }
-    for (int64_t i = 0; i < ns; i++) *traversed += iters[i];
+    if (any_error) {        // errors the reference raises as exceptions abort the call
+        for (int64_t i = 0; i < ns; i++) {
+            const uint32_t st = out.status[i];
+            if (st != ST_NULLPTR && st != ST_LINKSTORE_FULL && st != ST_COPY_OVERFLOW) continue;
+            free_tmp(); free_results();
+            rt::tfree(out.d_seed_words); rt::tfree(out.d_term);
+            out.d_seed_words = out.d_term = nullptr;
+            if (st == ST_NULLPTR)
+                throw StatusError(LDBG_ERR_NULLPOINTER, "getNextVertices: record missing while recruitment colours are set (seed " + std::to_string(first + i / 2) + ")");
+            if (st == ST_LINKSTORE_FULL) throw StatusError(LDBG_ERR_CAPACITY, "LINKSTORE_FULL");
+            throw StatusError(LDBG_ERR_UNSUPPORTED, "a vertex was visited more than 32767 times in one walk");
+        }
+    }
+    *traversed += (int64_t)ctr[27];
+    out.total_entries = (int64_t)ctr[32];
+    out.total_bytes = (int64_t)ctr[33];
+    out.host_ready = false;
 
     // contigs; the dense vertex entries now (a walk through a quirk-Q6 vertex is spelled k-mer by k-mer from them; a batch that was split
     // reuses the path pool) or when somebody asks for vertex lists (ensure_dense)
-    out.strand_off.assign(ns + 1, 0);
-    for (int64_t i = 0; i < ns; i++) out.strand_off[i + 1] = out.strand_off[i] + strand_n[i];
-    out.contig_off.assign(n + 1, 0);
-    for (int64_t i = 0; i < n; i++) out.contig_off[i + 1] = out.contig_off[i] + (out.walk_len[i] > 0 ? out.walk_len[i] + k - 1 : 0);
-    int64_t* d_strand_off = (int64_t*)rt::dmalloc((size_t)(ns + 1) * 8);
-    int64_t* d_contig_off = (int64_t*)rt::dmalloc((size_t)(n + 1) * 8);
-    rt::h2d(d_strand_off, out.strand_off.data(), (size_t)(ns + 1) * 8, s);
-    rt::h2d(d_contig_off, out.contig_off.data(), (size_t)(n + 1) * 8, s);
-    laps.lap("offsets");
-    std::vector<uint8_t> quirks((size_t)ns);
-    rt::d2h(quirks.data(), d_quirk, (size_t)ns, s);
-    rt::stream_sync(s);
-    bool any_quirk = false;
-    for (int64_t i = 0; i < ns; i++) any_quirk |= quirks[i] != 0;
     const bool lazy = !any_quirk && first == 0 && n == batch_n && !getenv("LDBG_EAGER_PATHS");
-    out.d_contigs = result_alloc((size_t)out.contig_off[n], &out.contigs_cap);
-    out.d_strand_off = d_strand_off;
-    out.d_strand_c = d_strand_c; d_strand_c = nullptr;           // the chunk owns them now (clear_batch frees)
+    out.d_contigs = result_alloc((size_t)out.total_bytes, &out.contigs_cap);
+    out.d_strand_off = d_strand_off; d_strand_off = nullptr;     // the chunk owns them now (clear_batch frees)
+    out.d_contig_off = d_contig_off;
+    out.d_walk_len = d_walk_len;
+    out.d_strand_c = d_strand_c; d_strand_c = nullptr;
     out.max_blocks = max_blocks;
     out.runs = a.e.runs;
     out.dense_pending = true;
@@ -1506,7 +1645,7 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
         ensure_dense(out);
         const int cg = grid_for(n * 64, 256, 4096);
         ContigArgs ca;
-        ca.g = graph->view; ca.n = n; ca.seeds = a.seeds; ca.dense = (const uint64_t*)out.d_path; ca.strand_off = d_strand_off;
+        ca.g = graph->view; ca.n = n; ca.seeds = a.seeds; ca.dense = (const uint64_t*)out.d_path; ca.strand_off = (const int64_t*)out.d_strand_off;
         ca.walk_len = d_walk_len; ca.contig_off = d_contig_off; ca.quirk = d_quirk; ca.term = (const uint64_t*)out.d_term;
         ca.out = (char*)out.d_contigs;
         switch (W) {
@@ -1521,17 +1660,9 @@ bool Engine::walk_finish(WalkRun& r, int64_t* traversed) {
     profile_add("contig", rt::Event::elapsed_ms(c0, c1));
     laps.lap("paths + contigs");
     free_tmp();
-    rt::dfree(d_walk_len); rt::dfree(d_seed_ok); rt::dfree(d_contig_off);
+    d_walk_len = nullptr; d_contig_off = nullptr;                // (the chunk's)
+    free_results();
     laps.lap("frees");
-
-    // errors the reference raises as exceptions abort the call
-    for (int64_t i = 0; i < ns; i++) {
-        if (out.status[i] == ST_NULLPTR)
-            throw StatusError(LDBG_ERR_NULLPOINTER, "getNextVertices: record missing while recruitment colours are set (seed " + std::to_string(first + i / 2) + ")");
-        if (out.status[i] == ST_LINKSTORE_FULL) throw StatusError(LDBG_ERR_CAPACITY, "LINKSTORE_FULL");
-        if (out.status[i] == ST_COPY_OVERFLOW)
-            throw StatusError(LDBG_ERR_UNSUPPORTED, "a vertex was visited more than 32767 times in one walk");
-    }
     return true;
 }
 
@@ -1545,23 +1676,21 @@ void Engine::sharded_walk_begin(ShardImage& img, const char* seeds, int64_t n, c
     rt::set_device(graph->device);
     sharded_abort();
     clear_batch();
-    const int k = graph->hdr.k, W = graph->hdr.W;
-    std::vector<uint64_t> words((size_t)n * W);
-    seed_valid_.resize((size_t)std::max<int64_t>(1, n));
-    ascii_batch_to_words(seeds, n, k, W, words.data(), seed_valid_.data());
+    seeds_to_device(seeds, n, false);
     batch_n = n;
     sharded_run_ = new WalkRun;
     sharded_img_ = &img;
     sharded_stream_ = round_stream ? round_stream : graph->stream;
     try {
-        walk_prepare(words, 0, n, *sharded_run_, &img, d_seed_slot);
+        walk_prepare(0, n, *sharded_run_, &img, d_seed_slot);
         rt::stream_sync(graph->stream);
     } catch (...) { sharded_abort(); throw; }
 }
 void Engine::sharded_abort() {
     if (sharded_run_) {
+        quiesce();
         sharded_run_->free_tmp();
-        rt::dfree(sharded_run_->out.d_seed_words); rt::dfree(sharded_run_->out.d_term);
+        rt::tfree(sharded_run_->out.d_seed_words); rt::tfree(sharded_run_->out.d_term);
         delete sharded_run_;
         sharded_run_ = nullptr;
     }
@@ -1595,21 +1724,21 @@ void Engine::sharded_walk_finish(int64_t* total_bytes, int64_t* traversed) {
     r.out = WalkChunk();
     sharded_abort();
     batch_traversed = trav;
-    batch_bytes = chunks.back().contig_off.back();
+    batch_bytes = chunks.back().total_bytes;
     if (total_bytes) *total_bytes = batch_bytes;
     if (traversed) *traversed = trav;
 }
 
-bool Engine::run_chunk(const std::vector<uint64_t>& seed_words, int64_t first, int64_t n, WalkChunk& out, int64_t* traversed) {
+bool Engine::run_chunk(int64_t first, int64_t n, WalkChunk& out, int64_t* traversed) {
     WalkRun r;
     try {
-        walk_prepare(seed_words, first, n, r, nullptr, nullptr);
+        walk_prepare(first, n, r, nullptr, nullptr);
         walk_launch(r);
         const bool ok = walk_finish(r, traversed);
         if (ok) out = std::move(r.out);
         r.free_tmp();
         return ok;
-    } catch (...) { r.free_tmp(); throw; }
+    } catch (...) { quiesce(); r.free_tmp(); throw; }
 }
 
 // Device -> caller's host buffer.  Into page-locked memory (ldbg_host_alloc) the copy runs at the bus rate as it is.  Into pageable memory
@@ -1643,8 +1772,23 @@ void Engine::download(char* dst, const void* d_src, size_t bytes) {
     scatter(nchunks - 1);
 }
 
+// offsets and lengths of a chunk on the host (they are computed and kept on the device, walk_finish)
+void Engine::ensure_host(WalkChunk& c) {
+    if (c.host_ready) return;
+    rt::stream_t s = graph->stream;
+    c.strand_off.resize((size_t)(2 * c.n + 1));
+    c.contig_off.resize((size_t)(c.n + 1));
+    c.walk_len.resize((size_t)c.n);
+    rt::d2h(c.strand_off.data(), c.d_strand_off, (size_t)(2 * c.n + 1) * 8, s);
+    rt::d2h(c.contig_off.data(), c.d_contig_off, (size_t)(c.n + 1) * 8, s);
+    rt::d2h(c.walk_len.data(), c.d_walk_len, (size_t)c.n * 8, s);
+    rt::stream_sync(s);
+    c.host_ready = true;
+}
+
 void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len) {
     rt::set_device(graph->device);
+    if (offsets || walk_len) for (auto& c : chunks) ensure_host(c);
     if (offsets) {
         int64_t o = 0;
         offsets[0] = 0;
@@ -1656,8 +1800,8 @@ void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_
     if (arena) {
         int64_t o = 0;
         for (auto& c : chunks) {
-            download(arena + o, c.d_contigs, (size_t)c.contig_off.back());
-            o += c.contig_off.back();
+            download(arena + o, c.d_contigs, (size_t)c.total_bytes);
+            o += c.total_bytes;
         }
     }
 }
@@ -1669,6 +1813,7 @@ void Engine::walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_
     for (auto& c : chunks) {
         if (walk < c.first || walk >= c.first + c.n) continue;
         int64_t i = walk - c.first;
+        ensure_host(c);
         int64_t L = c.walk_len[i];
         *len = L;
         if (L == 0) return;

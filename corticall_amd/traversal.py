@@ -335,16 +335,25 @@ class TraversalEngine:
 
     def walk_batch_arrays(self, seeds, fetch=True, pinned=False):
         """-> (contig arena u8[total], offsets i64[n+1], walk lengths i64[n]).  pinned=True: the arena is this engine's page-locked block
-        (the download runs at the bus rate); it is valid until the next batch of this engine."""
+        (the download runs at the bus rate); it is valid until the next batch of this engine.
+        seeds: strings, an (n, k) uint8 numpy array, or an (n, k) uint8 tensor ON THIS ENGINE'S DEVICE (anything with .data_ptr(), .is_cuda,
+        .shape: the seeds are used where they are, ldbg_engine_walk_batch_run_device; the caller has synchronised the stream that wrote them)."""
         k = self._graph.getKmerSize()
-        if isinstance(seeds, np.ndarray):
-            a = np.ascontiguousarray(seeds, dtype=np.uint8)
-        else:
-            a = np.frombuffer(b"".join(_as_bytes(s) for s in seeds), dtype=np.uint8).reshape(len(seeds), k)
-        n = a.shape[0]
         total, trav = C.c_int64(), C.c_int64()
-        self._lib.check(self._d.ldbg_engine_walk_batch_run(self._h, a.ctypes.data_as(C.c_char_p), C.c_int64(n),
-                                                           C.byref(total), C.byref(trav)))
+        if hasattr(seeds, "data_ptr") and getattr(seeds, "is_cuda", False):
+            if seeds.dim() != 2 or seeds.shape[1] != k or seeds.element_size() != 1 or not seeds.is_contiguous():
+                raise ValueError("device seeds: a contiguous (n, %d) uint8 tensor" % k)
+            n = int(seeds.shape[0])
+            self._lib.check(self._d.ldbg_engine_walk_batch_run_device(self._h, C.c_void_p(seeds.data_ptr()), C.c_int64(n),
+                                                                      C.byref(total), C.byref(trav)))
+        else:
+            if isinstance(seeds, np.ndarray):
+                a = np.ascontiguousarray(seeds, dtype=np.uint8)
+            else:
+                a = np.frombuffer(b"".join(_as_bytes(s) for s in seeds), dtype=np.uint8).reshape(len(seeds), k)
+            n = a.shape[0]
+            self._lib.check(self._d.ldbg_engine_walk_batch_run(self._h, a.ctypes.data_as(C.c_char_p), C.c_int64(n),
+                                                               C.byref(total), C.byref(trav)))
         self.kmers_traversed = trav.value
         self.last_total_bytes = total.value
         if not fetch:

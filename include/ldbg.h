@@ -264,6 +264,12 @@ ldbg_status ldbg_engine_walk_batch_run(ldbg_engine* e, const char* seeds, int64_
                                        int64_t* total_contig_bytes, int64_t* kmers_traversed);
 ldbg_status ldbg_engine_walk_batch_fetch(ldbg_engine* e, char* contig_arena, int64_t arena_capacity,
                                          int64_t* offsets, int64_t* walk_len);
+/* the same batch with the seeds ALREADY IN DEVICE MEMORY (d_seeds: n x k ASCII bytes on the engine's device, e.g. the output of a seed
+ * selection that ran there, or a torch uint8 CUDA tensor's data_ptr): nothing crosses the bus before the walks start.  The seeds must
+ * stay valid until the call returns; work queued on other streams that produces them must have completed (the call does not wait
+ * for foreign streams).  Results as after ldbg_engine_walk_batch_run. */
+ldbg_status ldbg_engine_walk_batch_run_device(ldbg_engine* e, const void* d_seeds, int64_t n,
+                                              int64_t* total_contig_bytes, int64_t* kmers_traversed);
 /* Page-locked host memory for result arenas (contig_arena above): a download into it runs at the bus rate (C3: 780 MB of contigs in
  * about 16 ms); into ordinary memory the library stages the copy through its own page-locked buffers (about twice as long).  A JNI
  * host wraps the block in a direct ByteBuffer (NewDirectByteBuffer) and reads the contigs in place. */

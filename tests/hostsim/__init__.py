@@ -25,7 +25,11 @@ def load(rebuild=True):
     from corticall_amd import NativeLib
     if rebuild and not os.environ.get("LDBG_HOSTSIM_SO"):
         build()
-    return NativeLib(SO)
+    lib = NativeLib(SO)
+    # one lane per wavefront unless the environment says otherwise — said explicitly: the two builds of the simulation used to share the
+    # setting through a GNU-unique symbol (now -fno-gnu-unique), and a test that had switched 64 lanes on left it on for this one too
+    lib.dll.ldbg_hostsim_set_lanes(int(os.environ.get("LDBG_HOSTSIM_LANES", "1")))
+    return lib
 
 
 def load_wavefront(lanes=64, rebuild=True):

@@ -85,10 +85,63 @@ class Case:
         return oe, f.make()
 
 
+class _HostSeedsAsDevice:
+    """the host simulation's "device memory" is host memory: an (n, k) uint8 array dressed as the device tensor walk_batch_arrays accepts"""
+    is_cuda = True
+
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a, dtype=np.uint8)
+        self.shape = self.a.shape
+
+    def data_ptr(self): return self.a.ctypes.data
+    def dim(self): return self.a.ndim
+    def element_size(self): return 1
+    def is_contiguous(self): return True
+
+
+def device_seeds(lib, seeds, k):
+    """the seeds as ldbg_engine_walk_batch_run_device takes them: an (n, k) uint8 array in the memory of the library's device"""
+    a = np.frombuffer("".join(seeds).encode(), dtype=np.uint8).reshape(len(seeds), k)
+    if lib.is_hostsim:
+        return _HostSeedsAsDevice(a)
+    return _HipSeeds(a)
+
+
+class _HipSeeds:
+    """(n, k) uint8 seeds in device memory through the HIP runtime itself (hipMalloc + a synchronous hipMemcpy): no torch needed — and
+    importing torch AFTER libldbg has initialised the runtime finds no GPU, which __graft_entry__.smoke() would do"""
+    is_cuda = True
+    _hip = None
+
+    def __init__(self, a):
+        import ctypes as C
+        if _HipSeeds._hip is None:
+            _HipSeeds._hip = C.CDLL("libamdhip64.so.7")      # by soname: the instance libldbg.so (and torch, if imported) already runs on
+        hip = _HipSeeds._hip
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        self.shape = a.shape
+        self._n = a.ndim
+        self._p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(self._p), C.c_size_t(max(1, a.nbytes))) == 0
+        assert hip.hipMemcpy(self._p, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), C.c_int(1)) == 0      # hipMemcpyHostToDevice
+
+    def __del__(self):
+        if _HipSeeds._hip is not None and self._p:
+            _HipSeeds._hip.hipFree(self._p)
+
+    def data_ptr(self): return self._p.value
+    def dim(self): return self._n
+    def element_size(self): return 1
+    def is_contiguous(self): return True
+
+
 def compare_walks(case, seeds, **cfg):
     oe, e = case.engines(**cfg)
     seeds = list(seeds)
     got, wl = e.walk_batch(seeds)
+    if seeds:       # the same batch with the seeds already in device memory: the same contigs
+        got_d, wl_d = e.walk_batch(device_seeds(case.lib, seeds, case.k))
+        assert got_d == got and (wl_d == wl).all()
     km = np.frombuffer("".join(seeds).encode(), dtype=np.uint8).reshape(len(seeds), case.k)
     arena, offs, nv = oe.walk_batch(km)
     raw = arena.tobytes()
