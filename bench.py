@@ -9,6 +9,9 @@ workload : configs[2] — synthetic P. falciparum-scale (23,332,839 bp) 3-colour
            and the seeds (2.35 MB of ASCII, an (n, k) uint8 device array) are resident in HBM before the
            timed region and the results stay there; `host_seeds` is the same step with the seeds handed
            over as a host buffer, `with_contigs_fetched` with every contig brought back as well.
+           --in-flight N (default 2): the K steps are dealt out to N engines on the one graph, each with its
+           own HIP stream and host thread (a launch is bound by its longest strands; another batch fills
+           the compute units its early finishers leave); `single_batch` = the same steps one at a time.
 N > 1    : one process per GPU (torchrun); every rank holds a replica of the graph (it fits: ~2 GB) and
            walks its own 50,000 seeds — independent units, no data-path collective, weak scaling.
 Prints ONE JSON line on rank 0.
@@ -555,6 +558,7 @@ def main():
     ap.add_argument("--lookups", type=int, default=100000, help="c2: lookups per step (configs[1] says 100k)")
     ap.add_argument("--sharded", action="store_true", help="hash-shard the table over the ranks: c2 routes lookups with all-to-all, c3 walks over local images of the table")
     ap.add_argument("--sharded-seeds", type=int, default=50000, help="--sharded: seeds per GPU and step")
+    ap.add_argument("--in-flight", type=int, default=2, help="c3: engines (own HIP stream + host thread each) that take the steps in turn; 1 = one batch at a time")
     ap.add_argument("--rows-per-owner", type=int, default=65536, help="--sharded: rows one rank may ask of one owner per round")
     ap.add_argument("--check-every", type=int, default=16, help="--sharded: rounds between two looks at the 'anyone still walking' count")
     ap.add_argument("--chain-depth", type=int, default=32, help="--sharded: row slots per request (the row asked for + rows around it its owner holds too)")
@@ -643,15 +647,55 @@ def main():
         sync()
         first_batch_ms = (time.time() - t_first) * 1e3
     run_index_ms, _ = ca.profile_get("run_index")
+    # --in-flight N: N engines on the one graph, each with its own HIP stream and host thread, take the steps in turn.  A walk launch lasts
+    # as long as its longest strands and most of its wavefronts are done long before: the next batch of another engine fills
+    # the compute units they leave.  Every step is still one whole walk_batch over all the seeds of the rank.
+    engines = [eng]
+    for _ in range(max(1, args.in_flight) - 1):
+        f2 = (TraversalEngineFactory().traversalColors(g.getColorForSampleName("child")).traversalDirection(BOTH).combinationOperator(OR)
+              .stoppingRule(ContigStopper).maxBranchLength(args.max_len).graph(g).strictJavaFlip(not args.no_strict))
+        if not args.no_links:
+            f2.links(links)
+        engines.append(f2.make())
+    for e2 in engines[1:]:
+        e2.walk_batch_arrays(d_seeds, fetch=False)          # (each engine builds its run index and pools with its first batch)
     for _ in range(max(0, args.warmup - 1)):
-        eng.walk_batch_arrays(d_seeds, fetch=False)
+        for e2 in engines:
+            e2.walk_batch_arrays(d_seeds, fetch=False)
+
+    def run_steps(engs, n_steps):
+        """n_steps walk batches, dealt out to the engines in turn; one host thread per engine (ctypes drops the GIL during the call)"""
+        import threading
+        trav = [0] * len(engs)
+
+        def work(i):
+            for _ in range(i, n_steps, len(engs)):
+                engs[i].walk_batch_arrays(d_seeds, fetch=False)      # results stay in HBM (contigs, offsets, vertex lists)
+                trav[i] += engs[i].kmers_traversed
+        if len(engs) == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(i,)) for i in range(len(engs))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        return sum(trav)
+
+    # one batch at a time first (the latency of a step, the kernel durations without a neighbour): reported as `single_batch`
     ca.profile_reset()
     sync()
     t0 = time.time()
-    traversed = 0
-    for _ in range(args.steps):
-        eng.walk_batch_arrays(d_seeds, fetch=False)      # results stay in HBM (contigs, offsets, vertex lists)
-        traversed += eng.kmers_traversed
+    run_steps(engines[:1], args.steps)
+    sync()
+    dt_single = time.time() - t0
+    single_walk_ms, single_launches = ca.profile_get("walk")
+    single_contig_ms, _ = ca.profile_get("contig")
+    # the timed region of `value`
+    ca.profile_reset()
+    sync()
+    t0 = time.time()
+    traversed = run_steps(engines, args.steps)
     sync()
     dt = time.time() - t0
     walk_ms, walk_launches = ca.profile_get("walk")
@@ -733,7 +777,13 @@ def main():
                 "multi_gpu": "replicated graph, seeds partitioned, no data-path collective" if world > 1 else "single GPU",
                 "load_seconds": round(t_load, 2), "run_index_build_ms": run_index_ms, "first_batch_ms": first_batch_ms,
                 "inputs": "graph, links and seeds resident in HBM before the timed region (ldbg_engine_walk_batch_run_device); results stay in HBM",
+                "batches_in_flight": len(engines),
+                "schedule": ("%d engines on the one graph (own HIP stream and host thread each) take the %d steps in turn; every step is one whole "
+                             "walk_batch over all the seeds" % (len(engines), args.steps)) if len(engines) > 1 else "one batch at a time",
             },
+            "single_batch": {"ms_per_step": dt_single / args.steps * 1e3, "value": traversed / dt_single if dt_single > 0 else None,
+                             "k_walk_ms": single_walk_ms / max(1, single_launches), "k_contigs_rle_ms": single_contig_ms / max(1, args.steps),
+                             "note": "the same steps one batch at a time on one engine: the latency of a step and the kernel durations without a neighbour"},
             "roofline": {
                 "bound": "hbm", "kernel": "k_walk<%d>" % W, "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": model_gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -765,11 +815,11 @@ def main():
                                      "note": "a step must at least read one base byte and write one contig byte per k-mer"},
             },
             "host_seeds": {"value": tot_trav / max_dt * dt / dt_host_seeds if dt_host_seeds > 0 else None, "ms_per_step": dt_host_seeds / args.steps * 1e3,
-                           "note": "rank 0's steps again with the seeds handed over as a host buffer (pageable numpy array, %d bytes per step over "
+                           "note": "rank 0's steps again, one batch at a time, with the seeds handed over as a host buffer (pageable numpy array, %d bytes per step over "
                                    "PCIe) instead of resident in HBM; results stay in HBM as for `value`" % seeds.nbytes},
             "with_contigs_fetched": {"value": tot_trav / max_dt * dt / dt_fetch if dt_fetch > 0 else None, "ms_per_step": dt_fetch / args.steps * 1e3,
                                      "bytes_per_step": fetched_bytes // max(1, args.steps),
-                                     "note": "rank 0's steps again, host seeds in and all contigs downloaded into the engine's page-locked arena (ldbg_host_alloc): "
+                                     "note": "rank 0's steps again, one batch at a time, host seeds in and all contigs downloaded into the engine's page-locked arena (ldbg_host_alloc): "
                                              "what a host that hands over strings and reads strings sees",
                                      "pageable_ms_per_step": dt_fetch_pageable * 1e3,
                                      "pageable_note": "the same into a fresh pageable array (staged through the library's page-locked buffers)"},

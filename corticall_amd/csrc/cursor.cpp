@@ -134,16 +134,16 @@ template <int W>
 static size_t state_size() { return sizeof(CursorStateDev<W>); }
 
 CursorHost::CursorHost(Engine& e) : eng_(e), impl_(new Impl) {
-    rt::set_device(e.graph->device);
+    e.enter();
     const int W = e.graph->hdr.W;
     impl_->state_bytes = W == 1 ? state_size<1>() : W == 2 ? state_size<2>() : W == 3 ? state_size<3>() : state_size<4>();
     impl_->d_state = rt::dmalloc(impl_->state_bytes);
     impl_->d_vtab = rt::dmalloc((size_t)impl_->vcap * 8);
     impl_->d_ls = rt::dmalloc((size_t)impl_->ecap * sizeof(LsElem));
     impl_->d_words = rt::dmalloc((size_t)W * 8);
-    rt::dmemset(impl_->d_state, 0, impl_->state_bytes, e.graph->stream);
-    rt::dmemset(impl_->d_vtab, 0, (size_t)impl_->vcap * 8, e.graph->stream);
-    rt::stream_sync(e.graph->stream);
+    rt::dmemset(impl_->d_state, 0, impl_->state_bytes, e.estream());
+    rt::dmemset(impl_->d_vtab, 0, (size_t)impl_->vcap * 8, e.estream());
+    rt::stream_sync(e.estream());
 }
 CursorHost::~CursorHost() {
     rt::dfree(impl_->d_state); rt::dfree(impl_->d_vtab); rt::dfree(impl_->d_ls); rt::dfree(impl_->d_words);
@@ -163,9 +163,9 @@ void CursorHost::check_status(uint32_t st) {
 }
 
 void CursorHost::seek(const char* kmer) {
-    rt::set_device(eng_.graph->device);
+    eng_.enter();
     const int W = eng_.graph->hdr.W, k = eng_.graph->hdr.k;
-    rt::stream_t s = eng_.graph->stream;
+    rt::stream_t s = eng_.estream();
     std::vector<uint64_t> w(W);
     const int is_kmer = ascii_to_words(kmer, k, w.data(), W) ? 1 : 0;       // validity beside the words: at k = 32, 64, ... no bit pattern is free (Q4)
     if (!is_kmer) std::fill(w.begin(), w.end(), 0ull);
@@ -186,7 +186,7 @@ void CursorHost::seek(const char* kmer) {
 
 void CursorHost::peek(bool* has_next, bool* has_prev, uint32_t* status, uint64_t* out_words, int64_t* out_rec) {
     const int W = eng_.graph->hdr.W;
-    rt::stream_t s = eng_.graph->stream;
+    rt::stream_t s = eng_.estream();
 #define LDBG_PEEK(WW)                                                                       \
     {                                                                                       \
         CursorStateDev<WW> h;                                                               \
@@ -200,7 +200,7 @@ void CursorHost::peek(bool* has_next, bool* has_prev, uint32_t* status, uint64_t
 }
 
 int64_t CursorHost::cur_record() {
-    rt::stream_t s = eng_.graph->stream;
+    rt::stream_t s = eng_.estream();
     int64_t idx = -1;
 #define LDBG_CUR(WW) { CursorStateDev<WW> h; read_state<WW>(impl_->d_state, h, s); idx = h.cur.idx; }
     switch (eng_.graph->hdr.W) { case 1: LDBG_CUR(1) break; case 2: LDBG_CUR(2) break; case 3: LDBG_CUR(3) break; default: LDBG_CUR(4) break; }
@@ -209,7 +209,7 @@ int64_t CursorHost::cur_record() {
 }
 
 bool CursorHost::has(bool fwd) {
-    rt::set_device(eng_.graph->device);
+    eng_.enter();
     if (!impl_->sought) return false;
     bool hn, hp; uint32_t st;
     peek(&hn, &hp, &st, nullptr, nullptr);
@@ -218,9 +218,9 @@ bool CursorHost::has(bool fwd) {
 
 // TraversalEngine.assemble(seed) (:112-123): [previous() ... in contig order] + the seed's vertex + [next() ...]
 void CursorHost::assemble(const char* seed, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec) {
-    rt::set_device(eng_.graph->device);
+    eng_.enter();
     const int W = eng_.graph->hdr.W;
-    rt::stream_t s = eng_.graph->stream;
+    rt::stream_t s = eng_.estream();
     const int64_t max_len = std::max<int64_t>(0, eng_.cfg.max_branch_length);
     // the cursor's `seen` table holds every vertex stepped onto since the seek (load <= 1/2)
     uint32_t need = 1u << 17;
@@ -279,11 +279,11 @@ void CursorHost::assemble(const char* seed, int64_t capacity, int64_t* len, uint
 }
 
 void CursorHost::step(bool fwd, char* kmer_out, int64_t* rec_out) {
-    rt::set_device(eng_.graph->device);
+    eng_.enter();
     const int W = eng_.graph->hdr.W, k = eng_.graph->hdr.k;
     if (!has(fwd))
         throw StatusError(LDBG_ERR_NOSUCHELEMENT, std::string("No single ") + (fwd ? "advance" : "prev") + " kmer from cursor");
-    rt::stream_t s = eng_.graph->stream;
+    rt::stream_t s = eng_.estream();
     switch (W) {
         case 1: LDBG_LAUNCH(k_cursor_step<1>, 1, 64, s, eng_.view, (CursorStateDev<1>*)impl_->d_state, fwd ? 1 : 0, (uint64_t*)impl_->d_vtab, impl_->vcap, (LsElem*)impl_->d_ls, impl_->ecap); break;
         case 2: LDBG_LAUNCH(k_cursor_step<2>, 1, 64, s, eng_.view, (CursorStateDev<2>*)impl_->d_state, fwd ? 1 : 0, (uint64_t*)impl_->d_vtab, impl_->vcap, (LsElem*)impl_->d_ls, impl_->ecap); break;

@@ -1141,8 +1141,8 @@ LDBG_KERNEL void k_neighbours(DfsArgs a, const uint64_t* words, const uint8_t* v
 }
 
 void Engine::neighbours_batch(const char* kmers, int64_t n, bool forward, int64_t* offsets, uint64_t* kmer_words, int64_t* rec, int64_t capacity) {
-    rt::set_device(graph->device);
-    rt::stream_t s = graph->stream;
+    enter();
+    rt::stream_t s = stream_;
     const int k = graph->hdr.k, W = graph->hdr.W;
     offsets[0] = 0;
     if (n <= 0) return;
@@ -1255,7 +1255,7 @@ void Engine::build_roi_bits() {
     const GraphView& g = graph->view;
     if (rois->hdr.k != graph->hdr.k) throw StatusError(LDBG_ERR_ARG, "the ROI graph must have the k-mer size of the traversed graph");
     if (rois->device != graph->device) throw StatusError(LDBG_ERR_ARG, "the ROI graph must live on the device of the traversed graph");
-    rt::stream_t s = graph->stream;
+    rt::stream_t s = stream_;
     const size_t words = (size_t)((g.N + 31) / 32 + 1);
     d_roi_bits_ = rt::dmalloc(words * 4);
     rt::dmemset(d_roi_bits_, 0, words * 4, s);
@@ -1275,7 +1275,7 @@ void Engine::build_roi_bits() {
 
 DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, const int64_t* sink_offsets, const ShardedRun* sharded) {
     if (cfg.connect_all_neighbors) throw StatusError(LDBG_ERR_UNSUPPORTED, "dfs_batch: connectAllNeighbors is not supported on the device path");
-    rt::set_device(graph->device);
+    enter();
     materialize_pending();            // (the path pool is about to be reused: walks of the last batch keep their vertex lists)
     if (!sharded) build_roi_bits();      // (over an image the rules ask the ROI graph itself)
     const int k = graph->hdr.k, W = graph->hdr.W;
@@ -1311,7 +1311,7 @@ DfsBatch* Engine::dfs_batch(const char* sources, int64_t n, const char* sinks, c
 bool Engine::dfs_chunk(const std::vector<uint64_t>& seed_words, const std::vector<uint64_t>& sink_words, const int64_t* sink_offsets,
                        int64_t first, int64_t n, DfsBatch& out, const ShardedRun* sharded) {
     const int W = graph->hdr.W, C = graph->hdr.C;
-    rt::stream_t s = graph->stream;
+    rt::stream_t s = stream_;
     const int64_t ns = 2 * n;
     // a strand's visited table holds the vertices of one root-to-leaf chain of branches
     const uint64_t chain = std::min<uint64_t>((uint64_t)(cfg.max_branch_length + 12) * 64ull, (uint64_t)graph->view.N * 2 + 64);

@@ -106,6 +106,8 @@ public:
     void walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len);
     void walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index);
     void clear_batch();
+    void enter();                                                // entry of a call that queues device work (device, graph-stream work complete)
+    rt::stream_t estream() const { return stream_; }            // the stream this engine's work is queued on
     void quiesce() noexcept;                                     // waits for the streams this engine has work on (before blocks go back to rt::tfree)
     void walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, uint8_t* has_null);
     // walk_batch_run over the local image of a hash-sharded table, one bulk-synchronous round at a time (image.h): begin with the
@@ -129,6 +131,7 @@ public:
     uint32_t link_store_capacity = 64;
 
 private:
+    rt::stream_t stream_ = nullptr, own_stream_ = nullptr;       // own_stream_: created by this engine (resident tables); else the graph's
     // per-slot scratch kept across batches: visited tables, link stores, table generations
     void* d_vpool_ = nullptr; void* d_ls_ = nullptr; void* d_snap_ = nullptr;
     void* d_pool_ = nullptr; void* d_block_table_ = nullptr;

@@ -877,6 +877,7 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     if (!c.graph) throw StatusError(LDBG_ERR_CORTEXJDK, "Must provide graph to traverse.");
     graph = (const Graph*)c.graph;
     rois = (const Graph*)c.rois;
+    stream_ = graph->stream;           // (replaced by the engine's own stream at the end of the constructor)
     const int nc = graph->hdr.C;
     auto fail = [&](const char* what, int col) {
         throw StatusError(LDBG_ERR_CORTEXJDK, std::string(what) + " colors must be between 0 and " + std::to_string(nc) + " (provided " + std::to_string(col) + ")");
@@ -918,16 +919,34 @@ Engine::Engine(const ldbg_engine_config& c) : cfg(c) {
     view.link_flag_mask = merged_->flag_mask;
     // ec.getLinks().isEmpty() (not "my links") decides whether dfs uses the cursor (:363, :379)
     view.cursor_on = c.nlinks > 0 ? 1 : 0;
+    // Every engine over a resident table has its own HIP stream: engines on one graph, driven by different host threads, run side by side —
+    // a walk launch is bound by its longest strands, and the compute units its early finishers leave idle take the next
+    // batch of another engine.  (An engine over the image of a sharded table stays on that graph's stream: its rounds are ordered with
+    // the collectives by the caller's stream.)
+    if (!graph->is_image) {
+        rt::set_device(graph->device);
+        rt::stream_sync(graph->stream);
+        own_stream_ = rt::stream_create();
+        if (own_stream_) stream_ = own_stream_;
+    }
+}
+// entry of every call that queues device work: this engine's device, and whatever the graph's own stream still holds (a link set bound a
+// moment ago, the neighbour index) is complete before this engine's stream goes on
+void Engine::enter() {
+    rt::set_device(graph->device);
+    if (stream_ != graph->stream) rt::stream_sync(graph->stream);
 }
 
-Engine::~Engine() { sharded_abort(); clear_batch(); drop_batch_seeds(); drop_spares(); rt::hfree_pinned(h_small_); rt::hfree_pinned(h_log_); rt::hfree_pinned(h_stage_[0]); rt::hfree_pinned(h_stage_[1]); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_); }
+Engine::~Engine() { if (own_stream_) { try { rt::set_device(graph->device); } catch (...) {} }
+                    sharded_abort(); clear_batch(); drop_batch_seeds(); drop_spares(); rt::hfree_pinned(h_small_); rt::hfree_pinned(h_log_); rt::hfree_pinned(h_stage_[0]); rt::hfree_pinned(h_stage_[1]); release_scratch(); rt::dfree(d_frames_); rt::dfree(d_roi_bits_); rt::dfree(d_roi_of_);
+                    if (own_stream_) { quiesce(); rt::stream_destroy(own_stream_); } }
 
 // ROI hits of the walks of the last batch: offsets[n+1] into hits (ROI record numbers, order within a walk arbitrary),
 // has_null[i] = the dfs graph of seed i holds a vertex without a record
 void Engine::walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, uint8_t* has_null) {
     if (!rois) throw StatusError(LDBG_ERR_ARG, "walk_roi_hits: the engine has no ROI graph");
-    rt::set_device(graph->device);
-    rt::stream_t s = graph->stream;
+    enter();
+    rt::stream_t s = stream_;
     const int W = graph->hdr.W;
     if (!d_roi_of_) {
         if (rois->hdr.k != graph->hdr.k) throw StatusError(LDBG_ERR_ARG, "the ROI graph must have the k-mer size of the traversed graph");
@@ -988,7 +1007,7 @@ void Engine::walk_roi_hits(int64_t* offsets, uint32_t* hits, int64_t capacity, u
 
 void Engine::ensure_run_index() {
     if (runs_ || getenv("LDBG_NO_RUNS") || !(view.g.k & 1) || graph->is_image) return;
-    runs_.reset(new RunIndex(view, graph->device, graph->stream));
+    runs_.reset(new RunIndex(view, graph->device, stream_));
     profile_add("run_index", runs_->build_ms);
     if (getenv("LDBG_HOST_TIMES"))
         fprintf(stderr, "[ldbg] run index: %lld chains hold %lld of %lld records, built in %.1f ms\n", (long long)runs_->n_chains,
@@ -998,8 +1017,8 @@ void Engine::ensure_run_index() {
 // the dense 8-byte vertex entries of a chunk's walks, expanded from the stored paths the first time they are needed
 void Engine::ensure_dense(WalkChunk& c) {
     if (!c.dense_pending) return;
-    rt::set_device(graph->device);
-    rt::stream_t s = graph->stream;
+    enter();
+    rt::stream_t s = stream_;
     const int64_t ns = 2 * c.n;
     c.d_path = result_alloc((size_t)std::max<int64_t>(1, c.total_entries) * 8, &c.path_cap);
     unsigned* d_ovf = (unsigned*)rt::dmalloc(4);
@@ -1040,7 +1059,7 @@ LDBG_KERNEL void k_path_lengths(const uint64_t* pool, const uint32_t* block_tabl
     }
 }
 void Engine::launch_path_lengths(const uint32_t* d_strand_c, int64_t n_strands, int max_blocks, uint32_t* d_len) {
-    LDBG_LAUNCH(k_path_lengths, grid_for(n_strands * 64, LDBG_STREAM_BLOCK, LDBG_STREAM_GRID), LDBG_STREAM_BLOCK, graph->stream, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
+    LDBG_LAUNCH(k_path_lengths, grid_for(n_strands * 64, LDBG_STREAM_BLOCK, LDBG_STREAM_GRID), LDBG_STREAM_BLOCK, stream_, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
                 d_strand_c, n_strands, d_len);
 }
 void Engine::launch_expand_paths(const uint32_t* d_strand_c, const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks, const RunIndexView& runs,
@@ -1049,11 +1068,11 @@ void Engine::launch_expand_paths(const uint32_t* d_strand_c, const int64_t* d_st
     xa.pool = (const uint64_t*)d_pool_; xa.block_table = (const uint32_t*)d_block_table_; xa.max_blocks = max_blocks;
     xa.strand_c = d_strand_c; xa.strand_off = d_strand_off; xa.n_strands = n_strands;
     xa.runs = runs; xa.dense = d_dense; xa.overflow = d_overflow;
-    LDBG_LAUNCH(k_expand_paths, grid_for(n_strands * 64, LDBG_STREAM_BLOCK, LDBG_STREAM_GRID), LDBG_STREAM_BLOCK, graph->stream, xa);
+    LDBG_LAUNCH(k_expand_paths, grid_for(n_strands * 64, LDBG_STREAM_BLOCK, LDBG_STREAM_GRID), LDBG_STREAM_BLOCK, stream_, xa);
 }
 
 void Engine::launch_compact_paths(const int64_t* d_strand_off, int64_t n_strands, uint64_t* d_dense, int max_blocks) {
-    LDBG_LAUNCH(k_compact_paths, grid_for(n_strands * 64, 256, 4096), 256, graph->stream, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
+    LDBG_LAUNCH(k_compact_paths, grid_for(n_strands * 64, 256, 4096), 256, stream_, (const uint64_t*)d_pool_, (const uint32_t*)d_block_table_, max_blocks,
                 d_strand_off, n_strands, d_dense);
 }
 
@@ -1114,8 +1133,8 @@ void Engine::drop_spares() {
 // has work on (hipFree used to do that by itself).  Idle streams: microseconds.
 void Engine::quiesce() noexcept {
     try {
-        rt::stream_sync(graph->stream);
-        if (sharded_run_ && sharded_stream_ && sharded_stream_ != graph->stream) rt::stream_sync(sharded_stream_);
+        rt::stream_sync(stream_);
+        if (sharded_run_ && sharded_stream_ && sharded_stream_ != stream_) rt::stream_sync(sharded_stream_);
     } catch (...) {}
 }
 void Engine::clear_batch() {
@@ -1142,7 +1161,7 @@ uint32_t vt_initial_entries() {
 }
 
 void Engine::ensure_scratch(int64_t ns, uint32_t ecap, int max_blocks, uint64_t table_floor, bool small) {
-    rt::stream_t s = graph->stream;
+    rt::stream_t s = stream_;
     // small: the pools of a walk with the run index — a strand's table holds fringes and junction vertices, its path a few descriptors per
     // stretch — start at a fraction of the worst case (reserving the worst case was 200 GB of hipMalloc: 1.8 s of a 3.7 s first batch)
     // and are enlarged x4 by walk_batch_run when a batch does run out (ST_POOL_FULL: the batch is walked again, nothing is traded)
@@ -1188,7 +1207,7 @@ struct HostLaps {
 // the seeds of a batch go to the device as they are (n x k ASCII bytes; nothing to copy when the caller's seeds are there already) and
 // become packed words there: on the host that conversion was 0.5 ms of a 7 ms step at C3
 void Engine::seeds_to_device(const char* seeds, int64_t n, bool seeds_on_device) {
-    rt::stream_t s = graph->stream;
+    rt::stream_t s = stream_;
     const int k = graph->hdr.k, W = graph->hdr.W;
     drop_batch_seeds();
     d_batch_words_ = rt::tmalloc((size_t)std::max<int64_t>(1, n) * W * 8);
@@ -1211,7 +1230,7 @@ void Engine::walk_batch_run(const char* seeds, int64_t n, int64_t* total_bytes, 
     if (cfg.stopping_rule != LDBG_STOP_CONTIG || cfg.connect_all_neighbors)
         throw StatusError(LDBG_ERR_UNSUPPORTED, "walk_batch runs ContigStopper without connectAllNeighbors; use dfs_batch for other rules");
     if (cfg.n_secondary > 0) throw StatusError(LDBG_ERR_UNSUPPORTED, "secondary colours are not supported by walk_batch");
-    rt::set_device(graph->device);
+    enter();
     HostLaps laps;
     clear_batch();
     laps.lap("clear_batch");
@@ -1274,7 +1293,7 @@ struct WalkRun {
     const int max_blocks = (r).max_blocks; const uint32_t vcap_max = (r).vcap_max; (void)vcap_max; \
     uint32_t*& d_strand_n = (r).d_strand_n; uint32_t*& d_strand_c = (r).d_strand_c; uint32_t*& d_retry = (r).d_retry; uint32_t*& d_status = (r).d_status; \
     uint32_t*& d_iters = (r).d_iters; uint8_t*& d_quirk = (r).d_quirk; uint8_t*& d_seed_valid = (r).d_seed_valid; unsigned long long*& d_ctr = (r).d_ctr; \
-    (void)d_retry; (void)d_seed_valid; rt::stream_t s = graph->stream; auto free_tmp = [&] { (r).free_tmp(); }; (void)free_tmp
+    (void)d_retry; (void)d_seed_valid; rt::stream_t s = stream_; auto free_tmp = [&] { (r).free_tmp(); }; (void)free_tmp
 
 static void launch_k_walk(const WalkRun& r, const WalkArgs& a, rt::stream_t s) {
     const int block = r.block, grid = r.grid;
@@ -1422,7 +1441,7 @@ void Engine::walk_prepare(int64_t first_, int64_t n_, WalkRun& r, ShardImage* im
 
 // one launch of the walk kernel: the whole batch for a resident table, one bulk-synchronous round on an image
 void Engine::walk_launch(WalkRun& r) {
-    rt::stream_t s = graph->stream;
+    rt::stream_t s = stream_;
     r.ev0.record(s);
     launch_k_walk(r, r.a, s);
     r.ev1.record(s);
@@ -1673,17 +1692,17 @@ void Engine::sharded_walk_begin(ShardImage& img, const char* seeds, int64_t n, c
     if (cfg.stopping_rule != LDBG_STOP_CONTIG || cfg.connect_all_neighbors || cfg.n_secondary > 0)
         throw StatusError(LDBG_ERR_UNSUPPORTED, "walks over a sharded table run ContigStopper without connectAllNeighbors / secondary colours");
     if (&img.graph() != graph) throw StatusError(LDBG_ERR_ARG, "the engine was not created on this image's graph");
-    rt::set_device(graph->device);
+    enter();
     sharded_abort();
     clear_batch();
     seeds_to_device(seeds, n, false);
     batch_n = n;
     sharded_run_ = new WalkRun;
     sharded_img_ = &img;
-    sharded_stream_ = round_stream ? round_stream : graph->stream;
+    sharded_stream_ = round_stream ? round_stream : stream_;
     try {
         walk_prepare(0, n, *sharded_run_, &img, d_seed_slot);
-        rt::stream_sync(graph->stream);
+        rt::stream_sync(stream_);
     } catch (...) { sharded_abort(); throw; }
 }
 void Engine::sharded_abort() {
@@ -1700,7 +1719,7 @@ void Engine::sharded_abort() {
 // the image's overflow flag (a full image: the caller stops the rounds on every rank, enlarges the image and runs the batch again)
 void Engine::sharded_walk_round(int64_t* d_stats) {
     if (!sharded_run_) throw StatusError(LDBG_ERR_ARG, "sharded_walk_round without sharded_walk_begin");
-    rt::set_device(graph->device);
+    enter();
     WalkRun& r = *sharded_run_;
     rt::stream_t s = sharded_stream_;
     rt::dmemset(r.d_ctr + 4, 0, 8, s);
@@ -1711,7 +1730,7 @@ void Engine::sharded_walk_round(int64_t* d_stats) {
 }
 void Engine::sharded_walk_finish(int64_t* total_bytes, int64_t* traversed) {
     if (!sharded_run_) throw StatusError(LDBG_ERR_ARG, "sharded_walk_finish without sharded_walk_begin");
-    rt::set_device(graph->device);
+    enter();
     WalkRun& r = *sharded_run_;
     rt::stream_sync(sharded_stream_);
     profile_add("walk_rounds", (double)sharded_rounds_);
@@ -1746,7 +1765,7 @@ bool Engine::run_chunk(int64_t first, int64_t n, WalkChunk& out, int64_t* traver
 // buffers instead: chunk i + 1 crosses the bus while a few host threads move chunk i to its place.
 #define LDBG_STAGE_BYTES ((size_t)32 << 20)
 void Engine::download(char* dst, const void* d_src, size_t bytes) {
-    rt::stream_t s = graph->stream;
+    rt::stream_t s = stream_;
     if (bytes == 0) return;
     if (bytes < ((size_t)4 << 20) || rt::host_is_pinned(dst)) { rt::d2h(dst, d_src, bytes, s); rt::stream_sync(s); return; }
     for (int b = 0; b < 2; b++) if (!h_stage_[b]) h_stage_[b] = rt::hmalloc_pinned(LDBG_STAGE_BYTES);
@@ -1775,7 +1794,7 @@ void Engine::download(char* dst, const void* d_src, size_t bytes) {
 // offsets and lengths of a chunk on the host (they are computed and kept on the device, walk_finish)
 void Engine::ensure_host(WalkChunk& c) {
     if (c.host_ready) return;
-    rt::stream_t s = graph->stream;
+    rt::stream_t s = stream_;
     c.strand_off.resize((size_t)(2 * c.n + 1));
     c.contig_off.resize((size_t)(c.n + 1));
     c.walk_len.resize((size_t)c.n);
@@ -1787,7 +1806,7 @@ void Engine::ensure_host(WalkChunk& c) {
 }
 
 void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_t* walk_len) {
-    rt::set_device(graph->device);
+    enter();
     if (offsets || walk_len) for (auto& c : chunks) ensure_host(c);
     if (offsets) {
         int64_t o = 0;
@@ -1807,7 +1826,7 @@ void Engine::walk_batch_fetch(char* arena, int64_t cap, int64_t* offsets, int64_
 }
 
 void Engine::walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_t* words, int64_t* rec, int32_t* copy, int32_t* index) {
-    rt::set_device(graph->device);
+    enter();
     if (walk < 0 || walk >= batch_n) throw StatusError(LDBG_ERR_ARG, "walk index out of range");
     const int W = graph->hdr.W;
     for (auto& c : chunks) {
@@ -1819,7 +1838,7 @@ void Engine::walk_vertices(int64_t walk, int64_t capacity, int64_t* len, uint64_
         if (L == 0) return;
         if (capacity < L) throw StatusError(LDBG_ERR_CAPACITY, "vertex buffers too small: need " + std::to_string(L));
         ensure_dense(c);
-        rt::stream_t s = graph->stream;
+        rt::stream_t s = stream_;
         uint64_t* d_words = (uint64_t*)rt::dmalloc((size_t)L * W * 8);
         int64_t* d_rec = (int64_t*)rt::dmalloc((size_t)L * 8);
         int32_t* d_copy = (int32_t*)rt::dmalloc((size_t)L * 4);

@@ -246,7 +246,10 @@ typedef struct {
 } ldbg_engine_config;
 void ldbg_engine_config_default(ldbg_engine_config* cfg);
 
-/* TraversalEngineFactory.make()                 J/utils/traversal/TraversalEngineFactory.java:54-88 */
+/* TraversalEngineFactory.make()                 J/utils/traversal/TraversalEngineFactory.java:54-88
+ * Threads: an engine is used by one host thread at a time (as a TraversalEngine object is in the reference: it holds the cursor's
+ * state).  DIFFERENT engines — on one graph or on several — may be used from different host threads at the same time: every engine
+ * over a resident table queues its work on a HIP stream of its own, and batches of two engines overlap on the device. */
 ldbg_status ldbg_engine_create(const ldbg_engine_config* cfg, ldbg_engine** out);
 ldbg_status ldbg_engine_destroy(ldbg_engine* e);
 

@@ -454,6 +454,40 @@ def case_random_walks(orc, lib, tmp, k, seed, with_links, n=1500):
         compare_walks(cs, seeds[:40], trav=[2], links=["kid"], max_len=ML)          # cursor driven, no usable links
 
 
+def case_concurrent_engines(orc, lib, tmp):
+    """two engines on ONE graph, each driven by its own host thread (every engine has its own HIP stream: csrc/walk.cpp, Engine::Engine):
+    walk batches and dfs batches running side by side give what they give one after the other"""
+    import threading
+    rng = random.Random(4711)
+    k = 31
+    base = genome_with_repeats(rng, 6000, n_rep=10, rep_len=(k // 2 + 1, 4 * k), copies=(2, 3))
+    kid = mutate(rng, base, snv=0.01, indel=0.003)
+    rl = 3 * k
+    reads = {"kid": [kid[i:i + rl] for i in range(0, max(1, len(kid) - rl + 1), max(1, rl // 4))] + [kid[-rl:]]}
+    cs = Case(orc, tmp, lib, [("kid", [kid]), ("mom", [base])], k, link_samples=["kid"], reads=reads, name="conc")
+    kmers = cs.all_kmers()
+    batches = [rng.sample(kmers, 400) for _ in range(2)]
+    engines = [cs.engines(trav=[0], links=["kid"], max_len=2000)[1] for _ in range(2)]
+    expect = [engines[0].walk_batch(b) for b in batches]
+    out = [[None] * 6, [None] * 6]
+
+    def work(i):
+        for r in range(6):
+            out[i][r] = engines[i].walk_batch(batches[i])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        for r in range(6):
+            got, wl = out[i][r]
+            assert got == expect[i][0] and (wl == expect[i][1]).all(), (i, r)
+    oe = cs.engines(trav=[0], links=["kid"], max_len=2000)[0]
+    for s, c in list(zip(batches[0], expect[0][0]))[:40]:
+        assert c == oe.walk(s)[0]
+
+
 def case_dense_cycles(orc, lib, tmp, seed):
     """tiny k on a low-complexity genome: junctions and cycles everywhere"""
     rng = random.Random(seed)

@@ -270,3 +270,6 @@ def test_small_visited_tables(orc, lib, tmp_path, monkeypatch):
     pc.case_dense_cycles(orc, lib, tmp_path, 2)
     pc.case_dfs_dense(orc, lib, tmp_path, 3)
     pc.case_dfs_rules(orc, lib, tmp_path, 31, 2, True)
+
+
+def test_concurrent_engines(orc, lib, tmp_path): pc.case_concurrent_engines(orc, lib, tmp_path)
