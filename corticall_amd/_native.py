@@ -12,9 +12,9 @@ LIB_PATH = os.path.join(_HERE, "_build", "libldbg.so")
 if os.environ.get("LDBG_DIAG_LIB") == "1":
     # the same sources built with the walk kernel's timers compiled in (make -C corticall_amd/csrc diag): profiling sessions only (tools/)
     LIB_PATH = os.path.join(_HERE, "_build_diag", "libldbg.so")
-elif os.environ.get("LDBG_DIAG_LIB") == "variant":
-    # a tuning variant (make -C corticall_amd/csrc variant VARIANT_FLAGS=...): experiments of tools/ only
-    LIB_PATH = os.path.join(_HERE, "_build_variant", "libldbg.so")
+elif os.environ.get("LDBG_DIAG_LIB", "").startswith("variant"):
+    # a tuning variant (make -C corticall_amd/csrc variant VARIANT_FLAGS=...; copies kept as _build_variantNAME): experiments of tools/ only
+    LIB_PATH = os.path.join(_HERE, "_build_" + os.environ["LDBG_DIAG_LIB"], "libldbg.so")
 
 LDBG_OK = 0
 STATUS_NAMES = {
