@@ -211,7 +211,7 @@ def bench_c2(args, ca, rank, local_rank, world, dist):
         print(json.dumps({
             "metric": "random-access lookups/sec (configs[1]; not the headline metric)", "value": world * n * args.steps / max_dt, "unit": "lookups/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "library": ca.default_lib().dll.ldbg_version().decode(),
             "config": {"workload": "configs[1]: synthetic 10 Mb 1-colour k=31 graph, %d lookups per step and GPU (50%% present)%s"
                                    % (n, ", table hash-sharded over the ranks, all-to-all routed" if args.sharded else ""),
                        "records": N, "found": found},
@@ -464,7 +464,7 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
             "metric": "k-mers traversed/sec (whole node) + contigs/sec, k=47 3-color LdBG",
             "value": tot_trav / max_dt, "unit": "k-mers traversed/s", "contigs_per_s": tot_seeds / max_dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": max_dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "library": ca.default_lib().dll.ldbg_version().decode(),
             "config": {
                 "workload": ("configs[3]: same %.1f Mb 3-colour k=%d LdBG with child links; dfs with %s, FORWARD, from %d seeds per GPU "
                              "to the child k-mer 200-2000 bp downstream on the seed's contig; timed: the C-ABI call (kernel, log expansion and download, "
@@ -788,6 +788,10 @@ def main():
                 "bound": "hbm", "kernel": "k_walk<%d>" % W, "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": model_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": avg_ms, "launches": walk_launches,
+                "aggregate": {"achieved": model_bytes * walk_launches / dt / 1e9 if dt > 0 else None,
+                              "frac": model_bytes * walk_launches / dt / 1e9 / HBM_PEAK_GBS if dt > 0 else None,
+                              "note": "the model bytes of ALL launches of the timed region / its wall time: with engines in flight launches overlap, and "
+                                      "each waits for compute units inside its own HIP events (`achieved` / `frac` above are per launch, as measured)"},
                 "model": {
                     "bytes_per_launch": model_bytes, "bytes_per_step_kind": B,
                     "per_launch": {"run_steps": kinds["steps_run"], "vertices_crossed_by_run_steps": kinds["run_vertices"], "lean_steps": kinds["steps_lean"],

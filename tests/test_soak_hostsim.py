@@ -1,6 +1,6 @@
 """Seed sweep of the randomised parity cases on the host simulation: the state space of run steps, merged graph sizes and repeat
 detection is larger than the 7-10 seeds per case the parity suites hold (round 2's only parity bug — a RUN descriptor counted as one
-vertex in a sibling's merged size — appeared at seed 109 of a sweep).  CI runs LDBG_SOAK_SEEDS seeds per case (default 6, beyond the
+vertex in a sibling's merged size — appeared at seed 109 of a sweep).  CI runs LDBG_SOAK_SEEDS seeds per case (default 3, beyond the
 seeds of tests/test_hostsim_parity.py) in a few worker processes; the round's full sweep is LDBG_SOAK_SEEDS=64 (profiles/r03_soak_hostsim.log)."""
 import os
 import pathlib
@@ -10,7 +10,7 @@ from concurrent.futures import ProcessPoolExecutor
 
 import pytest
 
-SEEDS = int(os.environ.get("LDBG_SOAK_SEEDS", "6"))
+SEEDS = int(os.environ.get("LDBG_SOAK_SEEDS", "3"))
 FIRST = int(os.environ.get("LDBG_SOAK_FIRST", "200"))
 WORKERS = max(1, min(8, (os.cpu_count() or 2) // 2))
 CASES = ("run_steps", "dfs_run_steps", "dense_cycles", "dfs_dense", "random_walks", "facade")
