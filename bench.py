@@ -421,16 +421,43 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
     eng = (TraversalEngineFactory().traversalColors(g.getColorForSampleName("child")).traversalDirection(FORWARD)
            .combinationOperator(OR).stoppingRule(args.stopper).maxBranchLength(args.max_len).graph(g).links(links).make())
     n = len(seeds)
-    for _ in range(args.warmup):
-        eng.dfs_batch_arrays(src, n, sink_buf, sink_off)
+    # --in-flight N: N engines on the one graph (own HIP stream and host thread each) take the calls in turn, as for the walks
+    engines = [eng]
+    for _ in range(max(1, args.in_flight) - 1):
+        engines.append(TraversalEngineFactory().traversalColors(g.getColorForSampleName("child")).traversalDirection(FORWARD)
+                       .combinationOperator(OR).stoppingRule(args.stopper).maxBranchLength(args.max_len).graph(g).links(links).make())
+    for _ in range(max(1, args.warmup)):
+        for e2 in engines:
+            e2.dfs_batch_arrays(src, n, sink_buf, sink_off)
+
+    def run_calls(engs, n_calls):
+        import threading
+        trav, last = [0] * len(engs), [None] * len(engs)
+
+        def work(i):
+            for _ in range(i, n_calls, len(engs)):
+                last[i] = engs[i].dfs_batch_arrays(src, n, sink_buf, sink_off)
+                trav[i] += engs[i].dfs_kmers_traversed
+        if len(engs) == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(i,)) for i in range(len(engs))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        return sum(trav), next(x for x in last if x is not None)
+
+    sync()
+    t0 = time.time()
+    run_calls(engines[:1], args.steps)
+    sync()
+    dt_single = time.time() - t0
     ca.profile_reset()
     sync()
     t0 = time.time()
-    traversed = 0
     found = 0
-    for _ in range(args.steps):
-        b = eng.dfs_batch_arrays(src, n, sink_buf, sink_off)
-        traversed += eng.dfs_kmers_traversed
+    traversed, b = run_calls(engines, args.steps)
     sync()
     dt = time.time() - t0
     dfs_ms, launches = ca.profile_get("dfs")
@@ -477,6 +504,9 @@ def bench_c4(args, ca, g, links, walk_eng, seeds, st, prefix, rank, world, dist,
             "roofline": {"bound": "hbm", "kernel": "k_dfs<%d>" % W, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_kmer": b_find + b_link,
                          "avg_launch_ms": avg_ms, "launches": launches},
+            "single_batch": {"ms_per_step": dt_single / args.steps * 1e3, "contigs_per_s": n * args.steps / dt_single if dt_single > 0 else None,
+                             "note": "the same calls one at a time on one engine"},
+            "batches_in_flight": len(engines),
             "with_graphs_fetched": {"ms_per_step": dt_fetched * 1e3, "value": (traversed / args.steps) / dt_fetched,
                                     "note": "one call + unpacking every graph of the batch + k-mers and coverages of all their vertices gathered from the device"},
         }
