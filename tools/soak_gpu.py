@@ -26,6 +26,7 @@ for seed in range(first, first + count):
                      ("findtips", lambda t: pc.case_findtips(orc, lib, t, k, seed, seed % 2 == 0)),
                      ("partition", lambda t: pc.case_partition(orc, lib, t, r.choice([21, 31, 47]), seed, seed % 2 == 1)),
                      ("dfs_rules", lambda t: pc.case_dfs_rules(orc, lib, t, r.choice([21, 31]), seed, seed % 2 == 0)),      # (k = 9: some rules fork without end in the checker too)
+                     ("facade", lambda t: pc.case_facade(orc, lib, t, r.choice([21, 31, 47]), seed, seed % 2 == 0)),
                      ("random_walks", lambda t: pc.case_random_walks(orc, lib, t, r.choice([21, 31, 47, 64]), seed, seed % 2 == 0))):
         tmp = pathlib.Path(tempfile.mkdtemp(prefix="soak_"))
         try:
