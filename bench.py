@@ -576,8 +576,8 @@ WALK_STEP_BYTES = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--genome-len", type=int, default=GENOME_LEN)
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--seeds", type=int, default=N_SEEDS)
