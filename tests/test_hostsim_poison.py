@@ -25,10 +25,10 @@ lanes = int(sys.argv[1])
 lib = hostsim.load(rebuild=False) if lanes == 1 else hostsim.load_wavefront(lanes, rebuild=False)
 tmp = lambda: pathlib.Path(tempfile.mkdtemp(prefix="poison_"))
 pc.case_run_steps(orc, lib, tmp(), 201)
-pc.case_random_walks(orc, lib, tmp(), 31, 4, True)
 pc.case_dense_cycles(orc, lib, tmp(), 2)
-pc.case_dfs_dense(orc, lib, tmp(), 1)
-if lanes == 1:
+if lanes == 1:          # (the lock-step run keeps to the two cases above: a fibre switch per lane and primitive)
+    pc.case_random_walks(orc, lib, tmp(), 31, 4, True)
+    pc.case_dfs_dense(orc, lib, tmp(), 1)
     pc.case_dfs_run_steps(orc, lib, tmp(), 231)
     pc.case_facade(orc, lib, tmp(), 31, 3, True)
 print("poison ok", lanes)
