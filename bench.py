@@ -585,6 +585,7 @@ def main():
     ap.add_argument("--repeat-families", type=int, default=4000)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-timed", action="store_true", help="c3: skip the side measurements (single_batch, host_seeds, with_contigs_fetched): for runs under a profiler")
     ap.add_argument("--lookups", type=int, default=100000, help="c2: lookups per step (configs[1] says 100k)")
     ap.add_argument("--sharded", action="store_true", help="hash-shard the table over the ranks: c2 routes lookups with all-to-all, c3 walks over local images of the table")
     ap.add_argument("--sharded-seeds", type=int, default=50000, help="--sharded: seeds per GPU and step")
@@ -713,10 +714,12 @@ def main():
         return sum(trav)
 
     # one batch at a time first (the latency of a step, the kernel durations without a neighbour): reported as `single_batch`
+    # (--only-timed: profiling runs — the kernel trace of the process is then the timed region's launches and little else)
+    side = 0 if args.only_timed else args.steps
     ca.profile_reset()
     sync()
     t0 = time.time()
-    run_steps(engines[:1], args.steps)
+    run_steps(engines[:1], side)
     sync()
     dt_single = time.time() - t0
     single_walk_ms, single_launches = ca.profile_get("walk")
@@ -736,25 +739,26 @@ def main():
     # the same steps with the seeds handed over in host memory (n x k ASCII bytes of an ordinary numpy array)
     sync()
     t1 = time.time()
-    for _ in range(args.steps):
+    for _ in range(side):
         eng.walk_batch_arrays(seeds, fetch=False)
     sync()
     dt_host_seeds = time.time() - t1
     # the same steps with every contig downloaded to the caller (what the reference's walk() hands over): reported beside `value`
-    eng.walk_batch_arrays(seeds, fetch=True, pinned=True)        # (the page-locked arena is allocated once, like every other buffer of the engine)
+    if side:
+        eng.walk_batch_arrays(seeds, fetch=True, pinned=True)        # (the page-locked arena is allocated once, like every other buffer of the engine)
     sync()
     t1 = time.time()
     fetched_bytes = 0
-    for _ in range(args.steps):
+    for _ in range(side):
         arena, _, _ = eng.walk_batch_arrays(seeds, fetch=True, pinned=True)
         fetched_bytes += len(arena)
     sync()
     dt_fetch = time.time() - t1
     t1 = time.time()
-    for _ in range(min(3, args.steps)):
+    for _ in range(min(3, side)):
         eng.walk_batch_arrays(seeds, fetch=True)               # into a fresh pageable array: staged through page-locked buffers by the library
     sync()
-    dt_fetch_pageable = (time.time() - t1) / min(3, args.steps)
+    dt_fetch_pageable = (time.time() - t1) / max(1, min(3, side))
 
     tot_trav, tot_seeds, max_dt = traversed, len(seeds) * args.steps, dt
     if dist is not None:
@@ -858,6 +862,9 @@ def main():
                                      "pageable_ms_per_step": dt_fetch_pageable * 1e3,
                                      "pageable_note": "the same into a fresh pageable array (staged through the library's page-locked buffers)"},
         }
+        if args.only_timed:
+            for key in ("single_batch", "host_seeds", "with_contigs_fetched"):
+                out[key] = {"skipped": "--only-timed"}
         if not args.no_cpu_baseline:
             pick = np.random.default_rng(20261004).choice(len(seeds), min(2000, len(seeds)), replace=False)
             contigs, _ = eng.walk_batch(seeds[pick])

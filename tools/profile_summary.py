@@ -51,7 +51,7 @@ for sub in ("fetch", "write", "sq1", "sq2", "sq3"):
             continue
         pmc.setdefault((k, r.get("Counter_Name", "?")), []).append(float(r.get("Counter_Value", "0")))
 with open(os.path.join(out_dir, "%s_pmc.log" % tag), "w") as f:
-    f.write("# tools/profile_walk.sh %s: rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline ; one pass per counter set\n" % tag)
+    f.write("# tools/profile_walk.sh %s: rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline --only-timed (c2 passes: tools/profile_find.sh) ; one pass per counter set\n" % tag)
     f.write("# kernel counter dispatches mean_per_dispatch (FETCH_SIZE / WRITE_SIZE in KB)\n")
     for (k, c), v in sorted(pmc.items()):
         f.write("%s %s %d %.3f\n" % (k, c, len(v), sum(v) / len(v)))

@@ -7,7 +7,9 @@ TAG=${1:-r02}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 set -e
-B="python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline $*"
+# --only-timed: the process's kernel trace is then the timed region (engines in flight) + two warm-up batches per engine, so that the
+# per-kernel averages of the trace are those of the region bench.py's own HIP events time
+B="python3 $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --only-timed $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_kt -o kt -- $B > $R/gpurun_out/prof_${TAG}_kt_bench.log 2>&1
 echo kt done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -o f -- $B > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1
