@@ -486,6 +486,16 @@ def case_concurrent_engines(orc, lib, tmp):
     oe = cs.engines(trav=[0], links=["kid"], max_len=2000)[0]
     for s, c in list(zip(batches[0], expect[0][0]))[:40]:
         assert c == oe.walk(s)[0]
+    # the same through the host mirror's EnginePool: five batches dealt out to two engines, results in the order of the batches
+    pool = (TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).maxBranchLength(2000).stoppingRule(ContigStopper)
+            .links(cs.links["kid"]).make_pool(2))
+    more = [batches[0], batches[1], batches[1][:50], batches[0][:7], batches[1]]
+    res = pool.walk_batches(more)
+    assert len(res) == 5
+    for b, (got, wl) in zip(more, res):
+        ref_c, ref_wl = engines[0].walk_batch(b)
+        assert got == ref_c and (wl == ref_wl).all()
+    pool.close()
 
 
 def case_dense_cycles(orc, lib, tmp, seed):

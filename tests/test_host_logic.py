@@ -17,3 +17,30 @@ def test_java_hashmap_order_matches_an_emulated_hashmap():
         assert list(java_hashmap_order(np.array(hashes, dtype=np.uint32))) == m.keys(), n
     # Arrays.hashCode(byte[]) of ASCII k-mers: "abc" -> 126145 (the value the reference's JVM gives)
     assert int(java_bytes_hash(np.frombuffer(b"abc", dtype=np.uint8).reshape(1, 3))[0]) == 126145
+
+
+def test_engine_pool_deals_items_out_in_order():
+    """EnginePool.map: items dealt out to the engines in turn, one thread per engine, results in item order, a worker's exception raised in
+    the caller (no device needed: the engines are stand-ins)"""
+    from corticall_amd.traversal import EnginePool
+
+    class F:
+        made = 0
+
+        def make(self):
+            F.made += 1
+            return "engine%d" % F.made
+    pool = EnginePool(F(), 3)
+    assert pool.engines == ["engine1", "engine2", "engine3"]
+    out = pool.map(lambda e, x: (e, x * x), range(8))
+    assert [v for _, v in out] == [x * x for x in range(8)]
+    assert [e for e, _ in out] == ["engine%d" % (1 + j % 3) for j in range(8)]
+    assert pool.map(lambda e, x: x, []) == [] and pool.map(lambda e, x: (e, x), [5]) == [("engine1", 5)]
+
+    def boom(e, x):
+        if x == 4:
+            raise ValueError("four")
+        return x
+    import pytest
+    with pytest.raises(ValueError):
+        pool.map(boom, range(6))
