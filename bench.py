@@ -592,7 +592,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="c3: engines (own HIP stream + host thread each) that take the steps in turn; 1 = one batch at a time")
     ap.add_argument("--rows-per-owner", type=int, default=65536, help="--sharded: rows one rank may ask of one owner per round")
     ap.add_argument("--check-every", type=int, default=16, help="--sharded: rounds between two looks at the 'anyone still walking' count")
-    ap.add_argument("--chain-depth", type=int, default=32, help="--sharded: row slots per request (the row asked for + rows around it its owner holds too)")
+    ap.add_argument("--chain-depth", type=int, default=256, help="--sharded: row slots per request (the row asked for + rows around it its owner holds too); "
+                    "the loop iterations a wavefront runs before it ends its round follow it (LDBG_IMG_YIELD, INTEGRATION.md 5) unless the environment sets them: "
+                    "profiles/r03_sharded_round_sweep2.log")
     ap.add_argument("--workload", choices=["c3", "c4", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): link-guided contig walks; c4: DestinationStopper dfs to a sink 200-2000 bp downstream")
     ap.add_argument("--stopper", default="DestinationStopper", help="c4: the stopping rule of the searches (a rule that never fails, like ExplorationStopper, returns every branch it explored: use a small --max-len with it)")
@@ -642,6 +644,8 @@ def main():
     if args.use_seeds:
         seeds = seeds[np.random.default_rng(7).permutation(len(seeds))[:args.use_seeds]]
 
+    if args.sharded:
+        os.environ.setdefault("LDBG_IMG_YIELD", str(max(32, args.chain_depth)))
     if args.workload == "c3" and args.sharded:
         return bench_c3_sharded(args, ca, prefix, st, seeds, rank, local_rank, world, dist)
 
