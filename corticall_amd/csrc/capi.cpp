@@ -66,7 +66,7 @@ ldbg_status ldbg_device_count(int* count) { *count = rt::device_count(); return 
 ldbg_status ldbg_kmer_encode(const char* ascii, int k, uint64_t* words_out) {
     return guard([&] {
         if (k <= 0 || k > 128) throw StatusError(LDBG_ERR_ARG, "bad k");
-        if (!ascii_to_words(ascii, k, words_out, (k + 31) / 32))
+        if (!ascii_to_words_ci(ascii, k, words_out, (k + 31) / 32))        // encodeBinaryKmer takes either case
             throw StatusError(LDBG_ERR_ARG, "Nucleotide is not a valid character nucleotide");
     });
 }

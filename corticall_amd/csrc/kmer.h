@@ -177,17 +177,20 @@ LDBG_HD uint32_t kmer_prefix(const Kmer<W>& a, int k, int p) {
 }
 
 // ---- host-only ASCII conversion -------------------------------------------------------------
-// returns false when the string contains a non-ACGT byte (case-insensitive like charToBinaryNucleotide,
-// CortexRecord.java:347-360)
-inline bool ascii_to_words(const char* s, int k, uint64_t* w, int W) {
+// Two rules, as in the reference.  ENCODING a k-mer (CortexRecord.encodeBinaryKmer -> charToBinaryNucleotide, CortexRecord.java:347-360) takes
+// either case: ascii_to_words_ci, behind ldbg_kmer_encode only.  LOOKING a k-mer UP does not: findRecord(String) compares the query's bytes
+// with the records' upper-case k-mers (CortexGraph.java:272-317), so "acgt…" has no record, exactly like a string with an N (quirk Q4) —
+// every query path (find, walk and dfs seeds, sinks, seek, assemble, neighbours) goes through ascii_to_words / ascii_batch_to_words /
+// walk.cpp: k_seed_words, which accept ACGT only.
+inline bool ascii_to_words_impl(const char* s, int k, uint64_t* w, int W, bool any_case) {
     for (int i = 0; i < W; i++) w[i] = 0;
     for (int i = 0; i < k; i++) {
         uint64_t v;
-        switch (s[i]) {
-            case 'A': case 'a': v = 0; break;
-            case 'C': case 'c': v = 1; break;
-            case 'G': case 'g': v = 2; break;
-            case 'T': case 't': v = 3; break;
+        switch (any_case ? (s[i] & ~0x20) : s[i]) {
+            case 'A': v = 0; break;
+            case 'C': v = 1; break;
+            case 'G': v = 2; break;
+            case 'T': v = 3; break;
             default: return false;
         }
         int bit = 2 * (k - 1 - i);
@@ -195,13 +198,15 @@ inline bool ascii_to_words(const char* s, int k, uint64_t* w, int W) {
     }
     return true;
 }
+inline bool ascii_to_words(const char* s, int k, uint64_t* w, int W) { return ascii_to_words_impl(s, k, w, W, false); }
+inline bool ascii_to_words_ci(const char* s, int k, uint64_t* w, int W) { return ascii_to_words_impl(s, k, w, W, true); }
 // the same for a batch of n k-mers of k bytes each (seeds of a walk / dfs batch): table lookup, one shift-or per base, a few
 // threads for large batches.  valid[q] = 1 where string q is a k-mer over ACGT, 0 otherwise (findRecord then misses, quirk Q4):
 // validity travels beside the words — at k = 32, 64, 96, 128 every bit pattern of the words is a k-mer, none is left for a mark.
 inline void ascii_batch_to_words(const char* s, int64_t n, int k, int W, uint64_t* words, uint8_t* valid) {
     static const struct Lut {
         uint8_t v[256];
-        Lut() { for (int i = 0; i < 256; i++) v[i] = 0x80; v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; }
+        Lut() { for (int i = 0; i < 256; i++) v[i] = 0x80; v['A'] = 0; v['C'] = 1; v['G'] = 2; v['T'] = 3; }       // (upper case only: a lookup, see above)
     } lut;
     const int nw = (k + 31) / 32, lead = W - nw;         // words that carry bases; leading all-zero words
     auto run = [&](int64_t lo, int64_t hi) {

@@ -439,12 +439,12 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
         }
         hashset_order(rec.juncs);
         std::vector<uint64_t> w(W), rc(W);
-        if ((int)rec.kmer.size() != k || !ascii_to_words(rec.kmer.c_str(), k, w.data(), W))
+        if ((int)rec.kmer.size() != k || !ascii_to_words_ci(rec.kmer.c_str(), k, w.data(), W))
             throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record: bad k-mer '" + rec.kmer + "'");
         // canonical key (CortexBinaryKmer(byte[]) canonicalises, CortexBinaryKmer.java:17-19)
         std::string rcs(k, 'A');
         for (int i = 0; i < k; i++) { char ch = rec.kmer[k - 1 - i]; rcs[i] = complement_ascii(std::string(1, ch))[0]; }
-        ascii_to_words(rcs.c_str(), k, rc.data(), W);
+        ascii_to_words_ci(rcs.c_str(), k, rc.data(), W);
         by_key[std::min(w, rc)] = rec;
         have = next_line(line);
         while (have && line.empty()) have = next_line(line);
@@ -454,7 +454,7 @@ Links::Links(const std::string& path, const Graph& g) : device(g.device) {
         record_keys.push_back(kv.first);
         records.push_back(kv.second);
         std::vector<uint64_t> w(W);
-        ascii_to_words(kv.second.kmer.c_str(), k, w.data(), W);
+        ascii_to_words_ci(kv.second.kmer.c_str(), k, w.data(), W);
         record_is_canonical.push_back(w == kv.first ? 1 : 0);
     }
     // claim a flag bit in the graph's probe rows and set it on every record that has links here
@@ -588,7 +588,7 @@ int64_t links_index_file(const std::string& in_path, const std::string& out_path
         std::vector<uint64_t> w(W), rc(W);
         std::string rcs(k, 'A');
         for (int i = 0; i < k; i++) rcs[i] = complement_ascii(std::string(1, kv.first[k - 1 - i]))[0];
-        if ((int)kv.first.size() != k || !ascii_to_words(kv.first.c_str(), k, w.data(), W) || !ascii_to_words(rcs.c_str(), k, rc.data(), W))
+        if ((int)kv.first.size() != k || !ascii_to_words_ci(kv.first.c_str(), k, w.data(), W) || !ascii_to_words_ci(rcs.c_str(), k, rc.data(), W))
             throw StatusError(LDBG_ERR_CORTEXJDK, "Unable to parse CortexLinks record: bad k-mer '" + kv.first + "'");
         const std::vector<uint64_t>& cw = std::min(w, rc);
         for (int i = 0; i < W; i++) ix.append((const char*)&cw[i], 8);
@@ -705,10 +705,10 @@ const HostLinksRecord* Links::get(const std::string& kmer_ascii) const {
     if (records.empty() || (int)kmer_ascii.size() != k) return nullptr;
     const int W = (int)record_keys[0].size();
     std::vector<uint64_t> w(W), rc(W);
-    if (!ascii_to_words(kmer_ascii.c_str(), k, w.data(), W)) return nullptr;
+    if (!ascii_to_words_ci(kmer_ascii.c_str(), k, w.data(), W)) return nullptr;
     std::string rcs(k, 'A');
     for (int i = 0; i < k; i++) rcs[i] = complement_ascii(std::string(1, kmer_ascii[k - 1 - i]))[0];
-    ascii_to_words(rcs.c_str(), k, rc.data(), W);
+    ascii_to_words_ci(rcs.c_str(), k, rc.data(), W);
     auto key = std::min(w, rc);
     auto it = std::lower_bound(record_keys.begin(), record_keys.end(), key);
     if (it == record_keys.end() || *it != key) return nullptr;

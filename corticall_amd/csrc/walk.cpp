@@ -360,7 +360,7 @@ LDBG_WAVE_KERNEL_N(BS) void k_walk(WalkArgs a) {
 }
 
 // ---- result assembly -------------------------------------------------------------------------
-// the seeds of a batch: n x k ASCII bytes -> packed words + the Q4 validity byte (a string with a byte outside ACGTacgt is no k-mer: its
+// the seeds of a batch: n x k ASCII bytes -> packed words + the Q4 validity byte (a string with a byte outside ACGT is no record's k-mer: its
 // words are zero and findRecord misses, kmer.h: ascii_batch_to_words is the host form of the same rule)
 LDBG_KERNEL void k_seed_words(const unsigned char* ascii, int64_t n, int k, int W, uint64_t* words, uint8_t* valid) {
     const int nw = (k + 31) / 32, lead = W - nw;         // words that carry bases; leading all-zero words
@@ -374,11 +374,11 @@ LDBG_KERNEL void k_seed_words(const unsigned char* ascii, int64_t n, int k, int 
             uint64_t acc = 0;
             for (int j = 0; j < cnt; j++) {
                 unsigned v = 0;
-                switch (c[i++] | 0x20u) {
-                    case 'a': v = 0; break;
-                    case 'c': v = 1; break;
-                    case 'g': v = 2; break;
-                    case 't': v = 3; break;
+                switch (c[i++]) {                 // upper case only: a seed is looked up, not encoded (kmer.h)
+                    case 'A': v = 0; break;
+                    case 'C': v = 1; break;
+                    case 'G': v = 2; break;
+                    case 'T': v = 3; break;
                     default: bad = true; break;
                 }
                 acc = (acc << 2) | (uint64_t)v;

@@ -532,6 +532,11 @@ class TraversalEngine:
             if r >= 0 and r not in cache:
                 cache[r] = self._graph.getRecord(r)
             out.append(CortexVertex(CortexRecord(words[j], [0], [0], k).getKmerAsString(), cache.get(r)))
+        # the seed vertex carries the string it was given (:115-118); one that is no k-mer over ACGT (an N, lower case: no record, so no
+        # neighbour either) has no packed form to come back in
+        sb = _as_bytes(seed)
+        if len(out) == 1 and out[0].getCortexRecord() is None and any(c not in b"ACGT" for c in sb):
+            out[0] = CortexVertex(sb.decode(), None)
         return out
 
     def dfs_batch(self, sources, sinks=None):

@@ -158,7 +158,13 @@ public class GpuTraversalEngine {
         int n = (int) assemble(handle, seed.getBytes(), 0, null, null);
         long[] words = new long[Math.max(1, n) * w], rec = new long[Math.max(1, n)];
         assemble(handle, seed.getBytes(), n, words, rec);
-        return makeVertices(n, words, rec, new int[Math.max(1, n)], new int[Math.max(1, n)]);
+        List<CortexVertex> vs = makeVertices(n, words, rec, new int[Math.max(1, n)], new int[Math.max(1, n)]);
+        // the seed vertex carries the string it was given (TraversalEngine.java:115-118); one that is no k-mer over ACGT (an N, lower case:
+        // no record, so no neighbour either) has no packed form to come back in
+        if (n == 1 && rec[0] < 0 && !seed.matches("[ACGT]*")) {
+            vs.set(0, new CortexVertexFactory().bases(seed).record(null).make());
+        }
+        return vs;
     }
 
     private DirectedWeightedPseudograph<CortexVertex, CortexEdge> graphOf(long res, long i) {

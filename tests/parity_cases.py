@@ -454,6 +454,61 @@ def case_random_walks(orc, lib, tmp, k, seed, with_links, n=1500):
         compare_walks(cs, seeds[:40], trav=[2], links=["kid"], max_len=ML)          # cursor driven, no usable links
 
 
+def case_lowercase_queries(orc, lib, tmp):
+    """Encoding a k-mer takes either case (CortexRecord.encodeBinaryKmer -> charToBinaryNucleotide, CortexRecord.java:347-360); LOOKING ONE UP
+    compares bytes with the records' upper-case k-mers (CortexGraph.findRecord, :272-317): "acgt…" has no record, like a string with an N.
+    findRecord, walk, dfs sources and sinks, neighbours, assemble and the cursor agree with the oracle on lower- and mixed-case strings —
+    through the host-seed and the device-seed entry of the walks alike."""
+    import ctypes as C
+    rng = random.Random(77)
+    k = 31
+    base = genome_with_repeats(rng, 1500, n_rep=4, rep_len=(k // 2 + 1, 3 * k), copies=(2, 3))
+    kid = mutate(rng, base, snv=0.01, indel=0.0)
+    rl = 3 * k
+    reads = {"kid": [kid[i:i + rl] for i in range(0, max(1, len(kid) - rl + 1), rl // 4)] + [kid[-rl:]]}
+    cs = Case(orc, tmp, lib, [("kid", [kid]), ("mom", [base])], k, link_samples=["kid"], reads=reads, name="lower")
+    kmers = cs.all_kmers()
+    up = [kmers[5], kmers[200], kid[300:300 + k], orc.revcomp(kid[700:700 + k])]
+    qs = []
+    for q in up:
+        qs += [q, q.lower(), q[:7].lower() + q[7:], q[:-1] + q[-1].lower()]
+    # findRecord
+    for q in qs:
+        cr = cs.g.findRecord(q)
+        assert (cr.index if cr is not None else -1) == cs.og.find(q)[0], q
+        assert (cr is None) == (q != q.upper())
+    # encodeBinaryKmer: either case, the same words
+    for q in up:
+        w1, w2 = (C.c_uint64 * 4)(), (C.c_uint64 * 4)()
+        lib.check(lib.dll.ldbg_kmer_encode(q.encode(), k, w1))
+        lib.check(lib.dll.ldbg_kmer_encode(q.lower().encode(), k, w2))
+        assert list(w1)[:1] == list(w2)[:1] == orc.encode_kmer(q) == orc.encode_kmer(q.lower())
+    # walks (compare_walks runs the host-seed and the device-seed entry), with and without links
+    compare_walks(cs, qs, trav=[0], links=["kid"], max_len=500)
+    compare_walks(cs, qs, trav=[0])
+    # dfs: sources and sinks
+    oe = orc.Engine(cs.og, [0], links=[cs.olinks["kid"]], stopper="DestinationStopper", direction=orc.FORWARD, max_length=300)
+    e = (TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).stoppingRule("DestinationStopper").traversalDirection(FORWARD).maxBranchLength(300)
+         .links(cs.links["kid"]).make())
+    src = kid[100:100 + k]
+    snk = kid[100 + 2 * k:100 + 3 * k]
+    for source, sinks in ((src, [snk]), (src, [snk.lower()]), (src.lower(), [snk]), (src[:3].lower() + src[3:], [snk, snk.lower()])):
+        r = oe.dfs(source, sinks)
+        g = e.dfs(source, *sinks)
+        assert (g is None) == r.is_null, (source, sinks)
+        if g is not None:
+            assert g.vertex_tuples() == r.vertices() and g.edge_tuples() == r.edges(), (source, sinks)
+        r.free()
+    # neighbours, assemble, cursor
+    oc = orc.Engine(cs.og, [0], links=[cs.olinks["kid"]], stopper="ContigStopper")
+    ec = TraversalEngineFactory(lib=lib).traversalColors(0).graph(cs.g).stoppingRule(ContigStopper).links(cs.links["kid"]).make()
+    for q in qs:
+        assert [(v.getKmerAsString(), v.getCortexRecord().index if v.getCortexRecord() is not None else -1) for v in ec.getNextVertices(q)] == oc.next_vertices(q), q
+        assert [(v.getKmerAsString(), v.getCortexRecord().index if v.getCortexRecord() is not None else -1) for v in ec.assemble(q)] == oc.assemble(q, 75000), q
+        ec.seek(q); oc.seek(q)
+        assert ec.hasNext() == oc.has_next(), q
+
+
 def case_concurrent_engines(orc, lib, tmp):
     """two engines on ONE graph, each driven by its own host thread (every engine has its own HIP stream: csrc/walk.cpp, Engine::Engine):
     walk batches and dfs batches running side by side give what they give one after the other"""

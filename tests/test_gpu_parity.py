@@ -273,3 +273,6 @@ def test_small_visited_tables(orc, lib, tmp_path, monkeypatch):
 
 
 def test_concurrent_engines(orc, lib, tmp_path): pc.case_concurrent_engines(orc, lib, tmp_path)
+
+
+def test_lowercase_queries(orc, lib, tmp_path): pc.case_lowercase_queries(orc, lib, tmp_path)

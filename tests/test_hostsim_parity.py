@@ -139,3 +139,6 @@ def test_small_visited_tables(orc, lib, tmp_path, monkeypatch):
     pc.case_random_walks(orc, lib, tmp_path, 31, 5, True, n=600)
     pc.case_dfs_dense(orc, lib, tmp_path, 3)
     pc.case_dfs_rules(orc, lib, tmp_path, 31, 2, True)
+
+
+def test_lowercase_queries(orc, lib, tmp_path): pc.case_lowercase_queries(orc, lib, tmp_path)
